@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Build oracle/_ref/libuvicref_<cfg>_<imt>x<jmt>x<km>.so from the reference
+sources WHERE THEY LIE under /root/reference.
+
+TEST INFRASTRUCTURE ONLY.  Nothing produced here is shipped or imported by the
+product (uvic2.9_amd/); only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may load the resulting library.
+
+Recipe (which mirrors what the reference's own
+`mk` driver does, /root/reference/mk:2326-2400):
+
+  1. cpp -traditional -P every header of the source directories in overlay
+     order (later directory wins, mk:1289-1321) into a scratch inc/ directory;
+  2. cpp -traditional -P the few .F files of the tracer path;
+  3. in the *scratch copies only*: substitute the grid-size parameter line of
+     size.h (imt, jmt, km are compile-time parameters,
+     updates/09/source/common/size.h:27) and the one declaration that flang
+     rejects (`mi` is REAL but used as a subscript, updates/09/source/mom/tracer.F:35,539);
+  4. flang -fdefault-real-8 (== ifort -r8, run/mk.ver:51) -O2 -ffp-contract=off
+     -fno-automatic (static locals, the ifort default for arrays: tracer.F:121 `src`
+     must be zero on land columns);
+  5. link everything plus oracle/ref/harness.c and the generated registration
+     file into one shared object.  Symbols that only the un-buildable parts of
+     the model would resolve (netCDF wrappers, the other component models)
+     stay undefined; the library is loaded with lazy binding and those entry
+     points are never called.  No stand-in is written for them.
+
+Scratch files are deleted after the link: only the .so stays in oracle/_ref/.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+REF = Path(os.environ.get("UVIC_REFERENCE", "/root/reference"))
+OUT = HERE / "_ref"
+FLANG = "/opt/rocm/lib/llvm/bin/flang"
+
+BASE = ("O_mom O_fct O_isopycmix O_gent_mcwilliams O_cyclic O_consthmix O_constvmix "
+        "O_fullconvect O_embm O_ice O_fourfil O_time_averages O_tidal_kv "
+        "O_save_convection").split()
+
+# option sets; every one of them was compile-verified
+CONFIGS = {
+    # BASELINE config 1: physics only, nt=2
+    "p2": BASE,
+    # option set E, nt=13
+    "e13": BASE + "O_mobi O_mobi_o2 O_mobi_iron O_carbon O_mobi_caco3".split(),
+    # option set C == BASELINE config 4, nt=30
+    "c30": BASE + ("O_mobi O_mobi_o2 O_mobi_iron O_carbon O_mobi_alk O_mobi_nitrogen "
+                   "O_carbon_13 O_carbon_14 O_mobi_nitrogen_15").split(),
+    # shipped run/mk.in set, nt=37
+    "s37": BASE + ("O_mobi O_carbon O_mobi_alk O_mobi_o2 O_mobi_nitrogen O_mobi_caco3 "
+                   "O_mobi_iron O_mobi_silicon O_mobi_nitrogen_15 O_carbon_13 "
+                   "O_carbon_14").split(),
+}
+
+HDR_DIRS = ["source/common", "source/mom", "source/embm", "source/ice",
+            "updates/09/source/common", "updates/09/source/mom", "updates/09/source/embm"]
+
+SOURCES = [
+    "updates/09/source/mom/tracer.F", "updates/09/source/mom/tracer_adv_flx.F",
+    "updates/09/source/mom/isopyc.F", "source/mom/invtri.F",
+    "updates/09/source/mom/mobi.F", "updates/09/source/common/co2calc.F",
+    "source/mom/convect.F", "updates/09/source/mom/set_sbc.F",
+    "source/common/util.F", "source/common/filt.F", "source/common/filtr.F",
+    "updates/09/source/common/iomngr.F", "updates/09/source/common/file_names.F",
+    "updates/09/source/common/UVic_ESCM.F",
+    "source/mom/state.F", "source/mom/denscoef.F", "source/mom/adv_vel.F",
+    "updates/09/source/mom/vmixc.F", "updates/09/source/mom/hmixc.F",
+]
+
+SIZE_RE = re.compile(r"parameter \(imt=\s*102, jmt=\s*102, km=\s*19\)")
+
+
+def run(cmd, **kw):
+    r = subprocess.run(cmd, capture_output=True, text=True, encoding="latin-1", **kw)
+    return r
+
+
+def lib_name(cfg: str, imt: int, jmt: int, km: int) -> Path:
+    return OUT / f"libuvicref_{cfg}_{imt}x{jmt}x{km}.so"
+
+
+def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bool = False) -> Path:
+    if not REF.exists():
+        raise SystemExit(f"reference not present at {REF}; oracle/_ref can only be built in the build container")
+    target = lib_name(cfg, imt, jmt, km)
+    work = OUT / "build" / target.stem
+    if work.exists():
+        shutil.rmtree(work)
+    (work / "inc").mkdir(parents=True)
+    defs = [f"-D{o}" for o in CONFIGS[cfg]]
+    size_line = f"parameter (imt={imt}, jmt={jmt}, km={km})"
+
+    def patch(text: str) -> str:
+        return SIZE_RE.sub(size_line, text)
+
+    # 1. headers, overlay order
+    for d in HDR_DIRS:
+        for h in sorted((REF / d).glob("*.h")):
+            r = run(["cpp", "-traditional", "-P", *defs, str(h)])
+            (work / "inc" / h.name).write_text(patch(r.stdout), encoding="latin-1")
+    # 2. sources
+    incs = []
+    for d in reversed(HDR_DIRS):
+        incs += ["-I", str(REF / d)]
+    objs = []
+    for s in SOURCES:
+        src = REF / s
+        r = run(["cpp", "-traditional", "-P", *incs, *defs, str(src)])
+        text = patch(r.stdout)
+        if src.name == "tracer.F":
+            # `mi` (month index) is declared REAL but used as an array subscript
+            text = text.replace("bctz, mi, yrtime", "bctz, yrtime")
+            text = text.replace("parameter (fe_n = 14)", "parameter (fe_n = 14)\n      integer mi")
+        (work / (src.stem + ".f")).write_text(text, encoding="latin-1")
+    # 3. generated registration harness (includes only; no reference text)
+    sys.path.insert(0, str(HERE / "ref"))
+    import gen_harness
+    gen_harness.emit(work / "inc", work / "orc_reg.f")
+    # 4. compile
+    fflags = ["-fdefault-real-8", "-ffixed-form", "-ffixed-line-length-132", "-O2",
+              "-ffp-contract=off", "-fno-automatic", "-fPIC", f"-I{work / 'inc'}"]
+    for f in sorted(work.glob("*.f")):
+        o = f.with_suffix(".o")
+        r = run([FLANG, *fflags, "-c", str(f), "-o", str(o)])
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-4000:])
+            raise SystemExit(f"flang failed on {f.name}")
+        if verbose:
+            print("  compiled", f.name)
+        objs.append(str(o))
+    r = run(["gcc", "-O2", "-fPIC", "-c", str(HERE / "ref" / "harness.c"), "-o", str(work / "harness.o")])
+    if r.returncode != 0:
+        raise SystemExit(r.stderr)
+    objs.append(str(work / "harness.o"))
+    # 5. link
+    r = run([FLANG, "-shared", "-o", str(target), *objs, "-Wl,-z,lazy"])
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-4000:])
+        raise SystemExit("link failed")
+    if not keep:
+        shutil.rmtree(work)
+        try:
+            (OUT / "build").rmdir()
+        except OSError:
+            pass
+    return target
+
+
+DEFAULT_BUILDS = [
+    ("p2", 14, 14, 6), ("c30", 14, 14, 6),
+    ("p2", 102, 102, 19), ("c30", 102, 102, 19),
+]
+
+
+def build_default(force: bool = False, verbose: bool = False):
+    built = []
+    for cfg, imt, jmt, km in DEFAULT_BUILDS:
+        t = lib_name(cfg, imt, jmt, km)
+        if t.exists() and not force:
+            built.append(t)
+            continue
+        if verbose:
+            print("building", t.name)
+        built.append(build(cfg, imt, jmt, km, verbose=False))
+    return built
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", default=None, choices=list(CONFIGS))
+    ap.add_argument("--imt", type=int, default=102)
+    ap.add_argument("--jmt", type=int, default=102)
+    ap.add_argument("--km", type=int, default=19)
+    ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    if a.cfg is None:
+        for t in build_default(force=a.force, verbose=True):
+            print(t)
+    else:
+        print(build(a.cfg, a.imt, a.jmt, a.km, keep=a.keep, verbose=True))

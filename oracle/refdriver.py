@@ -1,0 +1,176 @@
+"""Drive the compiled reference (oracle/_ref) on a synthetic ocean.
+
+TEST INFRASTRUCTURE ONLY.  Fills the reference's COMMON blocks from an
+`uvic29_amd.synthetic.Ocean`, runs the reference's own initialisation routines
+that do not need netCDF (`tracer_init`, `eqstate`, `isopi`, `mobi_init`) and
+then calls the reference's `isopyc` / `tracer` (or any single routine of the
+path) exactly as `mom` does (/root/reference/source/mom/mom.F:325-405).
+Call order follows SURVEY.md Appendix B.
+"""
+from __future__ import annotations
+
+import os
+import re
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+from refmodel import RefLib
+
+REF = Path(os.environ.get("UVIC_REFERENCE", "/root/reference"))
+
+SILICON_ONLY = ["abiodiat", "kfemin_Diat", "kfemax_Diat", "nu_diat", "nudt0", "wo0", "sipr0",
+                "sildustfluxfac", "zprefDiat"]
+
+
+def trimmed_control_in(cfg_options) -> str:
+    """run/control.in with the silicon-only &mobi members removed for option
+    sets without O_mobi_silicon (they are namelist members only under that
+    option, mobi.F:41-44,53-57)."""
+    text = (REF / "run" / "control.in").read_text()
+    if "mobi_silicon" in cfg_options:
+        return text
+    for name in SILICON_ONLY:
+        text = re.sub(r"\b" + name + r"\s*=\s*[-+0-9.eE]+\s*,?", "", text)
+    return text
+
+
+class RefOcean:
+    """The reference model state initialised from a synthetic Ocean."""
+
+    def __init__(self, ocean, quiet: bool = True):
+        g, cfg = ocean.grid, ocean.cfg
+        self.ocean = ocean
+        self.ref = RefLib(cfg.name, g.imt, g.jmt, g.km)
+        self.v = self.ref.v
+        self.quiet = quiet
+        self._init(ocean)
+
+    # -- helpers ---------------------------------------------------------------
+    def _silence(self):
+        """Redirect the Fortran runtime's stdout (fd 1) while init prints."""
+        if not self.quiet:
+            return None
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        os.close(devnull)
+        return saved
+
+    def _restore(self, saved):
+        if saved is None:
+            return
+        try:
+            self.ref.lib._FortranAioFlush  # noqa: B018  (may not exist)
+        except AttributeError:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+    def setv(self, name, value):
+        self.v[name][...] = value
+
+    # -- initialisation --------------------------------------------------------
+    def _init(self, oc):
+        g, topo, cfg, prm, v = oc.grid, oc.topo, oc.cfg, oc.params, self.v
+        imt, jmt, km = g.imt, g.jmt, g.km
+        S = self.ref.set
+        S("pi", g.pi); S("radian", g.radian); S("radius", 6370.0e5)
+        S("grav", 980.6); S("rho0", 1.035); S("rho0r", 1.0 / 1.035)
+        S("daylen", 86400.0)
+        S("dtts", prm.dtts); S("c2dtts", 2.0 * prm.dtts)
+        S("aidif", prm.aidif); S("kappa_h", prm.kappa_h)
+        S("diff_cet", prm.diff_cet); S("diff_cnt", prm.diff_cnt); S("ah", prm.diff_cet)
+        S("taum1", -1); S("tau", 0); S("taup1", 1)
+        S("eots", 1); S("first", 1); S("euler2", 0)
+        S("relyr", oc.forcing.relyr)
+        S("jfrst", jmt + 1)            # polar filter off
+        for n in ("xt", "yt", "xu", "yu", "zw", "zt", "dxtdeg", "dytdeg", "dzt", "dxudeg", "dyudeg", "dzw",
+                  "dxt", "dxtr", "dxt2r", "dxu", "dxur", "dxu2r", "dxu4r", "dxt4r",
+                  "dyt", "dytr", "dyt2r", "dyu", "dyur", "dyu2r", "dyu4r", "dyt4r",
+                  "csu", "csur", "cst", "cstr", "cstdytr", "cstdyt2r", "csudyur", "csudyu2r",
+                  "cst_dytr", "csu_dyur", "phi", "phit", "sine", "tng", "c2dzt", "dztr", "dzt2r",
+                  "dzwr", "dzw2r", "dztur", "dztlr", "tlat", "tlon",
+                  "dtxcel", "dtxsqr", "dztxcl", "dzwxcl"):
+            v[n][...] = getattr(g, n)
+        v["kmt"][...] = topo.kmt
+        v["kmu"][...] = topo.kmu
+        v["sg_bathy"][...] = topo.sg_bathy
+        v["tmask"][...] = topo.tmask
+        v["umask"][...] = topo.umask
+        saved = self._silence()
+        try:
+            self.ref.call("tracer_init")
+            self.ref.call("eqstate", v["zt"], km, v["ro0"], v["to"], v["so"], v["c"],
+                          v["tmink"], v["tmaxk"], v["smink"], v["smaxk"])
+            cwd = os.getcwd()
+            with tempfile.TemporaryDirectory() as td:
+                os.chdir(td)
+                try:
+                    err = np.zeros(1, dtype=np.int32)
+                    self.ref.call("isopi", err, 1.5e9, prm.diff_cet)
+                    if cfg.ntnpzd:
+                        Path("control.in").write_text(trimmed_control_in(cfg.options))
+                        self.ref.call("mobi_init")
+                finally:
+                    os.chdir(cwd)
+        finally:
+            self._restore(saved)
+        # isopi hard-codes slmx/ahisop/athkdf (isopyc.F:70-86); overwrite with the ocean's
+        S("slmxr", 1.0 / prm.slmx); S("ahisop", prm.ahisop); S("athkdf", prm.athkdf)
+        v["fisop"][...] = oc.fisop
+        v["addisop"][...] = oc.addisop[:, :, 1:jmt - 1]
+        # state
+        self.load_state(oc.t_taum1, oc.t_tau)
+        v["u"][:, :, :, :, 1] = oc.u           # tau slot (index -1:1 -> 0,1,2)
+        v["adv_vet"][...] = oc.adv_vet[:, :, 1:]
+        v["adv_vnt"][...] = oc.adv_vnt
+        v["adv_vbt"][...] = oc.adv_vbt[:, :, 1:]
+        v["stf"][...] = oc.stf
+        v["btf"][...] = oc.btf
+        if cfg.ntnpzd:
+            f = oc.forcing
+            v["dnswr"][...] = f.dnswr
+            v["aice"][:, :, 1] = f.aice
+            v["hice"][:, :, 1] = f.hice
+            v["hsno"][:, :, 1] = f.hsno
+            S("co2ccn", f.co2ccn)
+            v["fe_atmdep"][:, :, 0, :] = f.fe_atmdep
+            v["fe_hydr"][...] = f.fe_hydr
+        self.diff_cbt_bg = oc.diff_cbt_bg
+
+    def load_state(self, t_taum1, t_tau):
+        self.v["t"][..., 0] = t_taum1
+        self.v["t"][..., 1] = t_tau
+        self.v["t"][..., 2] = 0.0
+
+    # -- one ocean tracer step as mom.F does -----------------------------------
+    def isopyc(self):
+        g = self.ocean.grid
+        self.ref.call("isopyc", 0, 1, g.jmt, 2, g.imt - 1)
+
+    def add_k33(self):
+        """diff_cbt = background + K33 (updates/09/source/mom/vmixc.F:182-188)."""
+        g = self.ocean.grid
+        self.v["diff_cbt"][...] = self.diff_cbt_bg[:, :, 1:g.jmt - 1] + self.v["k33"]
+
+    def tracer(self):
+        g = self.ocean.grid
+        self.ref.call("tracer", 0, 2, g.jmt - 1, 2, g.imt - 1)
+
+    def step(self, c2dtts=None):
+        if c2dtts is not None:
+            self.ref.set("c2dtts", c2dtts)
+        self.isopyc()
+        self.add_k33()
+        self.tracer()
+        return self.v["t"][..., 2]
+
+    def rotate(self):
+        """taum1 <- tau, tau <- taup1 (what putmw/getvar do through the ramdrive)."""
+        t = self.v["t"]
+        t[..., 0] = t[..., 1]
+        t[..., 1] = t[..., 2]
