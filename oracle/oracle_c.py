@@ -1,0 +1,145 @@
+"""ctypes binding of the CPU restatement (oracle/uvic_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "liboracle.so"
+SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c"]
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int)
+
+_INTS = ["imt", "jmt", "km", "nt", "nsrc"]
+_SCALARS = ["c2dtts", "aidif", "diff_cet", "diff_cnt", "slmxr", "ahisop", "athkdf"]
+_DPTR = ["dxt", "dxtr", "dxu", "dxur", "dxt4r", "dyt", "dytr", "dyu", "dyur", "dyt4r",
+         "cst", "cstr", "csu", "cstdytr", "cstdyt2r", "csu_dyur",
+         "dzt", "dztr", "dzt2r", "dztur", "dztlr", "dzw", "dzwr", "dtxcel", "dtxsqr", "dztxcl",
+         "to", "so", "c"]
+_AFTER_KMT = ["tmask", "fisop", "addisop", "t_taum1", "t_tau", "t_taup1", "adv_vet", "adv_vnt", "adv_vbt",
+              "diff_cbt", "stf", "btf", "src"]
+_TAIL = ["alphai", "betai", "ddxt", "ddyt", "ddzt", "Ai_ez", "Ai_nz", "Ai_bx", "Ai_by", "K11", "K22", "K33",
+         "adv_vetiso", "adv_vntiso", "adv_vbtiso", "adv_fe", "adv_fn", "adv_fb", "diff_fe", "diff_fn",
+         "diff_fb", "diff_fbiso"]
+
+
+class OrcCtx(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int) for n in _INTS] + [(n, ctypes.c_double) for n in _SCALARS]
+                + [(n, _D) for n in _DPTR] + [("kmt", _I)] + [(n, _D) for n in _AFTER_KMT]
+                + [("itrc", _I)] + [(n, _D) for n in _TAIL])
+
+
+def build(force: bool = False) -> Path:
+    srcs = [s for s in SOURCES if s.exists()]
+    if LIB.exists() and not force and all(LIB.stat().st_mtime >= s.stat().st_mtime for s in srcs + [HERE / "uvic_oracle.h"]):
+        return LIB
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c99", "-o", str(LIB)] + [str(s) for s in srcs] + ["-lm"]
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(LIB))
+    return _lib
+
+
+def _f(shape):
+    return np.zeros(shape, dtype=np.float64, order="F")
+
+
+class Oracle:
+    """Holds an orc_ctx built from a synthetic Ocean; arrays are numpy, F order."""
+
+    def __init__(self, ocean, to=None, so=None, c=None, src=None):
+        g, topo, cfg, prm = ocean.grid, ocean.topo, ocean.cfg, ocean.params
+        imt, jmt, km, nt = g.imt, g.jmt, g.km, cfg.nt
+        self.ocean = ocean
+        self.a = a = {}
+        for n in _DPTR[:-3]:
+            a[n] = np.ascontiguousarray(getattr(g, n), dtype=np.float64)
+        a["to"] = np.ascontiguousarray(to, dtype=np.float64)
+        a["so"] = np.ascontiguousarray(so, dtype=np.float64)
+        a["c"] = np.asfortranarray(c, dtype=np.float64)
+        a["kmt"] = np.asfortranarray(topo.kmt, dtype=np.int32)
+        a["tmask"] = np.asfortranarray(topo.tmask)
+        a["fisop"] = np.asfortranarray(ocean.fisop)
+        a["addisop"] = np.asfortranarray(ocean.addisop)
+        a["t_taum1"] = np.array(ocean.t_taum1, order="F")
+        a["t_tau"] = np.array(ocean.t_tau, order="F")
+        a["t_taup1"] = _f((imt, km, jmt, nt))
+        a["adv_vet"], a["adv_vnt"], a["adv_vbt"] = ocean.adv_vet, ocean.adv_vnt, ocean.adv_vbt
+        a["diff_cbt"] = _f((imt, km, jmt))
+        a["stf"], a["btf"] = ocean.stf, ocean.btf
+        a["src"] = None if src is None else np.asfortranarray(src)
+        a["itrc"] = np.array(cfg.itrc(), dtype=np.int32)
+        for n in ("alphai", "betai", "K11", "K22", "K33", "adv_vetiso", "adv_vntiso", "adv_fe", "adv_fn",
+                  "diff_fe", "diff_fn"):
+            a[n] = _f((imt, km, jmt))
+        for n in ("ddxt", "ddyt"):
+            a[n] = _f((imt, km, jmt, 2))
+        a["ddzt"] = _f((imt, km + 1, jmt, 2))
+        for n in ("Ai_ez", "Ai_nz", "Ai_bx", "Ai_by"):
+            a[n] = _f((imt, km, jmt, 2, 2))
+        for n in ("adv_vbtiso", "adv_fb", "diff_fb", "diff_fbiso"):
+            a[n] = _f((imt, km + 1, jmt))
+        self.ctx = OrcCtx()
+        self.ctx.imt, self.ctx.jmt, self.ctx.km, self.ctx.nt, self.ctx.nsrc = imt, jmt, km, nt, cfg.nsrc
+        self.ctx.c2dtts = 2.0 * prm.dtts
+        self.ctx.aidif = prm.aidif
+        self.ctx.diff_cet, self.ctx.diff_cnt = prm.diff_cet, prm.diff_cnt
+        self.ctx.slmxr, self.ctx.ahisop, self.ctx.athkdf = 1.0 / prm.slmx, prm.ahisop, prm.athkdf
+        self.rebind()
+        self.lib = lib()
+
+    def rebind(self):
+        for name, typ in OrcCtx._fields_:
+            if typ in (_D, _I):
+                arr = self.a.get(name)
+                if arr is None:
+                    setattr(self.ctx, name, typ())
+                else:
+                    assert arr.flags.f_contiguous or arr.ndim <= 1, name
+                    setattr(self.ctx, name, arr.ctypes.data_as(typ))
+
+    def set_src(self, src):
+        self.a["src"] = np.asfortranarray(src)
+        self.rebind()
+
+    # entry points -------------------------------------------------------------
+    def isopyc(self):
+        self.lib.orc_isopyc(ctypes.byref(self.ctx))
+
+    def add_k33(self):
+        jmt = self.ctx.jmt
+        self.a["diff_cbt"][...] = 0.0
+        self.a["diff_cbt"][:, :, 1:jmt - 1] = self.ocean.diff_cbt_bg[:, :, 1:jmt - 1] + self.a["K33"][:, :, 1:jmt - 1]
+
+    def adv_flux(self, n):
+        self.lib.orc_adv_flux(ctypes.byref(self.ctx), ctypes.c_int(n))
+
+    def diff_flux(self, n):
+        self.lib.orc_diff_flux(ctypes.byref(self.ctx), ctypes.c_int(n))
+
+    def isoflux(self, n):
+        self.lib.orc_isoflux(ctypes.byref(self.ctx), ctypes.c_int(n))
+
+    def explicit_update(self, n):
+        self.lib.orc_explicit_update(ctypes.byref(self.ctx), ctypes.c_int(n))
+
+    def transport(self):
+        self.lib.orc_tracer_transport(ctypes.byref(self.ctx))
+        return self.a["t_taup1"]
