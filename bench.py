@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- tracer-cell updates/s of the UVic 2.9 ocean tracer step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--cfg c30|p2|perfNN] [--grid 102x102x19]
+
+One "step" is one pass of the hot path over the whole synthetic ocean: isopyc
+(mixing tensor + GM velocities), the tracer step (MOBI sources when the option
+set has them, FCT advection, isopycnal diffusion, explicit update, implicit
+vertical solve, convection) and the time-level rotation, with every input
+already resident in HBM.  Metric (BASELINE.json): imt*jmt*km*nt cell updates
+per completed step / wall time, whole job.  N > 1 (launched by
+torch.distributed.run, one rank per GPU, RCCL) shards the tracer index across
+ranks and all-gathers t(tau+1) after the step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "oracle"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def b_alg(nt, nsrc):
+    """Algorithmic bytes per cell update of the whole step, SURVEY.md §8(d)."""
+    return 24.0 + 8.0 * nsrc / nt + 280.0 / nt
+
+
+def kernel_alg_bytes(name, nt, nsrc):
+    """Algorithmic bytes per cell update of ONE kernel launch:
+    what the kernel must read/write once if every stencil neighbour were free."""
+    if name == "fct_rows":       # reads t(tau-1), t(tau); shared: 3 total velocities, tmask; writes nothing algorithmic
+        return 16.0 + 32.0 / nt
+    if name == "update_rows":    # reads t(tau-1), t(tau), source; writes t(tau+1); shared isopyc fields + metrics
+        return 24.0 + 8.0 * nsrc / nt + 248.0 / nt
+    return None
+
+
+def cpu_baseline(ocean, to, so, c, src, budget_s=20.0):
+    """Time the CPU path on this box's host cores, 1 core, bounded sample."""
+    import oracle_c
+    import refmodel
+    g, cfg = ocean.grid, ocean.cfg
+    units = g.imt * g.jmt * g.km * cfg.nt
+    if cfg.name in ("p2", "c30") and refmodel.available(cfg.name, g.imt, g.jmt, g.km):
+        try:
+            import refdriver
+            ro = refdriver.RefOcean(ocean)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                ro.step()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or n >= 5:
+                    break
+            return {"value": units * n / el, "unit": "cell-updates/s", "cores": 1, "kind": "reference",
+                    "sample": f"{n} full isopyc+tracer steps of the compiled reference Fortran (oracle/_ref, flang -O2), "
+                              f"{cfg.name} {g.imt}x{g.jmt}x{g.km}"}
+        except Exception as e:  # fall through to the C port
+            print(f"[bench] reference baseline unavailable: {e}", file=sys.stderr)
+    orc = oracle_c.Oracle(ocean, to=to, so=so, c=c, src=src)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.isopyc(); orc.add_k33(); orc.transport()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 5:
+            break
+    return {"value": units * n / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{n} isopyc+transport+convection steps of the C oracle (gcc -O2 -ffp-contract=off), "
+                      f"{cfg.name} {g.imt}x{g.jmt}x{g.km}, sources given"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cfg", default="c30")
+    ap.add_argument("--grid", default="102x102x19")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    from uvic29_amd import OPTION_SETS, performance_set, synthetic
+    from uvic29_amd.tracer import TracerModel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tracer step has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    imt, jmt, km = (int(x) for x in a.grid.split("x"))
+    cfg = OPTION_SETS[a.cfg] if a.cfg in OPTION_SETS else performance_set(int(a.cfg.replace("perf", "")))
+    ocean = synthetic.make_ocean(cfg, imt, jmt, km)
+    to, so, c = synthetic.load_eos(km)
+    nt, nsrc = cfg.nt, cfg.nsrc
+    src = None
+    if nsrc:
+        rng = np.random.default_rng(2029)
+        src = np.asfortranarray(rng.standard_normal((imt, km, jmt, nsrc)) * 1e-10 * ocean.topo.tmask[..., None])
+
+    from uvic29_amd.parallel import TracerShard
+    shard = TracerShard(nt, world, rank)
+    if shard.nt_model != nt:          # pad the tracer dimension with inert tracers (see parallel.py)
+        ocean = synthetic.pad_tracers(ocean, shard.nt_model)
+    m = TracerModel(imt, jmt, km, shard.nt_model, nsrc, cfg.ntnpzd, device=local_rank)
+    m.load_ocean(ocean, to, so, c, src=src)
+    shard.apply(m)
+
+    def one_step():
+        shard.step(m)
+        m.rotate()
+
+    def barrier():
+        m.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    units = imt * jmt * km * nt
+    value = units * a.steps / el
+
+    out = None
+    if rank == 0:
+        # restore a sane state (the timed loop may have drifted far) and profile per kernel
+        m.load_ocean(ocean, to, so, c, src=src)
+        shard.apply(m)
+        prof = m.profile(nrep=10)
+        names = [k for k in prof if kernel_alg_bytes(k, nt, nsrc)]
+        dom = max(names, key=lambda k: prof[k])
+        local_units = imt * jmt * km * shard.nt_local
+        ach = kernel_alg_bytes(dom, nt, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
+        step_gbs = b_alg(nt, nsrc) * value / 1e9
+        out = {
+            "metric": "tracer-cell updates/s (imt*jmt*km*nt)", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
+                                   f"(FCT adv_flux, isoflux, explicit update, invtri, convct2"
+                                   f"{', MOBI sources' if m_has_mobi(m) else ', source term given (MOBI column kernel not in this build)'})",
+                       "grid": a.grid, "nt": nt, "parallelism": f"tracer-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": {k: round(v, 5) for k, v in prof.items()},
+                         "alg_bytes_per_cell_update": kernel_alg_bytes(dom, nt, nsrc)},
+            "step_hbm": {"alg_bytes_per_cell_update": b_alg(nt, nsrc), "achieved_GBs": step_gbs,
+                         "frac_of_peak": step_gbs / HBM_PEAK_GBS},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ocean, to, so, c, src)
+        print(json.dumps(out), flush=True)
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def m_has_mobi(m):
+    return bool(getattr(m, "has_mobi", False))
+
+
+if __name__ == "__main__":
+    main()

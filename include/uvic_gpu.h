@@ -1,0 +1,132 @@
+/* uvic_gpu.h -- C ABI of the MI355X-native UVic 2.9 ocean tracer time-step.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference has no FFI:
+ * its tracer path consists of Fortran-77 external procedures with implicit
+ * interfaces that exchange all bulk data through COMMON blocks.  The entry
+ * points below are what a Fortran `bind(C)` interface in an overlay `tracer.F`
+ * binds (uvic2.9_amd/fortran/); each one cites the reference
+ * interface it replaces (paths relative to /root/reference, "u09/" =
+ * updates/09/source/).
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, int status (0 = ok); no C++ or torch types.
+ *   - `integer` = int32_t, `real` = double (the reference is built -r8,
+ *     run/mk.ver:51), `logical` = int32_t.
+ *   - arrays are Fortran order, i fastest.  The device keeps every field over
+ *     all jmt rows; `uvic_gpu_upload_rows` maps the reference's row ranges
+ *     (jsmw:jemw, 1:jemw, jsmw:jmw; u09/mom/mw.h:246-316) onto them.
+ *   - ownership: the caller owns every host array; device buffers belong to
+ *     the handle between uvic_gpu_create and uvic_gpu_destroy.
+ *   - all calls are synchronous with respect to the host unless stated.
+ */
+#ifndef UVIC_GPU_H
+#define UVIC_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uvic_gpu uvic_gpu;
+
+/* compile-time `parameter`s of the reference (u09/common/size.h:27-144,
+ * u09/mom/mobi.h:104-142) become run-time dimensions */
+typedef struct uvic_dims {
+  int32_t imt, jmt, km, nt, nsrc, ntnpzd;
+} uvic_dims;
+
+/* device fields.  Shapes: C = (imt,km,jmt), F = (imt,km+1,jmt), S = (imt,jmt) */
+enum uvic_field {
+  /* 1-D metrics, u09 & source/common: grdvar.h, coord.h, accel.h */
+  UVIC_F_DXT = 0, UVIC_F_DXTR, UVIC_F_DXU, UVIC_F_DXUR, UVIC_F_DXT4R,          /* (imt) */
+  UVIC_F_DYT, UVIC_F_DYTR, UVIC_F_DYU, UVIC_F_DYUR, UVIC_F_DYT4R,              /* (jmt) */
+  UVIC_F_CST, UVIC_F_CSTR, UVIC_F_CSU, UVIC_F_CSTDYTR, UVIC_F_CSTDYT2R, UVIC_F_CSU_DYUR,
+  UVIC_F_DZT, UVIC_F_DZTR, UVIC_F_DZT2R, UVIC_F_DZTUR, UVIC_F_DZTLR,           /* (km) */
+  UVIC_F_DZW, UVIC_F_DZWR,                                                    /* (0:km) */
+  UVIC_F_DTXCEL, UVIC_F_DTXSQR, UVIC_F_DZTXCL,                                /* (km) */
+  UVIC_F_TO, UVIC_F_SO, UVIC_F_C,             /* source/mom/state.h:38: (km),(km),(km,9) */
+  UVIC_F_KMT,                                 /* int32 (imt,jmt), u09/common/levind.h:9 */
+  UVIC_F_FISOP,                               /* (imt,jmt,km), u09/common/isopyc.h */
+  UVIC_F_ADDISOP,                             /* C */
+  UVIC_F_T_TAUM1, UVIC_F_T_TAU, UVIC_F_T_TAUP1, /* (imt,km,jmt,nt), u09/mom/mw.h:77 */
+  UVIC_F_ADV_VET, UVIC_F_ADV_VNT,             /* C,  mw.h adv_vet(imt,km,jsmw:jmw), adv_vnt(imt,km,1:jmw) */
+  UVIC_F_ADV_VBT,                             /* F,  mw.h adv_vbt(imt,0:km,jsmw:jmw) */
+  UVIC_F_DIFF_CBT_BG,                         /* C,  vmixc.h diff_cbt BEFORE "+K33" (u09/mom/vmixc.F:182-188) */
+  UVIC_F_STF, UVIC_F_BTF,                     /* (imt,jmt,nt), mw.h stf/btf(imt,1:jmw,nt) */
+  UVIC_F_SRC,                                 /* (imt,km,jmt,nsrc), tracer.F:121 */
+  UVIC_F_ITRC,                                /* int32 (nt), mw.h itrc */
+  /* products of uvic_gpu_isopyc (downloadable; u09/common/isopyc.h:20-83) */
+  UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT,
+  UVIC_F_AI_EZ, UVIC_F_AI_NZ, UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33,
+  UVIC_F_ADV_VETISO, UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO,
+  UVIC_F_DIFF_CBT,                            /* C, background + K33 */
+  UVIC_F_COUNT
+};
+
+/* scalars that change per step or per run (scalar.h, vmixc.h, hmixc.h, isopyc.h) */
+typedef struct uvic_params {
+  double c2dtts;   /* 2*dtts on leapfrog steps, dtts on mixing steps (source/mom/mom.F:108-148) */
+  double aidif;    /* implicit fraction of vertical diffusion, control.in &mixing */
+  double diff_cet, diff_cnt; /* u09/mom/hmixc.F:177-200 */
+  double slmxr;    /* 1/slmx, u09/mom/isopyc.F:105 */
+  double ahisop, athkdf; /* isopyc.F:79-83 */
+} uvic_params;
+
+const char *uvic_gpu_last_error(void);
+int uvic_gpu_abi_version(void);
+
+/* allocate all device state for one model instance on `device` */
+int uvic_gpu_create(uvic_gpu **h, const uvic_dims *dims, int device);
+int uvic_gpu_destroy(uvic_gpu *h);
+
+/* whole-field transfers; `count` elements starting at element `offset` */
+int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t offset, int64_t count);
+int uvic_gpu_download(uvic_gpu *h, int field, void *host, int64_t offset, int64_t count);
+/* host array dimensioned (imt, kdim, jlo:jhi [, extra]) -> device rows jlo..jhi */
+int uvic_gpu_upload_rows(uvic_gpu *h, int field, const double *host, int jlo, int jhi);
+int uvic_gpu_download_rows(uvic_gpu *h, int field, double *host, int jlo, int jhi);
+/* number of elements and device address of a field (for zero-copy plumbing) */
+int64_t uvic_gpu_field_elems(uvic_gpu *h, int field);
+void *uvic_gpu_field_devptr(uvic_gpu *h, int field);
+void *uvic_gpu_stream(uvic_gpu *h); /* hipStream_t the kernels are launched on */
+
+int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p);
+/* work decomposition: this instance computes tracers n0+1..n0+nt_local and rows
+ * js..je (1-based, inclusive); defaults: all tracers, rows 2..jmt-1 */
+int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je);
+
+/* replaces `call isopyc (joff, js, je, is, ie)`, source/mom/mom.F:340
+ * (u09/mom/isopyc.F:466-557), plus the "+K33" of u09/mom/vmixc.F:182-188 */
+int uvic_gpu_isopyc(uvic_gpu *h);
+/* replaces the per-tracer loop of `tracer` (u09/mom/tracer.F:902-1167):
+ * adv_flux (FCT), diffusive fluxes, isoflux, explicit update, ivdift/invtri,
+ * cyclic conditions -- for all tracers of the shard; reads UVIC_F_SRC */
+int uvic_gpu_transport(uvic_gpu *h);
+/* replaces `call convct2 (t(1,1,1,1,taup1), joff, js, je, is, ie, kmt)`,
+ * u09/mom/tracer.F:1198-1203 (source/mom/convect.F:99-311) */
+int uvic_gpu_convect(uvic_gpu *h);
+/* replaces `call tracer (joff, js, je, is, ie)`, source/mom/mom.F:389:
+ * sources, transport, convection */
+int uvic_gpu_tracer(uvic_gpu *h);
+/* time-level rotation done by putmw/getvar through the ramdrive
+ * (u09/mom/loadmw.F:528-588,717-744): taum1 <- tau, tau <- taup1 */
+int uvic_gpu_rotate(uvic_gpu *h);
+int uvic_gpu_sync(uvic_gpu *h);
+
+/* asynchronous forms for a device-resident time loop (no host synchronisation;
+ * pair with uvic_gpu_sync): one whole step; or, for tracer-index sharding,
+ * the part before the exchange of t(tau+1) and the convection after it */
+int uvic_gpu_step_async(uvic_gpu *h);
+int uvic_gpu_step_pre_async(uvic_gpu *h);
+int uvic_gpu_convect_async(uvic_gpu *h);
+
+/* run `nrep` x [isopyc, tracer] back to back and return the mean duration in
+ * milliseconds of every kernel, measured with HIP events on the launch stream;
+ * names[i] points to static strings.  Used by bench.py for the roofline. */
+int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const char **names, double *mean_ms, int *nkernels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the reference itself.
+
+Run in the build container only (needs /root/reference and oracle/_ref built by
+oracle/build_ref.py).  The reference has no tests or golden vectors of its own
+(SURVEY.md §4), so every vector here is an OUTPUT OF THE COMPILED REFERENCE on
+the deterministic synthetic ocean of uvic2.9_amd/synthetic.py; inputs are
+regenerated from that module by the tests, so only outputs are stored.
+
+Fixtures
+  uvic2.9_amd/data/eos.json            to, so, c(km,9) of the reference's eqstate
+                                       (source/mom/denscoef.F) for the synthetic
+                                       vertical grids (inputs of the hot path)
+  tests/golden/step_<cfg>_<grid>.npz   t(tau+1) after one isopyc+tracer step,
+                                       K33 and the GM velocities
+  tests/golden/run_<cfg>_<grid>.npz    t after N leapfrog steps (mixing step every
+                                       nmix-th) and the tbar/travar integrals
+"""
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+from uvic29_amd import synthetic  # noqa: E402
+import refdriver  # noqa: E402
+import refmodel  # noqa: E402
+
+HERE = Path(__file__).resolve().parent
+
+
+def eos_fixture():
+    ref = refmodel.RefLib("p2", 14, 14, 6)
+    out = {}
+    for km in (6, 19, 32):
+        g = synthetic.make_grid(14, 14, km)
+        zt = np.ascontiguousarray(g.zt)
+        ro0, to, so = np.zeros(km), np.zeros(km), np.zeros(km)
+        c = np.zeros((km, 9), order="F")
+        tmink, tmaxk, smink, smaxk = (np.zeros(km) for _ in range(4))
+        ref.call("eqstate", zt, km, ro0, to, so, c, tmink, tmaxk, smink, smaxk)
+        out[str(km)] = {"zt": zt.tolist(), "to": to.tolist(), "so": so.tolist(),
+                        "c": [c[:, m].tolist() for m in range(9)]}
+    p = ROOT / "uvic2.9_amd" / "data" / "eos.json"
+    p.parent.mkdir(exist_ok=True)
+    p.write_text(json.dumps(out))
+    print("wrote", p)
+
+
+def step_fixture(cfg, imt, jmt, km):
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    ro = refdriver.RefOcean(oc)
+    tp = ro.step().copy()
+    v = ro.v
+    np.savez_compressed(HERE / f"step_{cfg}_{imt}x{jmt}x{km}.npz", t_taup1=tp, k33=v["k33"].copy(),
+                        adv_vetiso=v["adv_vetiso"].copy(), adv_vntiso=v["adv_vntiso"].copy(),
+                        adv_vbtiso=v["adv_vbtiso"].copy())
+    print("wrote step", cfg, imt, jmt, km)
+
+
+def run_fixture(cfg, imt, jmt, km, nsteps):
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    ro = refdriver.RefOcean(oc)
+    dtts, nmix = oc.params.dtts, oc.params.nmix
+    for it in range(1, nsteps + 1):
+        mixing = (it % nmix) == 0
+        if mixing:                      # forward step: both slots hold tau (loadmw.F:107-111)
+            ro.v["t"][..., 0] = ro.v["t"][..., 1]
+        ro.step(c2dtts=dtts if mixing else 2.0 * dtts)
+        ro.rotate()
+    t = ro.v["t"][..., 1].copy()
+    np.savez_compressed(HERE / f"run_{cfg}_{imt}x{jmt}x{km}_n{nsteps}.npz", t=t)
+    print("wrote run", cfg, imt, jmt, km, nsteps)
+
+
+if __name__ == "__main__":
+    eos_fixture()
+    step_fixture("p2", 14, 14, 6)
+    step_fixture("c30", 14, 14, 6)
+    run_fixture("p2", 14, 14, 6, 20)
+    run_fixture("c30", 14, 14, 6, 20)

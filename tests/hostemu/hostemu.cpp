@@ -1,0 +1,60 @@
+// tests/hostemu/hostemu.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the package's kernel sources (uvic2.9_amd/csrc/kernels_*.hpp) for the
+// host with `HostEnv` (kenv.hpp): every barrier-delimited phase of a workgroup
+// routine is run for tid = 0..nthreads-1 in a loop.  The build container has
+// no GPU; this lets `pytest -m "not gpu"` check the kernel LOGIC (indexing, tile
+// halos, cyclic wrap, evaluation order) bit-for-bit against the oracle.  The
+// product never loads this library and has no CPU path (uvic2.9_amd/capi.py
+// fails loudly when libuvic_gpu.so or a GPU is missing).
+#include <cstdlib>
+#include <vector>
+
+#include "../../uvic2.9_amd/csrc/kernels_fct.hpp"
+#include "../../uvic2.9_amd/csrc/kernels_isopyc.hpp"
+#include "../../uvic2.9_amd/csrc/kernels_mobi.hpp"
+
+using namespace uvic;
+
+extern "C" int emu_ctx_size(void) { return (int)sizeof(uvic_ctx); }
+
+extern "C" void emu_isopyc(const uvic_ctx *cp) {
+  const uvic_ctx &c = *cp;
+  for (int j = 1; j <= c.jmt; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) isopyc_elements_cell(c, i, k, j);
+  for (int j = 1; j <= c.jmt - 1; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) isopyc_ai_cell(c, i, k, j);
+  for (int j = 1; j <= c.jmt - 1; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 1; i <= c.imt; ++i) isopyc_adv_cell(c, i, k, j);
+  for (int j = 2; j <= c.jmt - 1; ++j)
+    for (int i = 2; i <= c.imt - 1; ++i) isopyc_column(c, i, j);
+}
+
+extern "C" void emu_transport(const uvic_ctx *cp, int nchunk, int nthreads) {
+  const uvic_ctx &c = *cp;
+  const int per = (c.imt - 2 + nchunk - 1) / nchunk, W = per + 4;
+  std::vector<double> lds((size_t)W * c.km * 6 + (size_t)W * (c.km + 1) * 2, -7.0e33);
+  HostEnv env{nthreads};
+  const int r0 = c.js - 1 < 2 ? 2 : c.js - 1, r1 = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
+  for (int r = r0; r <= r1; ++r)
+    for (int n = c.n0 + 1; n <= c.n0 + c.nt_local; ++n)
+      for (int ch = 0; ch < nchunk; ++ch) {
+        std::fill(lds.begin(), lds.end(), -7.0e33);   // poison: reads of unwritten LDS show up
+        fct_rows_block(env, c, n, r, ch, nchunk, lds.data());
+      }
+  for (int j = c.js; j <= c.je; ++j)
+    for (int n = c.n0 + 1; n <= c.n0 + c.nt_local; ++n)
+      for (int ch = 0; ch < nchunk; ++ch) {
+        std::fill(lds.begin(), lds.end(), -7.0e33);
+        update_rows_block(env, c, n, j, ch, nchunk, lds.data());
+      }
+}
+
+extern "C" void emu_convect(const uvic_ctx *cp) {
+  const uvic_ctx &c = *cp;
+  for (int j = c.js; j <= c.je; ++j)
+    for (int i = 2; i <= c.imt - 1; ++i) convect_column(c, i, j);
+}

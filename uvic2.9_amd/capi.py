@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI (include/uvic_gpu.h -> csrc/libuvic_gpu.so).
+
+There is no CPU path: importing works anywhere (so that the symbol table can be
+checked on a GPU-less host), but creating a model instance without the HIP
+library or without a GPU raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+HEADER = PKG.parent / "include" / "uvic_gpu.h"
+LIBPATH = PKG / "csrc" / "libuvic_gpu.so"
+
+
+class UvicGpuError(RuntimeError):
+    pass
+
+
+def _parse_fields():
+    text = HEADER.read_text()
+    body = text[text.index("enum uvic_field {") + len("enum uvic_field {"):]
+    body = body[:body.index("};")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for tok in body.split(","):
+        tok = tok.strip().split("=")[0].strip()
+        if tok:
+            names.append(tok)
+    assert names[-1] == "UVIC_F_COUNT"
+    return {n[len("UVIC_F_"):].lower(): i for i, n in enumerate(names[:-1])}
+
+
+FIELD = _parse_fields()
+
+EXPORTS = [
+    "uvic_gpu_last_error", "uvic_gpu_abi_version", "uvic_gpu_create", "uvic_gpu_destroy", "uvic_gpu_upload",
+    "uvic_gpu_download", "uvic_gpu_upload_rows", "uvic_gpu_download_rows", "uvic_gpu_field_elems",
+    "uvic_gpu_field_devptr", "uvic_gpu_stream", "uvic_gpu_set_params", "uvic_gpu_set_shard", "uvic_gpu_isopyc",
+    "uvic_gpu_transport", "uvic_gpu_convect", "uvic_gpu_tracer", "uvic_gpu_rotate", "uvic_gpu_sync",
+    "uvic_gpu_profile", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async",
+]
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("imt", "jmt", "km", "nt", "nsrc", "ntnpzd")]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("c2dtts", "aidif", "diff_cet", "diff_cnt", "slmxr", "ahisop", "athkdf")]
+
+
+_lib = None
+
+
+def load():
+    """Load libuvic_gpu.so; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIBPATH.exists():
+        raise UvicGpuError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(str(LIBPATH))
+    lib.uvic_gpu_last_error.restype = ctypes.c_char_p
+    lib.uvic_gpu_field_elems.restype = ctypes.c_int64
+    lib.uvic_gpu_field_elems.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.uvic_gpu_field_devptr.restype = ctypes.c_void_p
+    lib.uvic_gpu_field_devptr.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.uvic_gpu_stream.restype = ctypes.c_void_p
+    lib.uvic_gpu_stream.argtypes = [ctypes.c_void_p]
+    lib.uvic_gpu_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(Dims), ctypes.c_int]
+    for fn in ("uvic_gpu_upload", "uvic_gpu_download"):
+        getattr(lib, fn).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    for fn in ("uvic_gpu_upload_rows", "uvic_gpu_download_rows"):
+        getattr(lib, fn).argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.uvic_gpu_set_params.argtypes = [ctypes.c_void_p, ctypes.POINTER(Params)]
+    lib.uvic_gpu_set_shard.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4
+    for fn in ("uvic_gpu_destroy", "uvic_gpu_isopyc", "uvic_gpu_transport", "uvic_gpu_convect", "uvic_gpu_tracer",
+               "uvic_gpu_rotate", "uvic_gpu_sync", "uvic_gpu_step_async", "uvic_gpu_step_pre_async",
+               "uvic_gpu_convect_async"):
+        getattr(lib, fn).argtypes = [ctypes.c_void_p]
+    lib.uvic_gpu_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise UvicGpuError(f"{what} failed (status {rc}): {load().uvic_gpu_last_error().decode()}")

@@ -1,0 +1,59 @@
+/* uvic_ctx.h -- the data contract of the tracer step on the device.
+ *
+ * One plain struct of dimensions, scalars and (device) pointers, passed by
+ * value to every kernel.  Layout conventions (package-wide):
+ * Fortran order, i fastest;  cell fields (imt,km,jmt);  vertical-face fields
+ * (imt,km+1,jmt) with face index 0..km;  2-D fields (imt,jmt);  tracers
+ * (imt,km,jmt,nt).  The reference dimensions many arrays over a sub-range of
+ * rows (updates/09/source/mom/mw.h:246-316); here every field carries all jmt
+ * rows and the C ABI maps the reference's row ranges onto them.
+ */
+#ifndef UVIC_CTX_H
+#define UVIC_CTX_H
+
+typedef struct uvic_ctx {
+  int imt, jmt, km, nt, nsrc;
+  /* scalars of the step */
+  double c2dtts, aidif, diff_cet, diff_cnt;
+  double slmxr, ahisop, athkdf;
+  /* metrics */
+  const double *dxt, *dxtr, *dxu, *dxur, *dxt4r;                  /* (imt) */
+  const double *dyt, *dytr, *dyu, *dyur, *dyt4r;                  /* (jmt) */
+  const double *cst, *cstr, *csu, *cstdytr, *cstdyt2r, *csu_dyur; /* (jmt) */
+  const double *dzt, *dztr, *dzt2r, *dztur, *dztlr;               /* (km) */
+  const double *dzw, *dzwr;                                       /* (0:km) */
+  const double *dtxcel, *dtxsqr, *dztxcl;                         /* (km) */
+  const double *to, *so, *c;                                      /* (km),(km),(km,9) */
+  const int *kmt;                                                 /* (imt,jmt) */
+  const double *tmask;                                            /* (imt,km,jmt) */
+  const double *fisop;                                            /* (imt,jmt,km) */
+  const double *addisop;                                          /* (imt,km,jmt) */
+  const double *t_taum1, *t_tau;                                  /* (imt,km,jmt,nt) */
+  double *t_taup1;
+  const double *adv_vet, *adv_vnt;                                /* (imt,km,jmt) */
+  const double *adv_vbt;                                          /* (imt,km+1,jmt) */
+  double *diff_cbt;                                               /* (imt,km,jmt) incl. K33 */
+  const double *stf, *btf;                                        /* (imt,jmt,nt) */
+  const double *src;                                              /* (imt,km,jmt,nsrc) */
+  const int *itrc;                                                /* (nt) */
+  /* isopyc products */
+  double *alphai, *betai;
+  double *ddxt, *ddyt;                                            /* (imt,km,jmt,2) */
+  double *ddzt;                                                   /* (imt,km+1,jmt,2) */
+  double *Ai_ez, *Ai_nz, *Ai_bx, *Ai_by;                          /* (imt,km,jmt,2,2) */
+  double *K11, *K22, *K33;
+  double *adv_vetiso, *adv_vntiso;
+  double *adv_vbtiso;                                             /* (imt,km+1,jmt) */
+  /* device-only work space */
+  const double *diff_cbt_bg;                                      /* (imt,km,jmt) before K33 */
+  double *tot_e, *tot_n;                                          /* adv_v?t + adv_v?tiso */
+  double *tot_b;                                                  /* (imt,km+1,jmt) */
+  double *adv_x, *adv_z;                                          /* ADV_Tx, ADV_Tz (imt,km,jmt,nt) */
+  double *RpY, *RmY;                                              /* y-limiter ratios (imt,km,jmt,nt) */
+  /* tracer-index shard handled by this context: global tracers n0+1 .. n0+nt_local */
+  int n0, nt_local;
+  /* latitude slab handled by this context (rows js..je are computed) */
+  int js, je;
+} uvic_ctx;
+
+#endif

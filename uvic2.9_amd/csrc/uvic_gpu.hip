@@ -1,0 +1,589 @@
+// uvic_gpu.hip -- gfx950 kernels' launch wrappers and the C ABI of include/uvic_gpu.h.
+//
+// GPU code only: there is no CPU path in this library.  Every entry point
+// returns a non-zero status (and sets uvic_gpu_last_error) when a HIP call
+// fails, so that the Fortran shim can `stop '=>tracer (gpu)'` like the
+// reference does on its own errors (updates/09/source/mom/tracer.F:1250).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uvic_gpu.h"
+#include "kernels_fct.hpp"
+#include "kernels_isopyc.hpp"
+#include "kernels_mobi.hpp"
+#include "uvic_ctx.h"
+
+using namespace uvic;
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+// XCD-aware work-item order: the dispatcher deals workgroups round-robin over
+// the 8 XCDs (MI355X_MICROARCH.md "Workgroup dispatch"), so block b and b+8
+// share an L2.  Remap so that each XCD walks a CONTIGUOUS range of the logical
+// work list; neighbouring tiles (same row, next tracer / next row, same tracer)
+// then hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+  const int per = (total + 7) / 8;
+  return (b % 8) * per + b / 8;
+}
+
+// decode a flat cell id into (i,k,j), i fastest
+#define CELL_DECODE(c)                                        \
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; \
+  const int i = (int)(gid % (c).imt) + 1;                     \
+  const int k = (int)((gid / (c).imt) % (c).km) + 1;          \
+  const int j = (int)(gid / ((long long)(c).imt * (c).km)) + 1
+
+__global__ void __launch_bounds__(256) k_isopyc_elements(const uvic_ctx c) {
+  CELL_DECODE(c);
+  if (j > c.jmt || i < 2 || i > c.imt - 1) return;
+  isopyc_elements_cell(c, i, k, j);
+}
+__global__ void __launch_bounds__(256) k_isopyc_ai(const uvic_ctx c) {
+  CELL_DECODE(c);
+  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  isopyc_ai_cell(c, i, k, j);
+}
+__global__ void __launch_bounds__(256) k_isopyc_adv(const uvic_ctx c) {
+  CELL_DECODE(c);
+  if (j > c.jmt - 1) return;
+  isopyc_adv_cell(c, i, k, j);
+}
+__global__ void __launch_bounds__(128) k_isopyc_column(const uvic_ctx c) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
+  if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  isopyc_column(c, i, j);
+}
+
+// one workgroup per (row, local tracer, longitude chunk)
+struct TileGrid {
+  int r0, nrows, nchunk, total;
+};
+__device__ __forceinline__ bool tile_decode(const uvic_ctx &c, const TileGrid &g, int &row, int &n1, int &chunk) {
+  const int L = xcd_remap(blockIdx.x, g.total);
+  if (L >= g.total) return false;
+  chunk = L % g.nchunk;
+  const int rest = L / g.nchunk;
+  n1 = c.n0 + rest % c.nt_local + 1;
+  row = g.r0 + rest / c.nt_local;
+  return true;
+}
+__global__ void __launch_bounds__(1024) k_fct_rows(const uvic_ctx c, const TileGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  int row, n1, chunk;
+  if (!tile_decode(c, g, row, n1, chunk)) return;
+  GpuEnv env;
+  fct_rows_block(env, c, n1, row, chunk, g.nchunk, lds);
+}
+__global__ void __launch_bounds__(1024) k_update_rows(const uvic_ctx c, const TileGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  int row, n1, chunk;
+  if (!tile_decode(c, g, row, n1, chunk)) return;
+  GpuEnv env;
+  update_rows_block(env, c, n1, row, chunk, g.nchunk, lds);
+}
+__global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
+  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  convect_column(c, i, j);
+}
+__global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
+  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  mobi_column_kernel(c, m, i, j);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const char *what, hipError_t e, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s: %s (uvic_gpu.hip:%d)", what, hipGetErrorString(e), line);
+  g_err = buf;
+  return 1;
+}
+static int fail_msg(const std::string &m) {
+  g_err = m;
+  return 2;
+}
+#define HIPCHK(x)                                   \
+  do {                                              \
+    hipError_t _e = (x);                            \
+    if (_e != hipSuccess) return fail(#x, _e, __LINE__); \
+  } while (0)
+
+enum Kind { K_IMT, K_JMT, K_KM, K_KMP1, K_KM9, K_NT, K_S, K_C, K_F };
+struct FieldDesc {
+  const char *name;
+  Kind kind;
+  int extra;  // 1, 2, 4, or -1 = nt, -2 = nsrc, -3 = km
+  bool is_int;
+};
+static const FieldDesc FIELDS[UVIC_F_COUNT] = {
+    {"dxt", K_IMT, 1, false}, {"dxtr", K_IMT, 1, false}, {"dxu", K_IMT, 1, false}, {"dxur", K_IMT, 1, false},
+    {"dxt4r", K_IMT, 1, false},
+    {"dyt", K_JMT, 1, false}, {"dytr", K_JMT, 1, false}, {"dyu", K_JMT, 1, false}, {"dyur", K_JMT, 1, false},
+    {"dyt4r", K_JMT, 1, false},
+    {"cst", K_JMT, 1, false}, {"cstr", K_JMT, 1, false}, {"csu", K_JMT, 1, false}, {"cstdytr", K_JMT, 1, false},
+    {"cstdyt2r", K_JMT, 1, false}, {"csu_dyur", K_JMT, 1, false},
+    {"dzt", K_KM, 1, false}, {"dztr", K_KM, 1, false}, {"dzt2r", K_KM, 1, false}, {"dztur", K_KM, 1, false},
+    {"dztlr", K_KM, 1, false},
+    {"dzw", K_KMP1, 1, false}, {"dzwr", K_KMP1, 1, false},
+    {"dtxcel", K_KM, 1, false}, {"dtxsqr", K_KM, 1, false}, {"dztxcl", K_KM, 1, false},
+    {"to", K_KM, 1, false}, {"so", K_KM, 1, false}, {"c", K_KM9, 1, false},
+    {"kmt", K_S, 1, true},
+    {"fisop", K_S, -3, false},
+    {"addisop", K_C, 1, false},
+    {"t_taum1", K_C, -1, false}, {"t_tau", K_C, -1, false}, {"t_taup1", K_C, -1, false},
+    {"adv_vet", K_C, 1, false}, {"adv_vnt", K_C, 1, false}, {"adv_vbt", K_F, 1, false},
+    {"diff_cbt_bg", K_C, 1, false},
+    {"stf", K_S, -1, false}, {"btf", K_S, -1, false},
+    {"src", K_C, -2, false},
+    {"itrc", K_NT, 1, true},
+    {"alphai", K_C, 1, false}, {"betai", K_C, 1, false}, {"ddxt", K_C, 2, false}, {"ddyt", K_C, 2, false},
+    {"ddzt", K_F, 2, false},
+    {"Ai_ez", K_C, 4, false}, {"Ai_nz", K_C, 4, false}, {"Ai_bx", K_C, 4, false}, {"Ai_by", K_C, 4, false},
+    {"K11", K_C, 1, false}, {"K22", K_C, 1, false}, {"K33", K_C, 1, false},
+    {"adv_vetiso", K_C, 1, false}, {"adv_vntiso", K_C, 1, false}, {"adv_vbtiso", K_F, 1, false},
+    {"diff_cbt", K_C, 1, false},
+};
+
+struct KernelStat {
+  const char *name;
+  double ms;
+  int calls;
+};
+
+struct uvic_gpu {
+  uvic_dims d;
+  int device;
+  hipStream_t stream;
+  void *buf[UVIC_F_COUNT];
+  double *work[8];  // tot_e, tot_n, tot_b, adv_x, adv_z, RpY, RmY
+  uvic_ctx ctx;
+  mobi_dev mobi;
+  void *mobi_buf;
+  bool have_mobi;
+  int nchunk, fct_threads, upd_threads;
+  size_t fct_lds, upd_lds;
+  // profiling
+  bool profiling;
+  std::vector<hipEvent_t> ev;
+  std::vector<const char *> ev_names;
+};
+
+static int64_t plane(const uvic_dims &d, Kind k) {
+  switch (k) {
+    case K_IMT: return d.imt;
+    case K_JMT: return d.jmt;
+    case K_KM: return d.km;
+    case K_KMP1: return d.km + 1;
+    case K_KM9: return (int64_t)d.km * 9;
+    case K_NT: return d.nt;
+    case K_S: return (int64_t)d.imt * d.jmt;
+    case K_C: return (int64_t)d.imt * d.km * d.jmt;
+    case K_F: return (int64_t)d.imt * (d.km + 1) * d.jmt;
+  }
+  return 0;
+}
+static int64_t extra_of(const uvic_dims &d, int e) {
+  if (e == -1) return d.nt;
+  if (e == -2) return d.nsrc > 0 ? d.nsrc : 1;
+  if (e == -3) return d.km;
+  return e;
+}
+static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f].kind) * extra_of(d, FIELDS[f].extra); }
+static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
+
+extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
+extern "C" int uvic_gpu_abi_version(void) { return 1; }
+
+static void bind_ctx(uvic_gpu *h) {
+  uvic_ctx &c = h->ctx;
+  const uvic_dims &d = h->d;
+  c.imt = d.imt; c.jmt = d.jmt; c.km = d.km; c.nt = d.nt; c.nsrc = d.nsrc;
+#define B(field, F) c.field = (decltype(c.field))h->buf[F]
+  B(dxt, UVIC_F_DXT); B(dxtr, UVIC_F_DXTR); B(dxu, UVIC_F_DXU); B(dxur, UVIC_F_DXUR); B(dxt4r, UVIC_F_DXT4R);
+  B(dyt, UVIC_F_DYT); B(dytr, UVIC_F_DYTR); B(dyu, UVIC_F_DYU); B(dyur, UVIC_F_DYUR); B(dyt4r, UVIC_F_DYT4R);
+  B(cst, UVIC_F_CST); B(cstr, UVIC_F_CSTR); B(csu, UVIC_F_CSU); B(cstdytr, UVIC_F_CSTDYTR);
+  B(cstdyt2r, UVIC_F_CSTDYT2R); B(csu_dyur, UVIC_F_CSU_DYUR);
+  B(dzt, UVIC_F_DZT); B(dztr, UVIC_F_DZTR); B(dzt2r, UVIC_F_DZT2R); B(dztur, UVIC_F_DZTUR); B(dztlr, UVIC_F_DZTLR);
+  B(dzw, UVIC_F_DZW); B(dzwr, UVIC_F_DZWR); B(dtxcel, UVIC_F_DTXCEL); B(dtxsqr, UVIC_F_DTXSQR);
+  B(dztxcl, UVIC_F_DZTXCL); B(to, UVIC_F_TO); B(so, UVIC_F_SO); B(c, UVIC_F_C);
+  B(kmt, UVIC_F_KMT); B(fisop, UVIC_F_FISOP); B(addisop, UVIC_F_ADDISOP);
+  B(t_taum1, UVIC_F_T_TAUM1); B(t_tau, UVIC_F_T_TAU); B(t_taup1, UVIC_F_T_TAUP1);
+  B(adv_vet, UVIC_F_ADV_VET); B(adv_vnt, UVIC_F_ADV_VNT); B(adv_vbt, UVIC_F_ADV_VBT);
+  B(diff_cbt_bg, UVIC_F_DIFF_CBT_BG); B(diff_cbt, UVIC_F_DIFF_CBT);
+  B(stf, UVIC_F_STF); B(btf, UVIC_F_BTF); B(itrc, UVIC_F_ITRC);
+  c.src = d.nsrc > 0 ? (const double *)h->buf[UVIC_F_SRC] : nullptr;
+  B(alphai, UVIC_F_ALPHAI); B(betai, UVIC_F_BETAI); B(ddxt, UVIC_F_DDXT); B(ddyt, UVIC_F_DDYT); B(ddzt, UVIC_F_DDZT);
+  B(Ai_ez, UVIC_F_AI_EZ); B(Ai_nz, UVIC_F_AI_NZ); B(Ai_bx, UVIC_F_AI_BX); B(Ai_by, UVIC_F_AI_BY);
+  B(K11, UVIC_F_K11); B(K22, UVIC_F_K22); B(K33, UVIC_F_K33);
+  B(adv_vetiso, UVIC_F_ADV_VETISO); B(adv_vntiso, UVIC_F_ADV_VNTISO); B(adv_vbtiso, UVIC_F_ADV_VBTISO);
+#undef B
+  c.tot_e = h->work[0]; c.tot_n = h->work[1]; c.tot_b = h->work[2];
+  c.adv_x = h->work[3]; c.adv_z = h->work[4]; c.RpY = h->work[5]; c.RmY = h->work[6];
+}
+
+// the t(:,:,:,:,-1:1) slots rotate by pointer; tmask is derived from kmt on upload
+static int make_tmask(uvic_gpu *h);
+
+extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device) {
+  if (!out || !dims) return fail_msg("uvic_gpu_create: null argument");
+  if (dims->imt < 6 || dims->jmt < 6 || dims->km < 2 || dims->nt < 2)
+    return fail_msg("uvic_gpu_create: dimensions too small (need imt,jmt >= 6, km >= 2, nt >= 2)");
+  HIPCHK(hipSetDevice(device));
+  uvic_gpu *h = new uvic_gpu();
+  h->d = *dims;
+  h->device = device;
+  h->profiling = false;
+  h->have_mobi = false;
+  h->mobi_buf = nullptr;
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (int f = 0; f < UVIC_F_COUNT; ++f) {
+    const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
+    HIPCHK(hipMalloc(&h->buf[f], bytes));
+    HIPCHK(hipMemset(h->buf[f], 0, bytes));
+  }
+  const size_t N3 = (size_t)dims->imt * dims->km * dims->jmt, NF = (size_t)dims->imt * (dims->km + 1) * dims->jmt;
+  const size_t wsz[7] = {N3, N3, NF, N3 * dims->nt, N3 * dims->nt, N3 * dims->nt, N3 * dims->nt};
+  for (int w = 0; w < 7; ++w) {
+    HIPCHK(hipMalloc((void **)&h->work[w], wsz[w] * 8));
+    HIPCHK(hipMemset(h->work[w], 0, wsz[w] * 8));
+  }
+  // tmask lives in its own buffer (derived data)
+  double *tmask;
+  HIPCHK(hipMalloc((void **)&tmask, N3 * 8));
+  HIPCHK(hipMemset(tmask, 0, N3 * 8));
+  memset(&h->ctx, 0, sizeof h->ctx);
+  h->ctx.tmask = tmask;
+  bind_ctx(h);
+  h->ctx.n0 = 0; h->ctx.nt_local = dims->nt; h->ctx.js = 2; h->ctx.je = dims->jmt - 1;
+  h->ctx.c2dtts = 0.0; h->ctx.aidif = 0.5;
+  // tile geometry: keep the FCT tile within the LDS budget
+  int budget_kb = 150;
+  if (const char *e = getenv("UVIC_LDS_BUDGET_KB")) budget_kb = atoi(e);
+  h->fct_threads = 1024;
+  if (const char *e = getenv("UVIC_FCT_THREADS")) h->fct_threads = atoi(e);
+  h->upd_threads = 512;
+  if (const char *e = getenv("UVIC_UPD_THREADS")) h->upd_threads = atoi(e);
+  int nchunk = 1;
+  for (;; ++nchunk) {
+    const int per = (dims->imt - 2 + nchunk - 1) / nchunk;
+    const int W = per + 4;
+    const size_t need = ((size_t)W * dims->km * 6 + (size_t)W * (dims->km + 1) * 2) * 8;
+    if (need <= (size_t)budget_kb * 1024 || per <= 8) break;
+  }
+  if (const char *e = getenv("UVIC_NCHUNK")) nchunk = atoi(e);
+  h->nchunk = nchunk;
+  {
+    const int per = (dims->imt - 2 + nchunk - 1) / nchunk;
+    const int W = per + 4;
+    h->fct_lds = ((size_t)W * dims->km * 6 + (size_t)W * (dims->km + 1) * 2) * 8;
+    h->upd_lds = ((size_t)W * dims->km * 3 + (size_t)W * (dims->km + 1) * 2) * 8;
+  }
+  HIPCHK(hipFuncSetAttribute((const void *)k_fct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fct_lds));
+  HIPCHK(hipFuncSetAttribute((const void *)k_update_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->upd_lds));
+  HIPCHK(hipDeviceSynchronize());
+  *out = h;
+  return 0;
+}
+
+extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
+  for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
+  (void)hipFree((void *)h->ctx.tmask);
+  if (h->mobi_buf) (void)hipFree(h->mobi_buf);
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+extern "C" int64_t uvic_gpu_field_elems(uvic_gpu *h, int field) {
+  if (!h || field < 0 || field >= UVIC_F_COUNT) return -1;
+  return field_elems(h->d, field);
+}
+extern "C" void *uvic_gpu_field_devptr(uvic_gpu *h, int field) {
+  if (!h || field < 0 || field >= UVIC_F_COUNT) return nullptr;
+  return h->buf[field];
+}
+extern "C" void *uvic_gpu_stream(uvic_gpu *h) { return h ? (void *)h->stream : nullptr; }
+
+__global__ void k_make_tmask(const int *kmt, double *tmask, int imt, int km, int jmt) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)imt * km * jmt;
+  if (gid >= n) return;
+  const int i = (int)(gid % imt), k = (int)((gid / imt) % km), j = (int)(gid / ((long long)imt * km));
+  // updates/09/source/mom/loadmw.F:60-78
+  tmask[gid] = (kmt[i + (size_t)imt * j] >= k + 1) ? 1.0 : 0.0;
+}
+static int make_tmask(uvic_gpu *h) {
+  const long long n = (long long)h->d.imt * h->d.km * h->d.jmt;
+  hipLaunchKernelGGL(k_make_tmask, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx.kmt,
+                     (double *)h->ctx.tmask, h->d.imt, h->d.km, h->d.jmt);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t offset, int64_t count) {
+  if (!h || !host) return fail_msg("uvic_gpu_upload: null argument");
+  if (field < 0 || field >= UVIC_F_COUNT) return fail_msg("uvic_gpu_upload: bad field id");
+  const int64_t n = field_elems(h->d, field);
+  if (offset < 0 || count < 0 || offset + count > n) return fail_msg(std::string("uvic_gpu_upload: range outside field ") + FIELDS[field].name);
+  HIPCHK(hipSetDevice(h->device));
+  const size_t es = elem_size(field);
+  HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (field == UVIC_F_KMT) return make_tmask(h);
+  return 0;
+}
+extern "C" int uvic_gpu_download(uvic_gpu *h, int field, void *host, int64_t offset, int64_t count) {
+  if (!h || !host) return fail_msg("uvic_gpu_download: null argument");
+  if (field < 0 || field >= UVIC_F_COUNT) return fail_msg("uvic_gpu_download: bad field id");
+  const int64_t n = field_elems(h->d, field);
+  if (offset < 0 || count < 0 || offset + count > n) return fail_msg(std::string("uvic_gpu_download: range outside field ") + FIELDS[field].name);
+  HIPCHK(hipSetDevice(h->device));
+  const size_t es = elem_size(field);
+  HIPCHK(hipMemcpyAsync(host, (const char *)h->buf[field] + offset * es, count * es, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, bool up) {
+  if (!h || !host) return fail_msg("uvic_gpu_*_rows: null argument");
+  if (field < 0 || field >= UVIC_F_COUNT || FIELDS[field].is_int) return fail_msg("uvic_gpu_*_rows: bad field id");
+  const Kind kd = FIELDS[field].kind;
+  if (kd != K_S && kd != K_C && kd != K_F) return fail_msg("uvic_gpu_*_rows: field has no row dimension");
+  if (jlo < 1 || jhi > h->d.jmt || jlo > jhi) return fail_msg("uvic_gpu_*_rows: row range outside 1..jmt");
+  const int64_t rowlen = plane(h->d, kd) / h->d.jmt;
+  const int64_t ex = extra_of(h->d, FIELDS[field].extra);
+  const int64_t nrows = jhi - jlo + 1;
+  HIPCHK(hipSetDevice(h->device));
+  for (int64_t e = 0; e < ex; ++e) {
+    char *dev = (char *)h->buf[field] + (e * plane(h->d, kd) + (int64_t)(jlo - 1) * rowlen) * 8;
+    char *hst = (char *)host + e * nrows * rowlen * 8;
+    if (up)
+      HIPCHK(hipMemcpyAsync(dev, hst, nrows * rowlen * 8, hipMemcpyHostToDevice, h->stream));
+    else
+      HIPCHK(hipMemcpyAsync(hst, dev, nrows * rowlen * 8, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int uvic_gpu_upload_rows(uvic_gpu *h, int field, const double *host, int jlo, int jhi) {
+  return rows_xfer(h, field, (double *)host, jlo, jhi, true);
+}
+extern "C" int uvic_gpu_download_rows(uvic_gpu *h, int field, double *host, int jlo, int jhi) {
+  return rows_xfer(h, field, host, jlo, jhi, false);
+}
+
+extern "C" int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p) {
+  if (!h || !p) return fail_msg("uvic_gpu_set_params: null argument");
+  h->ctx.c2dtts = p->c2dtts; h->ctx.aidif = p->aidif;
+  h->ctx.diff_cet = p->diff_cet; h->ctx.diff_cnt = p->diff_cnt;
+  h->ctx.slmxr = p->slmxr; h->ctx.ahisop = p->ahisop; h->ctx.athkdf = p->athkdf;
+  return 0;
+}
+extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je) {
+  if (!h) return fail_msg("uvic_gpu_set_shard: null handle");
+  if (n0 < 0 || nt_local < 0 || n0 + nt_local > h->d.nt) return fail_msg("uvic_gpu_set_shard: tracer range outside 1..nt");
+  if (js < 2 || je > h->d.jmt - 1 || js > je) return fail_msg("uvic_gpu_set_shard: row range outside 2..jmt-1");
+  h->ctx.n0 = n0; h->ctx.nt_local = nt_local; h->ctx.js = js; h->ctx.je = je;
+  return 0;
+}
+
+// -- launch helpers ------------------------------------------------------------
+static void mark(uvic_gpu *h, const char *name) {
+  if (!h->profiling) return;
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  (void)hipEventRecord(e, h->stream);
+  h->ev.push_back(e);
+  h->ev_names.push_back(name);
+}
+static unsigned cell_blocks(const uvic_gpu *h, int bs) {
+  const long long n = (long long)h->d.imt * h->d.km * h->d.jmt;
+  return (unsigned)((n + bs - 1) / bs);
+}
+static unsigned col_blocks(const uvic_gpu *h, int bs) {
+  const long long n = (long long)h->d.imt * h->d.jmt;
+  return (unsigned)((n + bs - 1) / bs);
+}
+
+static int launch_isopyc(uvic_gpu *h) {
+  const uvic_ctx &c = h->ctx;
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
+  mark(h, "isopyc_elements");
+  hipLaunchKernelGGL(k_isopyc_ai, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
+  mark(h, "isopyc_ai");
+  hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
+  mark(h, "isopyc_adv");
+  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, c);
+  mark(h, "isopyc_column");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_transport(uvic_gpu *h) {
+  const uvic_ctx &c = h->ctx;
+  if (c.nt_local <= 0) return 0;
+  if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
+  TileGrid g1, g2;
+  g1.r0 = c.js - 1 < 2 ? 2 : c.js - 1;
+  const int r1 = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
+  g1.nrows = r1 - g1.r0 + 1;
+  g1.nchunk = h->nchunk;
+  g1.total = g1.nrows * c.nt_local * h->nchunk;
+  g2.r0 = c.js; g2.nrows = c.je - c.js + 1; g2.nchunk = h->nchunk;
+  g2.total = g2.nrows * c.nt_local * h->nchunk;
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_fct_rows, dim3((unsigned)(((g1.total + 7) / 8) * 8)), dim3(h->fct_threads), h->fct_lds, h->stream, c, g1);
+  mark(h, "fct_rows");
+  hipLaunchKernelGGL(k_update_rows, dim3((unsigned)(((g2.total + 7) / 8) * 8)), dim3(h->upd_threads), h->upd_lds, h->stream, c, g2);
+  mark(h, "update_rows");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_convect(uvic_gpu *h) {
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_convect, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx);
+  mark(h, "convect");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_mobi(uvic_gpu *h) {
+  if (!h->have_mobi) return 0;
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
+  mark(h, "mobi");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int uvic_gpu_isopyc(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_isopyc(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int uvic_gpu_transport(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_transport(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int uvic_gpu_convect(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_convect(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int launch_tracer(uvic_gpu *h) {
+  if (int rc = launch_mobi(h)) return rc;
+  if (int rc = launch_transport(h)) return rc;
+  if (int rc = launch_convect(h)) return rc;
+  return 0;
+}
+extern "C" int uvic_gpu_tracer(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_tracer(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// asynchronous variants used by the time loop of bench.py: no host sync
+extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  if (int rc = launch_isopyc(h)) return rc;
+  return launch_tracer(h);
+}
+// sharded time loop: everything before the exchange of t(tau+1) ...
+extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  if (int rc = launch_isopyc(h)) return rc;
+  if (int rc = launch_mobi(h)) return rc;
+  return launch_transport(h);
+}
+// ... and convection (all tracers, needs T,S of every column) after it
+extern "C" int uvic_gpu_convect_async(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  return launch_convect(h);
+}
+extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  void *m1 = h->buf[UVIC_F_T_TAUM1], *t0 = h->buf[UVIC_F_T_TAU], *p1 = h->buf[UVIC_F_T_TAUP1];
+  h->buf[UVIC_F_T_TAUM1] = t0;
+  h->buf[UVIC_F_T_TAU] = p1;
+  h->buf[UVIC_F_T_TAUP1] = m1;
+  bind_ctx(h);
+  return 0;
+}
+extern "C" int uvic_gpu_sync(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
+  if (!h || !names || !mean_ms || !nkernels) return fail_msg("uvic_gpu_profile: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  for (auto e : h->ev) (void)hipEventDestroy(e);
+  h->ev.clear();
+  h->ev_names.clear();
+  h->profiling = true;
+  int rc = 0;
+  for (int r = 0; r < nrep && !rc; ++r) {
+    rc = launch_isopyc(h);
+    if (!rc) rc = launch_tracer(h);
+  }
+  h->profiling = false;
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<KernelStat> st;
+  for (size_t e = 1; e < h->ev.size(); ++e) {
+    if (strcmp(h->ev_names[e], "begin") == 0) continue;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[e - 1], h->ev[e]));
+    bool found = false;
+    for (auto &s : st)
+      if (strcmp(s.name, h->ev_names[e]) == 0) {
+        s.ms += ms; s.calls++; found = true;
+      }
+    if (!found) st.push_back({h->ev_names[e], (double)ms, 1});
+  }
+  int n = 0;
+  for (auto &s : st) {
+    if (n >= max_kernels) break;
+    names[n] = s.name;
+    mean_ms[n] = s.ms / s.calls;
+    ++n;
+  }
+  *nkernels = n;
+  return 0;
+}
+
+// -- MOBI parameters -------------------------------------------------------------
+extern "C" int uvic_gpu_set_mobi(uvic_gpu *h, const mobi_host *m) {
+  if (!h || !m) return fail_msg("uvic_gpu_set_mobi: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  return mobi_bind(h->d.imt, h->d.jmt, h->d.km, m, &h->mobi, &h->mobi_buf, h->stream, &h->have_mobi, g_err);
+}

@@ -333,3 +333,41 @@ def make_ocean(cfg="c30", imt=102, jmt=102, km=19) -> Ocean:
     prm = SimpleNamespace(dtts=108000.0, aidif=0.5, kappa_h=kappa_h, diff_cet=1.0e5, diff_cnt=1.0e5,
                           slmx=0.01, ahisop=1.2e7, athkdf=8.0e6, nmix=16)
     return Ocean(cfg, g, topo, t0, t1, u, vet, vnt, vbt, dcb, stf, btf, fisop, addisop, frc, prm)
+
+
+def load_eos(km: int):
+    """Equation-of-state reference profiles and polynomial coefficients
+    `to(km), so(km), c(km,9)` (source/mom/state.h:38) for the synthetic vertical
+    grid with `km` levels.  They are outputs of the reference's `eqstate`
+    (source/mom/denscoef.F, initialisation -- out of scope),
+    stored by tests/golden/make_golden.py in data/eos.json."""
+    import json
+    from pathlib import Path
+    tab = json.loads((Path(__file__).resolve().parent / "data" / "eos.json").read_text())
+    if str(km) not in tab:
+        raise KeyError(f"no equation-of-state table for km={km}; available: {sorted(tab)}")
+    e = tab[str(km)]
+    to = np.array(e["to"], dtype=np.float64)
+    so = np.array(e["so"], dtype=np.float64)
+    c = np.asfortranarray(np.array(e["c"], dtype=np.float64).T)
+    return to, so, c
+
+
+def pad_tracers(ocean: Ocean, nt_model: int) -> Ocean:
+    """Append inert (all-zero, source-free) tracers so that the tracer dimension
+    is a multiple of the number of ranks (parallel.py)."""
+    import copy
+    from dataclasses import replace
+    nt = ocean.cfg.nt
+    extra = nt_model - nt
+    if extra <= 0:
+        return ocean
+    cfg = OptionSet(ocean.cfg.name, ocean.cfg.tracers + tuple(f"pad{n}" for n in range(extra)),
+                    ocean.cfg.sources, ocean.cfg.mobi, ocean.cfg.options)
+
+    def pad(a, axis):
+        shp = list(a.shape)
+        shp[axis] = extra
+        return np.asfortranarray(np.concatenate([a, np.zeros(shp)], axis=axis))
+    return replace(copy.copy(ocean), cfg=cfg, t_taum1=pad(ocean.t_taum1, 3), t_tau=pad(ocean.t_tau, 3),
+                   stf=pad(ocean.stf, 2), btf=pad(ocean.btf, 2))

@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference's ocean tracer entry points.
+
+`TracerModel` owns one device-resident model instance (C ABI handle) and exposes
+the calls that `subroutine mom` makes on the tracer path, with the same names,
+argument meaning and error behaviour:
+
+    isopyc(joff, js, je, is_, ie)   <- /root/reference/source/mom/mom.F:340
+    tracer(joff, js, je, is_, ie)   <- /root/reference/source/mom/mom.F:389
+
+In the reference all bulk data travel through COMMON blocks; here the fields of
+those blocks are device buffers addressed by name (`upload('t_taum1', a)`,
+`download('t_taup1')`).  Arrays are numpy, Fortran order, shaped as listed in
+include/uvic_gpu.h.  Everything computes on the GPU through libuvic_gpu.so.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import capi
+from .capi import FIELD, Dims, Params, UvicGpuError, check
+
+_GRID_1D = ("dxt", "dxtr", "dxu", "dxur", "dxt4r", "dyt", "dytr", "dyu", "dyur", "dyt4r", "cst", "cstr", "csu",
+            "cstdytr", "cstdyt2r", "csu_dyur", "dzt", "dztr", "dzt2r", "dztur", "dztlr", "dzw", "dzwr",
+            "dtxcel", "dtxsqr", "dztxcl")
+
+
+class TracerModel:
+    def __init__(self, imt, jmt, km, nt, nsrc=0, ntnpzd=0, device=0):
+        self.lib = capi.load()
+        self.dims = Dims(imt, jmt, km, nt, nsrc, ntnpzd)
+        self.imt, self.jmt, self.km, self.nt, self.nsrc = imt, jmt, km, nt, nsrc
+        self.h = ctypes.c_void_p()
+        check(self.lib.uvic_gpu_create(ctypes.byref(self.h), ctypes.byref(self.dims), device), "uvic_gpu_create")
+        self.params = Params()
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.uvic_gpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data movement -----------------------------------------------------------
+    def shape(self, name):
+        imt, jmt, km, nt, nsrc = self.imt, self.jmt, self.km, self.nt, max(self.nsrc, 1)
+        C, Fc, S = (imt, km, jmt), (imt, km + 1, jmt), (imt, jmt)
+        table = {
+            "kmt": S, "fisop": (imt, jmt, km), "addisop": C, "t_taum1": C + (nt,), "t_tau": C + (nt,),
+            "t_taup1": C + (nt,), "adv_vet": C, "adv_vnt": C, "adv_vbt": Fc, "diff_cbt_bg": C,
+            "stf": S + (nt,), "btf": S + (nt,), "src": C + (nsrc,), "itrc": (nt,), "alphai": C, "betai": C,
+            "ddxt": C + (2,), "ddyt": C + (2,), "ddzt": Fc + (2,), "ai_ez": C + (2, 2), "ai_nz": C + (2, 2),
+            "ai_bx": C + (2, 2), "ai_by": C + (2, 2), "k11": C, "k22": C, "k33": C, "adv_vetiso": C,
+            "adv_vntiso": C, "adv_vbtiso": Fc, "diff_cbt": C, "to": (km,), "so": (km,), "c": (km, 9),
+        }
+        if name in table:
+            return table[name]
+        if name in ("dxt", "dxtr", "dxu", "dxur", "dxt4r"):
+            return (imt,)
+        if name in ("dzw", "dzwr"):
+            return (km + 1,)
+        if name in ("dzt", "dztr", "dzt2r", "dztur", "dztlr", "dtxcel", "dtxsqr", "dztxcl"):
+            return (km,)
+        return (jmt,)
+
+    def upload(self, name, array):
+        f = FIELD[name.lower()]
+        dt = np.int32 if name.lower() in ("kmt", "itrc") else np.float64
+        a = np.asfortranarray(array, dtype=dt)
+        if a.shape != self.shape(name.lower()):
+            raise UvicGpuError(f"upload({name}): shape {a.shape} != {self.shape(name.lower())}")
+        check(self.lib.uvic_gpu_upload(self.h, f, a.ctypes.data_as(ctypes.c_void_p), 0, a.size), f"upload({name})")
+
+    def download(self, name):
+        f = FIELD[name.lower()]
+        dt = np.int32 if name.lower() in ("kmt", "itrc") else np.float64
+        a = np.zeros(self.shape(name.lower()), dtype=dt, order="F")
+        check(self.lib.uvic_gpu_download(self.h, f, a.ctypes.data_as(ctypes.c_void_p), 0, a.size), f"download({name})")
+        return a
+
+    def upload_rows(self, name, array, jlo, jhi):
+        """`array` dimensioned (imt, kdim, jlo:jhi[, extra]) as in the reference's COMMON."""
+        a = np.asfortranarray(array, dtype=np.float64)
+        check(self.lib.uvic_gpu_upload_rows(self.h, FIELD[name.lower()], a.ctypes.data_as(ctypes.c_void_p), jlo, jhi),
+              f"upload_rows({name})")
+
+    def devptr(self, name):
+        return self.lib.uvic_gpu_field_devptr(self.h, FIELD[name.lower()])
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            setattr(self.params, k, v)
+        check(self.lib.uvic_gpu_set_params(self.h, ctypes.byref(self.params)), "set_params")
+
+    def set_shard(self, n0=0, nt_local=None, js=2, je=None):
+        nt_local = self.nt - n0 if nt_local is None else nt_local
+        je = self.jmt - 1 if je is None else je
+        check(self.lib.uvic_gpu_set_shard(self.h, n0, nt_local, js, je), "set_shard")
+
+    def load_ocean(self, ocean, to, so, c, src=None):
+        """Upload every static and per-step input from a synthetic Ocean."""
+        g, topo, prm, cfg = ocean.grid, ocean.topo, ocean.params, ocean.cfg
+        for n in _GRID_1D:
+            self.upload(n, getattr(g, n))
+        self.upload("to", to)
+        self.upload("so", so)
+        self.upload("c", c)
+        self.upload("kmt", topo.kmt)
+        self.upload("fisop", ocean.fisop)
+        self.upload("addisop", ocean.addisop)
+        self.upload("t_taum1", ocean.t_taum1)
+        self.upload("t_tau", ocean.t_tau)
+        self.upload("adv_vet", ocean.adv_vet)
+        self.upload("adv_vnt", ocean.adv_vnt)
+        self.upload("adv_vbt", ocean.adv_vbt)
+        self.upload("diff_cbt_bg", ocean.diff_cbt_bg)
+        self.upload("stf", ocean.stf)
+        self.upload("btf", ocean.btf)
+        self.upload("itrc", np.array(cfg.itrc(), dtype=np.int32))
+        if src is not None:
+            self.upload("src", src)
+        self.set_params(c2dtts=2.0 * prm.dtts, aidif=prm.aidif, diff_cet=prm.diff_cet, diff_cnt=prm.diff_cnt,
+                        slmxr=1.0 / prm.slmx, ahisop=prm.ahisop, athkdf=prm.athkdf)
+
+    # -- the reference's entry points ------------------------------------------------
+    def _check_window(self, who, joff, js, je, is_, ie, js_expected):
+        if js > je:            # `if (js .gt. je) return`, tracer.F:219 / vmixc etc.
+            return False
+        if joff != 0 or is_ != 2 or ie != self.imt - 1 or js != js_expected[0] or je != js_expected[1]:
+            # the reference runs one memory window covering all rows (jmw = jmt,
+            # updates/09/source/common/size.h:155)
+            raise UvicGpuError(f"{who}: only the single full memory window is supported "
+                               f"(joff=0, js={js_expected[0]}, je={js_expected[1]}, is=2, ie=imt-1)")
+        return True
+
+    def isopyc(self, joff=0, js=1, je=None, is_=2, ie=None):
+        je = self.jmt if je is None else je
+        ie = self.imt - 1 if ie is None else ie
+        if self._check_window("isopyc", joff, js, je, is_, ie, (1, self.jmt)):
+            check(self.lib.uvic_gpu_isopyc(self.h), "isopyc")
+
+    def tracer(self, joff=0, js=2, je=None, is_=2, ie=None):
+        je = self.jmt - 1 if je is None else je
+        ie = self.imt - 1 if ie is None else ie
+        if self._check_window("tracer", joff, js, je, is_, ie, (2, self.jmt - 1)):
+            check(self.lib.uvic_gpu_tracer(self.h), "tracer")
+
+    def transport(self):
+        check(self.lib.uvic_gpu_transport(self.h), "transport")
+
+    def convect(self):
+        check(self.lib.uvic_gpu_convect(self.h), "convect")
+
+    def step_async(self):
+        check(self.lib.uvic_gpu_step_async(self.h), "step_async")
+
+    def rotate(self):
+        check(self.lib.uvic_gpu_rotate(self.h), "rotate")
+
+    def sync(self):
+        check(self.lib.uvic_gpu_sync(self.h), "sync")
+
+    def profile(self, nrep=5):
+        names = (ctypes.c_char_p * 32)()
+        ms = (ctypes.c_double * 32)()
+        n = ctypes.c_int()
+        check(self.lib.uvic_gpu_profile(self.h, nrep, 32, names, ms, ctypes.byref(n)), "profile")
+        return {names[i].decode(): ms[i] for i in range(n.value)}
