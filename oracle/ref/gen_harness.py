@@ -140,6 +140,7 @@ def emit(inc_dir: Path, out: Path):
         L("      return")
         L("      end")
         L("")
+    lines += ["      subroutine orc_flush", "      flush(6)", "      return", "      end", ""]
     lines.append("      subroutine orc_register_all")
     lines.append("      implicit none")
     for s in subs:

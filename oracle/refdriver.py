@@ -63,10 +63,7 @@ class RefOcean:
     def _restore(self, saved):
         if saved is None:
             return
-        try:
-            self.ref.lib._FortranAioFlush  # noqa: B018  (may not exist)
-        except AttributeError:
-            pass
+        self.ref.lib.orc_flush_()      # drain the Fortran runtime's unit-6 buffer into /dev/null
         os.dup2(saved, 1)
         os.close(saved)
 
