@@ -69,16 +69,23 @@ def cpu_baseline(ocean, to, so, c, src, budget_s=20.0):
         except Exception as e:  # fall through to the C port
             print(f"[bench] reference baseline unavailable: {e}", file=sys.stderr)
     orc = oracle_c.Oracle(ocean, to=to, so=so, c=c, src=src)
+    prm = None
+    if cfg.ntnpzd:
+        import mobi_c
+        from uvic29_amd import mobi as pm
+        prm = pm.load_table(cfg.name, g.km)
     n, t0 = 0, time.perf_counter()
     while True:
+        if prm is not None:
+            orc.set_src(mobi_c.mobi_sources(ocean, prm, ocean.t_taum1, 2.0 * ocean.params.dtts))
         orc.isopyc(); orc.add_k33(); orc.transport()
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 5:
             break
     return {"value": units * n / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"{n} isopyc+transport+convection steps of the C oracle (gcc -O2 -ffp-contract=off), "
-                      f"{cfg.name} {g.imt}x{g.jmt}x{g.km}, sources given"}
+            "sample": f"{n} full steps (isopyc, {'MOBI sources, ' if prm is not None else ''}transport, convection) of the C "
+                      f"oracle (gcc -O2 -ffp-contract=off), {cfg.name} {g.imt}x{g.jmt}x{g.km}"}
 
 
 def main():
@@ -114,7 +121,7 @@ def main():
     to, so, c = synthetic.load_eos(km)
     nt, nsrc = cfg.nt, cfg.nsrc
     src = None
-    if nsrc:
+    if nsrc and not cfg.ntnpzd:      # passive performance shapes: a given source term
         rng = np.random.default_rng(2029)
         src = np.asfortranarray(rng.standard_normal((imt, km, jmt, nsrc)) * 1e-10 * ocean.topo.tmask[..., None])
 
@@ -124,6 +131,8 @@ def main():
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, nsrc, cfg.ntnpzd, device=local_rank)
     m.load_ocean(ocean, to, so, c, src=src)
+    if cfg.ntnpzd:
+        m.set_mobi(ocean)
     shard.apply(m)
 
     def one_step():
@@ -170,7 +179,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
                                    f"(FCT adv_flux, isoflux, explicit update, invtri, convct2"
-                                   f"{', MOBI sources' if m_has_mobi(m) else ', source term given (MOBI column kernel not in this build)'})",
+                                   f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",
                        "grid": a.grid, "nt": nt, "parallelism": f"tracer-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,

@@ -73,6 +73,55 @@ typedef struct uvic_params {
   double ahisop, athkdf; /* isopyc.F:79-83 */
 } uvic_params;
 
+/* ---- MOBI biogeochemistry (option set C) --------------------- */
+/* 1-based positions, 0 = absent.  `im`: position in the MOBI column vector
+ * (imobi*, u09/mom/mobi.F:440-504); `is`: source slot (is*, u09/common/UVic_ESCM.F:1376-1483) */
+typedef struct uvic_mobi_index {
+  int32_t po4, phyt, phyt_phos, zoop, detr, detr_phos, dic, dic13, phytc13, zoopc13, detrc13, doc13, diazc13;
+  int32_t dop, no3, don, diaz, din15, don15, phytn15, zoopn15, detrn15, diazn15, dfe, detrfe, alk, o2, c14;
+} uvic_mobi_index;
+
+/* COMMON /npzd_r/ after mobi_init (u09/mom/mobi.h:144-262, unit conversions
+ * u09/mom/mobi.F:209-290, 432-438) and the vertical grid (coord.h, grdvar.h) */
+typedef struct uvic_mobi_params {
+  int32_t km, ntnpzd, nsrc, pad_;
+  uvic_mobi_index im, is;
+  int32_t tracer_of_mobi[40]; /* prognostic tracer index (1-based) of MOBI tracer m */
+  int32_t slot_of_mobi[40];   /* source slot (1-based) of MOBI tracer m */
+  int32_t itemp, isalt, idic, ialk, io2, ic14;
+  double dtnpzd;
+  double kw, kc, ki, tap, abio_P, bbio, cbio, nup, nup_D, nupt0, nupt0_D, gamma1, gbio, nuz, nud0, nudon0, nudop0;
+  double redptn, redctn, redntp, redotc, redntc, diazntp, diazptn, kzoo, geZ;
+  double zprefP, zprefDet, zprefZ, zprefDiaz;
+  double kfe_D, kfemin, kfemax, knmin, knmax, pmax, thetamaxlo, thetamaxhi, alphamin, alphamax;
+  double kfeleq, kfeorg, kfecol, mc, rfeton, iscr, jdiar, dbct_D, hdop, dfr, dfrt, pfr;
+  double eps_assim, eps_recy, eps_excr, eps_nfix, eps_wcdeni, eps_bdeni0, capr;
+  double wd[64], ztt[64], rcak[64], rcab[64];
+  double zt[64], dzt[64], dztr[64];
+} uvic_mobi_params;
+
+/* 2-D/3-D inputs MOBI reads from other components' COMMON blocks
+ * (u09/mom/tracer.F:370-390, 538-545): host arrays, copied by the call */
+typedef struct uvic_mobi_forcing {
+  double pi, radian;       /* ndcon, scalar.h */
+  double relyr;            /* tmngr.h: year fraction -> month index and solar declination */
+  double co2ccn;           /* cembm.h */
+  const double *tlat;      /* (imt,jmt) grdvar.h */
+  const double *dnswr;     /* (imt,jmt) u09/embm/atm.h:86 */
+  const double *aice, *hice, *hsno; /* (imt,jmt) ice.h, time level 2 */
+  const double *sg_bathy;  /* (imt,jmt,km) levind.h */
+  const double *fe_atmdep; /* (imt,jmt,12) mobi.h fe_atmdep(imt,jmt,1,12) */
+  const double *fe_hydr;   /* (imt,jmt,km) mobi.h */
+} uvic_mobi_forcing;
+
+/* upload MOBI parameters and forcing; after this uvic_gpu_tracer computes the
+ * source terms itself (replaces the column loop of u09/mom/tracer.F:355-545 with
+ * mobi_driver/mobi_src/co2calc_SWS and the 14C source, tracer.F:853-867) instead
+ * of reading UVIC_F_SRC as given */
+int uvic_gpu_set_mobi(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_forcing *f);
+/* the source-term kernel alone (for parity tests): fills UVIC_F_SRC */
+int uvic_gpu_mobi(uvic_gpu *h);
+
 const char *uvic_gpu_last_error(void);
 int uvic_gpu_abi_version(void);
 

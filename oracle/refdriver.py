@@ -109,9 +109,11 @@ class RefOcean:
                 try:
                     err = np.zeros(1, dtype=np.int32)
                     self.ref.call("isopi", err, 1.5e9, prm.diff_cet)
-                    if cfg.ntnpzd:
+                    if cfg.ntnpzd and (REF / "run" / "control.in").exists():
                         Path("control.in").write_text(trimmed_control_in(cfg.options))
                         self.ref.call("mobi_init")
+                    elif cfg.ntnpzd:
+                        self._mobi_from_fixture(cfg, km)
                 finally:
                     os.chdir(cwd)
         finally:
@@ -138,6 +140,17 @@ class RefOcean:
             v["fe_atmdep"][:, :, 0, :] = f.fe_atmdep
             v["fe_hydr"][...] = f.fe_hydr
         self.diff_cbt_bg = oc.diff_cbt_bg
+
+    def _mobi_from_fixture(self, cfg, km):
+        """GPU box: /root/reference (hence run/control.in) is absent, so COMMON /npzd_r/
+        and the imobi* indices are set from the committed fixture that mobi_init produced
+        in the build container (uvic2.9_amd/data/mobi_<cfg>.json)."""
+        from uvic29_amd import mobi as pm
+        tab = pm.load_table(cfg.name, km)
+        for n, val in tab.items():
+            self.v[n][...] = np.asarray(val).reshape(self.v[n].shape, order="F")
+        for m, name in enumerate(cfg.mobi):
+            self.ref.set("imobi" + name, m + 1)
 
     def load_state(self, t_taum1, t_tau):
         self.v["t"][..., 0] = t_taum1

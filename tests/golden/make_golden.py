@@ -53,6 +53,32 @@ def eos_fixture():
     print("wrote", p)
 
 
+MOBI_SCALARS = ("kw kc ki tap abio_p bbio cbio nup nup_d nupt0 nupt0_d gamma1 gbio nuz nud0 nudon0 nudop0 "
+                "redptn redctn redntp redotc redntc diazntp diazptn kzoo gez zprefp zprefdet zprefz zprefdiaz "
+                "kfe_d kfemin kfemax knmin knmax pmax thetamaxlo thetamaxhi alphamin alphamax "
+                "kfeleq kfeorg kfecol mc rfeton iscr jdiar dbct_d hdop dfr dfrt pfr "
+                "eps_assim eps_recy eps_excr eps_nfix eps_wcdeni eps_bdeni0 capr dtnpzd").split()
+
+
+def mobi_fixture():
+    """COMMON /npzd_r/ after the reference's own mobi_init (run/control.in, silicon-only
+    namelist members removed) for every synthetic vertical grid."""
+    import build_ref
+    out = {}
+    for km in (6, 19, 32):
+        if not refmodel.available("c30", 14, 14, km):
+            build_ref.build("c30", 14, 14, km)
+        oc = synthetic.make_ocean("c30", 14, 14, km)
+        ro = refdriver.RefOcean(oc)
+        d = {n: float(ro.v[n][0]) for n in MOBI_SCALARS}
+        for n in ("wd", "ztt", "rcak", "rcab"):
+            d[n] = ro.v[n].tolist()
+        out[str(km)] = d
+    p = ROOT / "uvic2.9_amd" / "data" / "mobi_c30.json"
+    p.write_text(json.dumps(out))
+    print("wrote", p)
+
+
 def step_fixture(cfg, imt, jmt, km):
     oc = synthetic.make_ocean(cfg, imt, jmt, km)
     ro = refdriver.RefOcean(oc)
@@ -81,6 +107,7 @@ def run_fixture(cfg, imt, jmt, km, nsteps):
 
 if __name__ == "__main__":
     eos_fixture()
+    mobi_fixture()
     step_fixture("p2", 14, 14, 6)
     step_fixture("c30", 14, 14, 6)
     run_fixture("p2", 14, 14, 6, 20)

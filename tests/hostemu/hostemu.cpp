@@ -58,3 +58,25 @@ extern "C" void emu_convect(const uvic_ctx *cp) {
   for (int j = c.js; j <= c.je; ++j)
     for (int i = 2; i <= c.imt - 1; ++i) convect_column(c, i, j);
 }
+
+// MOBI column kernel on the host: same source as the GPU kernel, libm instead of ocml
+extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uvic_mobi_forcing *F) {
+  const uvic_ctx &c = *cp;
+  mobi_dev M;
+  M.P = P;
+  M.tlat = F->tlat; M.dnswr = F->dnswr; M.aice = F->aice; M.hice = F->hice; M.hsno = F->hsno;
+  M.sg_bathy = F->sg_bathy; M.fe_atmdep = F->fe_atmdep; M.fe_hydr = F->fe_hydr;
+  M.pi = F->pi; M.radian = F->radian; M.relyr = F->relyr; M.co2ccn = F->co2ccn;
+  mobi_step &S = M.S;
+  S.nbio = (int)(c.c2dtts / P->dtnpzd);
+  S.dtbio = c.c2dtts / S.nbio;
+  S.rdtts = 1. / c.c2dtts;
+  S.rnbio = 1. / S.nbio;
+  const double yrtime = fmod(F->relyr, 1.);
+  S.month = 12;
+  for (int m = 1; m <= 12; ++m)
+    if (yrtime <= m / 12.) { S.month = m; break; }
+  S.declin = sin((fmod(F->relyr, 1.) - 0.22) * 2. * F->pi) * 0.4;
+  for (int j = c.js; j <= c.je; ++j)
+    for (int i = 2; i <= c.imt - 1; ++i) mobi_column_kernel(c, M, i, j);
+}

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -173,8 +174,9 @@ struct uvic_gpu {
   double *work[8];  // tot_e, tot_n, tot_b, adv_x, adv_z, RpY, RmY
   uvic_ctx ctx;
   mobi_dev mobi;
-  void *mobi_buf;
+  mobi_store mobi_st;
   bool have_mobi;
+  double mobi_dtnpzd;
   int nchunk, fct_threads, upd_threads;
   size_t fct_lds, upd_lds;
   // profiling
@@ -249,7 +251,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->device = device;
   h->profiling = false;
   h->have_mobi = false;
-  h->mobi_buf = nullptr;
+  memset(&h->mobi_st, 0, sizeof h->mobi_st);
+  memset(&h->mobi, 0, sizeof h->mobi);
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (int f = 0; f < UVIC_F_COUNT; ++f) {
     const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
@@ -307,7 +310,10 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
-  if (h->mobi_buf) (void)hipFree(h->mobi_buf);
+  if (h->mobi_st.params) {
+    (void)hipFree(h->mobi_st.params);
+    for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
+  }
   for (auto e : h->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(h->stream);
   delete h;
@@ -469,6 +475,21 @@ static int launch_convect(uvic_gpu *h) {
 }
 static int launch_mobi(uvic_gpu *h) {
   if (!h->have_mobi) return 0;
+  {  // per-step scalars, updates/09/source/mom/tracer.F:311-343
+    const uvic_ctx &c = h->ctx;
+    if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_mobi: c2dtts not set (uvic_gpu_set_params)");
+    mobi_step &S = h->mobi.S;
+    S.nbio = (int)(c.c2dtts / h->mobi_dtnpzd);
+    if (S.nbio < 1) return fail_msg("uvic_gpu_mobi: c2dtts/dtnpzd < 1");
+    S.dtbio = c.c2dtts / S.nbio;
+    S.rdtts = 1. / c.c2dtts;
+    S.rnbio = 1. / S.nbio;
+    const double yrtime = fmod(h->mobi.relyr, 1.);
+    S.month = 12;
+    for (int m = 1; m <= 12; ++m)
+      if (yrtime <= m / 12.) { S.month = m; break; }
+    S.declin = sin((fmod(h->mobi.relyr, 1.) - 0.22) * 2. * h->mobi.pi) * 0.4;
+  }
   mark(h, "begin");
   hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi");
@@ -582,8 +603,22 @@ extern "C" int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const ch
 }
 
 // -- MOBI parameters -------------------------------------------------------------
-extern "C" int uvic_gpu_set_mobi(uvic_gpu *h, const mobi_host *m) {
-  if (!h || !m) return fail_msg("uvic_gpu_set_mobi: null argument");
+extern "C" int uvic_gpu_set_mobi(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_forcing *f) {
+  if (!h || !p || !f) return fail_msg("uvic_gpu_set_mobi: null argument");
+  if (p->nsrc != h->d.nsrc || p->ntnpzd != h->d.ntnpzd) return fail_msg("uvic_gpu_set_mobi: nsrc/ntnpzd differ from uvic_gpu_create");
+  if (p->dtnpzd <= 0.0) return fail_msg("uvic_gpu_set_mobi: dtnpzd must be positive");
   HIPCHK(hipSetDevice(h->device));
-  return mobi_bind(h->d.imt, h->d.jmt, h->d.km, m, &h->mobi, &h->mobi_buf, h->stream, &h->have_mobi, g_err);
+  int rc = mobi_bind(h->d.imt, h->d.jmt, h->d.km, p, f, &h->mobi, &h->mobi_st, h->stream, g_err);
+  if (rc) return rc;
+  h->mobi_dtnpzd = p->dtnpzd;
+  h->have_mobi = true;
+  return 0;
+}
+extern "C" int uvic_gpu_mobi(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  if (!h->have_mobi) return fail_msg("uvic_gpu_mobi: call uvic_gpu_set_mobi first");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_mobi(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
 }

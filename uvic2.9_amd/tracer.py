@@ -35,6 +35,7 @@ class TracerModel:
         check(self.lib.uvic_gpu_create(ctypes.byref(self.h), ctypes.byref(self.dims), device), "uvic_gpu_create")
         self.params = Params()
         self.device = device
+        self.has_mobi = False
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -97,6 +98,19 @@ class TracerModel:
         for k, v in kw.items():
             setattr(self.params, k, v)
         check(self.lib.uvic_gpu_set_params(self.h, ctypes.byref(self.params)), "set_params")
+
+    def set_mobi(self, ocean, table=None):
+        """Upload MOBI parameters (COMMON /npzd_r/ after mobi_init) and forcing; from
+        then on `tracer` computes the source terms on the device."""
+        from . import mobi as pm
+        prm = table if table is not None else pm.load_table(ocean.cfg.name, ocean.grid.km)
+        P = pm.make_params(ocean.cfg, ocean.grid, prm)
+        F = pm.Forcing(ocean)
+        check(self.lib.uvic_gpu_set_mobi(self.h, ctypes.byref(P), ctypes.byref(F.c)), "set_mobi")
+        self.has_mobi = True
+
+    def mobi(self):
+        check(self.lib.uvic_gpu_mobi(self.h), "mobi")
 
     def set_shard(self, n0=0, nt_local=None, js=2, je=None):
         nt_local = self.nt - n0 if nt_local is None else nt_local
