@@ -96,7 +96,7 @@ def test_mobi_kernel_source_under_host_emulation_equals_oracle(dims):
     assert np.array_equal(em.mobi(prm), src_o)
 
 
-MOBI_RTOL = 1e-9   # per source slot, relative to the slot's max magnitude (measured: see DESIGN.md §6)
+MOBI_RTOL = 1e-11  # per source slot, relative to the slot max; measured on MI355X: 4.7e-13 (102x102x19), 5.8e-15 (14x14x6)
 
 
 @pytest.mark.gpu
@@ -147,7 +147,7 @@ def test_gpu_full_step_with_mobi_vs_golden_and_oracle():
 def test_gpu_twenty_steps_with_mobi_drift_vs_reference_run():
     """20 steps (one mixing step) device-resident vs the reference's golden run: the
     north-star drift criterion is < 1e-12 relative after 100 steps for tracers on the
-    same arithmetic; with device transcendentals we state and test 1e-9."""
+    same arithmetic; the device exp/log/pow differ from libm in the last bits, measured drift 2.9e-15."""
     from uvic29_amd.tracer import TracerModel
     oc = synthetic.make_ocean("c30", 14, 14, 6)
     to, so, c = synthetic.load_eos(6)
@@ -168,6 +168,6 @@ def test_gpu_twenty_steps_with_mobi_drift_vs_reference_run():
         a, b = got[:, :, 1:13, n], g["t"][:, :, 1:13, n]
         rel = np.abs(a - b).max() / np.abs(b).max()
         worst = max(worst, rel)
-        assert rel <= 1e-9, (name, rel)
+        assert rel <= 1e-12, (name, rel)   # measured on MI355X: 2.9e-15
     print("worst relative drift after 20 steps", worst)
     m.close()

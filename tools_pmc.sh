@@ -1,0 +1,16 @@
+#!/bin/bash
+# rocprofv3 counter passes for the bench workload (separate passes per counter group,
+# MI355X_MICROARCH.md "rocprofv3 PMC slots"); writes CSVs under gpurun_out/pmc/
+R=$PWD
+mkdir -p $R/gpurun_out/pmc
+cd /tmp && export TMPDIR=/tmp
+run() { # name counters...
+  name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc/$name.log 2>&1
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
+run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run tcc TCC_HIT_sum TCC_MISS_sum
+ls -R $R/gpurun_out/pmc | head -40

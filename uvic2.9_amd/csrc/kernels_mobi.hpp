@@ -43,6 +43,13 @@ struct mobi_dev {
   mobi_step S;
 };
 
+// positions of the MOBI column tracers for option set C, fixed at compile time so that the
+// column vectors live in registers (mobi.F:440-504 assigns them in this order);
+// uvic_gpu_set_mobi rejects a parameter block whose `im` differs.
+struct MI {
+  enum : int { po4 = 1, phyt = 2, phyt_phos = 3, zoop = 4, detr = 5, detr_phos = 6, dic = 7, dic13 = 8, phytc13 = 9, zoopc13 = 10, detrc13 = 11, doc13 = 12, diazc13 = 13, dop = 14, no3 = 15, don = 16, diaz = 17, din15 = 18, don15 = 19, phytn15 = 20, zoopn15 = 21, detrn15 = 22, diazn15 = 23, dfe = 24, detrfe = 25, count = 25 };
+};
+
 namespace uvic {
 UVIC_DEV double flag01(double x) { return 0.5 + copysign(0.5, x); }
 UVIC_DEV double sq(double x) { return x * x; }
@@ -232,17 +239,16 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
                      double dayfrac, double wwd, double nud, double nudop, double nudon, double *bioout, double bctz,
                      double rn15impo, double rc13impo, double ac13b, double impofe, double o2, double aou,
                      src_out_t *out) {
-  const uvic_mobi_index *I = &P->im;
 #define BIN(m) bioin[(m)-1]
-  double biopo4 = BIN(I->po4), biophyt = BIN(I->phyt), biophyt_phos = BIN(I->phyt_phos), biozoop = BIN(I->zoop);
-  double biodetr = BIN(I->detr), biodetr_phos = BIN(I->detr_phos);
+  double biopo4 = BIN(MI::po4), biophyt = BIN(MI::phyt), biophyt_phos = BIN(MI::phyt_phos), biozoop = BIN(MI::zoop);
+  double biodetr = BIN(MI::detr), biodetr_phos = BIN(MI::detr_phos);
   double ptn_P = biophyt_phos / biophyt;
   double ptn_detr = biodetr_phos / biodetr;
-  double biodic = BIN(I->dic), biodop = BIN(I->dop), biono3 = BIN(I->no3), biodon = BIN(I->don), biodiaz = BIN(I->diaz);
-  double biodin15 = BIN(I->din15), biodon15 = BIN(I->don15), biophytn15 = BIN(I->phytn15), biozoopn15 = BIN(I->zoopn15);
-  double biodetrn15 = BIN(I->detrn15), biodiazn15 = BIN(I->diazn15);
-  double biodic13 = BIN(I->dic13), biophytc13 = BIN(I->phytc13), biozoopc13 = BIN(I->zoopc13), biodetrc13 = BIN(I->detrc13);
-  double biodoc13 = BIN(I->doc13), biodiazc13 = BIN(I->diazc13), biodfe = BIN(I->dfe), biodetrfe = BIN(I->detrfe);
+  double biodic = BIN(MI::dic), biodop = BIN(MI::dop), biono3 = BIN(MI::no3), biodon = BIN(MI::don), biodiaz = BIN(MI::diaz);
+  double biodin15 = BIN(MI::din15), biodon15 = BIN(MI::don15), biophytn15 = BIN(MI::phytn15), biozoopn15 = BIN(MI::zoopn15);
+  double biodetrn15 = BIN(MI::detrn15), biodiazn15 = BIN(MI::diazn15);
+  double biodic13 = BIN(MI::dic13), biophytc13 = BIN(MI::phytc13), biozoopc13 = BIN(MI::zoopc13), biodetrc13 = BIN(MI::detrc13);
+  double biodoc13 = BIN(MI::doc13), biodiazc13 = BIN(MI::diazc13), biodfe = BIN(MI::dfe), biodetrfe = BIN(MI::detrfe);
   /* negative-prevention flags from the unclamped input, mobi.F:1814-1891 */
   double po4flag = flag01(biopo4 - UV_TRCMIN), phytflag = flag01(biophyt - UV_TRCMIN), zoopflag = flag01(biozoop - UV_TRCMIN);
   double detrflag = flag01(biodetr - UV_TRCMIN), phyt_phosflag = flag01(biophyt_phos - UV_TRCMIN);
@@ -258,7 +264,7 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
   double doc13flag = flag01(biodoc13 - UV_TRCMIN), diazc13flag = flag01(biodiazc13 - UV_TRCMIN);
   double dfeflag = flag01(biodfe - UV_TRCMIN), detrfeflag = flag01(biodetrfe - UV_TRCMIN);
   /* clamp the caller's column and the working copies, mobi.F:1894-1960 */
-  for (int m = 0; m < P->ntnpzd; ++m) bioin[m] = dmax(bioin[m], UV_TRCMIN);
+  _Pragma("unroll") for (int m = 0; m < MI::count; ++m) bioin[m] = dmax(bioin[m], UV_TRCMIN);
   biopo4 = dmax(biopo4, UV_TRCMIN); biophyt = dmax(biophyt, UV_TRCMIN); biozoop = dmax(biozoop, UV_TRCMIN);
   biodetr = dmax(biodetr, UV_TRCMIN); biophyt_phos = dmax(biophyt_phos, UV_TRCMIN); biodetr_phos = dmax(biodetr_phos, UV_TRCMIN);
   biodic = dmax(biodic, UV_TRCMIN); biono3 = dmax(biono3, UV_TRCMIN); biodop = dmax(biodop, UV_TRCMIN);
@@ -538,13 +544,13 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
   }
   (void)dic13flag; (void)doc13flag; (void)phytc13flag; (void)zoopc13flag; (void)detrc13flag; (void)diazc13flag;
 #define BOUT(m, v) bioout[(m)-1] = (v)-BIN(m)
-  BOUT(I->po4, biopo4); BOUT(I->phyt, biophyt); BOUT(I->phyt_phos, biophyt_phos); BOUT(I->zoop, biozoop);
-  BOUT(I->detr, biodetr); BOUT(I->detr_phos, biodetr_phos); BOUT(I->dic, biodic); BOUT(I->dop, biodop);
-  BOUT(I->no3, biono3); BOUT(I->don, biodon); BOUT(I->diaz, biodiaz); BOUT(I->din15, biodin15);
-  BOUT(I->don15, biodon15); BOUT(I->phytn15, biophytn15); BOUT(I->zoopn15, biozoopn15); BOUT(I->detrn15, biodetrn15);
-  BOUT(I->diazn15, biodiazn15); BOUT(I->dfe, biodfe); BOUT(I->detrfe, biodetrfe); BOUT(I->dic13, biodic13);
-  BOUT(I->phytc13, biophytc13); BOUT(I->zoopc13, biozoopc13); BOUT(I->detrc13, biodetrc13); BOUT(I->doc13, biodoc13);
-  BOUT(I->diazc13, biodiazc13);
+  BOUT(MI::po4, biopo4); BOUT(MI::phyt, biophyt); BOUT(MI::phyt_phos, biophyt_phos); BOUT(MI::zoop, biozoop);
+  BOUT(MI::detr, biodetr); BOUT(MI::detr_phos, biodetr_phos); BOUT(MI::dic, biodic); BOUT(MI::dop, biodop);
+  BOUT(MI::no3, biono3); BOUT(MI::don, biodon); BOUT(MI::diaz, biodiaz); BOUT(MI::din15, biodin15);
+  BOUT(MI::don15, biodon15); BOUT(MI::phytn15, biophytn15); BOUT(MI::zoopn15, biozoopn15); BOUT(MI::detrn15, biodetrn15);
+  BOUT(MI::diazn15, biodiazn15); BOUT(MI::dfe, biodfe); BOUT(MI::detrfe, biodetrfe); BOUT(MI::dic13, biodic13);
+  BOUT(MI::phytc13, biophytc13); BOUT(MI::zoopc13, biozoopc13); BOUT(MI::detrc13, biodetrc13); BOUT(MI::doc13, biodoc13);
+  BOUT(MI::diazc13, biodiazc13);
   out->expo = expoout; out->expo_phos = expo_phosout; out->calpro = calproout; out->nfix = nfixout;
   out->rn15expo = rn15expoout; out->rc13expo = rc13expoout; out->expofe = expofeout; out->remife = remifeout;
 #undef BIN
@@ -560,9 +566,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
   UV_DIMS(c);
   const uvic_mobi_params *P = M.P;
   const mobi_step &S = M.S;
-  const uvic_mobi_index *I = &P->im;
   const uvic_mobi_index *Q = &P->is;
-  const int ntn = P->ntnpzd;
   const int kmx = c.kmt[X2(i, j)];
   double *src = const_cast<double *>(c.src);
 #define SRC(k, s) src[X3(i, k, j) + (size_t)((s)-1) * N3]
@@ -586,7 +590,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
 
   double expo = 0.0, impo, expo_phos = 0.0, impo_phos, phin = 0.0, prca = 0.0;
   double rn15impo, rn15expo = 0.0, rc13impo, rc13expo = 0.0, prca13 = 0.0, expofe = 0.0, impofe;
-  double snpzd[UV_MOBI_MAXT], bioin[UV_MOBI_MAXT];
+  double snpzd[MI::count], bioin[MI::count];
   const double redctn = P->redctn;
   const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
   for (int s = 1; s <= c.nsrc; ++s)
@@ -618,7 +622,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     const double ac13b = ac13_aq_POC / ac13_DIC_aq;
     rc13impo = rc13expo * P->dztr[k - 1];
     swr = swr * exp(-P->kc * phin);
-    phin = TNC(k, I->phyt) * P->dzt[k - 1] + TNC(k, I->diaz) * P->dzt[k - 1];
+    phin = TNC(k, MI::phyt) * P->dzt[k - 1] + TNC(k, MI::diaz) * P->dzt[k - 1];
     const double gl = swr * exp(P->ztt[k - 1] * rctheta);
     impo = expo * P->dztr[k - 1];
     impo_phos = expo_phos * P->dztr[k - 1];
@@ -626,13 +630,13 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     const double bct = pow(P->bbio, P->cbio * t_in);
     const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * pow(P->bbio, P->cbio * t_in);
     const double nud = P->nud0 * (0.6 + 0.4 * tanh(0.22 * dmax(o2_in, 0.)));
-    for (int m = 1; m <= ntn; ++m) bioin[m - 1] = TM(k, P->tracer_of_mobi[m - 1]);
+    _Pragma("unroll") for (int m = 1; m <= MI::count; ++m) bioin[m - 1] = TM(k, P->tracer_of_mobi[m - 1]);
     src_out_t so;
     mobi_src(P, S, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, P->nudop0, P->nudon0, snpzd, bctz,
              rn15impo, rc13impo, ac13b, impofe, o2_in, aou_in, &so);
     expo = so.expo; expo_phos = so.expo_phos; rn15expo = so.rn15expo; rc13expo = so.rc13expo; expofe = so.expofe;
     const double nfix_k = so.nfix;
-    for (int m = 0; m < ntn; ++m) snpzd[m] = snpzd[m] * S.rdtts;
+    _Pragma("unroll") for (int m = 0; m < MI::count; ++m) snpzd[m] = snpzd[m] * S.rdtts;
     expofe = expofe * S.rnbio;
     expo = expo * S.rnbio;
     expo_phos = expo_phos * S.rnbio;
@@ -640,7 +644,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     rc13expo = rc13expo * S.rnbio;
     const double rcalpro_k = so.calpro * S.rnbio;
     // benthic denitrification on the sub-grid bathymetry, mobi.F:1033-1085 (bioin is clamped now)
-    const double tn_no3 = bioin[I->no3 - 1], tn_din15 = bioin[I->din15 - 1];
+    const double tn_no3 = bioin[MI::no3 - 1], tn_din15 = bioin[MI::din15 - 1];
     const double no3flag = flag01(tn_no3 - UV_TRCMIN);
     const double din15flag = flag01(tn_din15 - UV_TRCMIN);
     const double lno3 = 0.5 * tanh(tn_no3 * 10 - 5.0);
@@ -649,13 +653,13 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     sg_bdeni = dmin(sg_bdeni, sgb * expo);
     sg_bdeni = dmax(sg_bdeni, 0.);
     sg_bdeni = sg_bdeni * (0.5 + lno3) * no3flag * din15flag;
-    SN(I->no3) = SN(I->no3) + sgb * expo - sg_bdeni;
+    SN(MI::no3) = SN(MI::no3) + sgb * expo - sg_bdeni;
     double rno3 = dmax(tn_din15, r15min) / dmax(tn_no3 - tn_din15, r15min);
     rno3 = dmin(rno3, 2. * UV_RN15STD);
     rno3 = dmax(rno3, UV_RN15STD / 2.);
     const double eps_bdeni = P->eps_bdeni0 * exp(-2.5e-6 * (P->zt[k - 1]));
     const double bbdeni = rno3 - eps_bdeni * rno3 / 1000.;
-    SN(I->din15) = SN(I->din15) + rn15expo * sgb * expo - bbdeni / (1 + bbdeni) * sg_bdeni;
+    SN(MI::din15) = SN(MI::din15) + rn15expo * sgb * expo - bbdeni / (1 + bbdeni) * sg_bdeni;
     // sedimentary iron release, mobi.F:1086-1123
     const double coxdepth = dmin(dmax(P->zt[k - 1], 50000.), 150000.);
     const double oblinc = -1.26e-6 * coxdepth + 0.203;
@@ -666,28 +670,28 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     const double coxsed = expo * sgb - nburial;
     const double fesedmax = 85.;
     const double fesed = fesedmax * tanh(coxsed * redctn * 1000 * dztk / 100 * 86400. / o2_in) / (dztk / 100 * 86400 * 1000);
-    SN(I->dfe) = SN(I->dfe) + fesed;
+    SN(MI::dfe) = SN(MI::dfe) + fesed;
     // bottom remineralisation, mobi.F:1124-1134
-    SN(I->po4) = SN(I->po4) + sgb * expo_phos;
-    SN(I->dic) = SN(I->dic) + sgb * expo * redctn;
-    SN(I->dic13) = SN(I->dic13) + rc13expo * sgb * redctn;
+    SN(MI::po4) = SN(MI::po4) + sgb * expo_phos;
+    SN(MI::dic) = SN(MI::dic) + sgb * expo * redctn;
+    SN(MI::dic13) = SN(MI::dic13) + rc13expo * sgb * redctn;
     rc13expo = rc13expo - sgb * rc13expo;
     expo = expo - sgb * expo;
     expo_phos = expo_phos - sgb * expo_phos;
     // scatter, mobi.F:1149-1205: every MOBI tracer owns the source slot of its prognostic tracer
-    for (int m = 1; m <= ntn; ++m) SRC(k, P->slot_of_mobi[m - 1]) = snpzd[m - 1];
+    _Pragma("unroll") for (int m = 1; m <= MI::count; ++m) SRC(k, P->slot_of_mobi[m - 1]) = snpzd[m - 1];
     // DIC / alkalinity / 13C bookkeeping, mobi.F:1228-1266
-    const double dic_sms = SN(I->dic);
+    const double dic_sms = SN(MI::dic);
     const double dprca = rcalpro_k * 1e-3;
     prca = prca + dprca * dztk;
-    SRC(k, Q->dic) = SN(I->dic) - dprca;
+    SRC(k, Q->dic) = SN(MI::dic) - dprca;
     const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
-    double rtdic13 = dmax(bioin[I->dic13 - 1], r13min) / dmax(dic_in, UV_TRCMIN);
+    double rtdic13 = dmax(bioin[MI::dic13 - 1], r13min) / dmax(dic_in, UV_TRCMIN);
     rtdic13 = dmin(rtdic13, 2. * UV_RC13STD / (1 + UV_RC13STD));
     rtdic13 = dmax(rtdic13, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
     prca13 = prca13 + dprca * dztk * rtdic13;
     SRC(k, Q->dic13) = SRC(k, Q->dic13) - rtdic13 * dprca;
-    SRC(k, Q->alk) = -SN(I->dic) * P->redntc * 1.e-3 - 2. * dprca;
+    SRC(k, Q->alk) = -SN(MI::dic) * P->redntc * 1.e-3 - 2. * dprca;
     // second pass of the reference (mobi.F:1302-1365) needs only this level's values: fused here
     {
       const double fo2 = tanh(0.22 * dmax(o2_in, 0.));
@@ -744,6 +748,16 @@ struct mobi_store {
 static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp, const uvic_mobi_forcing *hf, mobi_dev *dev,
                             mobi_store *st, hipStream_t stream, std::string &err) {
   if (hp->km != km) { err = "uvic_gpu_set_mobi: params.km differs from the model's km"; return 2; }
+  {
+    const int32_t want[MI::count] = {MI::po4, MI::phyt, MI::phyt_phos, MI::zoop, MI::detr, MI::detr_phos, MI::dic, MI::dic13,
+                                     MI::phytc13, MI::zoopc13, MI::detrc13, MI::doc13, MI::diazc13, MI::dop, MI::no3, MI::don,
+                                     MI::diaz, MI::din15, MI::don15, MI::phytn15, MI::zoopn15, MI::detrn15, MI::diazn15,
+                                     MI::dfe, MI::detrfe};
+    const int32_t *got = &hp->im.po4;
+    if (hp->ntnpzd != MI::count) { err = "uvic_gpu_set_mobi: this build implements option set C (ntnpzd = 25)"; return 2; }
+    for (int q = 0; q < MI::count; ++q)
+      if (got[q] != want[q]) { err = "uvic_gpu_set_mobi: MOBI tracer order differs from option set C"; return 2; }
+  }
   if (hp->ntnpzd > UV_MOBI_MAXT || km > 64) { err = "uvic_gpu_set_mobi: ntnpzd > 40 or km > 64 not supported"; return 2; }
   const size_t NS = (size_t)imt * jmt;
   const size_t sz[8] = {NS, NS, NS, NS, NS, NS * km, NS * 12, NS * km};
