@@ -71,6 +71,12 @@ typedef struct uvic_params {
   double diff_cet, diff_cnt; /* u09/mom/hmixc.F:177-200 */
   double slmxr;    /* 1/slmx, u09/mom/isopyc.F:105 */
   double ahisop, athkdf; /* isopyc.F:79-83 */
+  /* 0: UVIC_F_DIFF_CBT_BG holds diff_cbt before "+K33" and uvic_gpu_isopyc adds K33
+   *    (device-resident stepping);
+   * 1: the caller uploaded UVIC_F_DIFF_CBT as host vmixc left it, K33 included
+   *    (u09/mom/vmixc.F:182-188; the host ran isopyc -> vmixc itself, mom.F:340-347) */
+  int32_t diff_cbt_has_k33;
+  int32_t pad_;
 } uvic_params;
 
 /* ---- MOBI biogeochemistry (option set C) --------------------- */
@@ -119,6 +125,16 @@ typedef struct uvic_mobi_forcing {
  * mobi_driver/mobi_src/co2calc_SWS and the 14C source, tracer.F:853-867) instead
  * of reading UVIC_F_SRC as given */
 int uvic_gpu_set_mobi(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_forcing *f);
+/* the same for callers without C structs (Fortran): `idx` = im(28), is(28) in the
+ * member order of uvic_mobi_index; `tracer_of_mobi`, `slot_of_mobi` (ntnpzd);
+ * `itr` = itemp,isalt,idic,ialk,io2,ic14; `scal` = dtnpzd followed by the double
+ * members of uvic_mobi_params from `kw` to `capr` in declaration order (1 + 59 values);
+ * `prof` = wd,ztt,rcak,rcab,zt,dzt,dztr, km values each; `fsc` = pi,radian,relyr,co2ccn */
+int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc, const int32_t *idx, const int32_t *tracer_of_mobi,
+                           const int32_t *slot_of_mobi, const int32_t *itr, const double *scal, const double *prof,
+                           const double *fsc, const double *tlat, const double *dnswr, const double *aice,
+                           const double *hice, const double *hsno, const double *sg_bathy, const double *fe_atmdep,
+                           const double *fe_hydr);
 /* the source-term kernel alone (for parity tests): fills UVIC_F_SRC */
 int uvic_gpu_mobi(uvic_gpu *h);
 

@@ -88,10 +88,18 @@ def lib_name(cfg: str, imt: int, jmt: int, km: int) -> Path:
     return OUT / f"libuvicref_{cfg}_{imt}x{jmt}x{km}.so"
 
 
-def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bool = False) -> Path:
+SHIM_DIR = HERE.parent / "uvic2.9_amd" / "fortran"
+GPU_LIB_DIR = HERE.parent / "uvic2.9_amd" / "csrc"
+
+
+def shim_lib_name(cfg: str, imt: int, jmt: int, km: int) -> Path:
+    return OUT / f"libuvicshim_{cfg}_{imt}x{jmt}x{km}.so"
+
+
+def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bool = False, shim: bool = False) -> Path:
     if not REF.exists():
         raise SystemExit(f"reference not present at {REF}; oracle/_ref can only be built in the build container")
-    target = lib_name(cfg, imt, jmt, km)
+    target = shim_lib_name(cfg, imt, jmt, km) if shim else lib_name(cfg, imt, jmt, km)
     work = OUT / "build" / target.stem
     if work.exists():
         shutil.rmtree(work)
@@ -121,6 +129,12 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
             text = text.replace("bctz, mi, yrtime", "bctz, yrtime")
             text = text.replace("parameter (fe_n = 14)", "parameter (fe_n = 14)\n      integer mi")
         (work / (src.stem + ".f")).write_text(text, encoding="latin-1")
+    if shim:
+        # the drop-in test: the package's Fortran overlay (uvic2.9_amd/fortran) provides `tracer`;
+        # it is preprocessed like any model source (it #includes the reference's headers)
+        for f in ("tracer_gpu.F",):
+            r = run(["cpp", "-traditional", "-P", *incs, *defs, str(SHIM_DIR / f)])
+            (work / (Path(f).stem + ".f")).write_text(patch(r.stdout), encoding="latin-1")
     # 3. generated registration harness (includes only; no reference text)
     sys.path.insert(0, str(HERE / "ref"))
     import gen_harness
@@ -128,6 +142,14 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
     # 4. compile
     fflags = ["-fdefault-real-8", "-ffixed-form", "-ffixed-line-length-132", "-O2",
               "-ffp-contract=off", "-fno-automatic", "-fPIC", f"-I{work / 'inc'}"]
+    if shim:
+        r = run([FLANG, "-fdefault-real-8", "-O2", "-fPIC", f"-J{work}", "-c", str(SHIM_DIR / "uvic_gpu_mod.F90"),
+                 "-o", str(work / "uvic_gpu_mod.o")])
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-4000:])
+            raise SystemExit("flang failed on uvic_gpu_mod.F90")
+        objs.append(str(work / "uvic_gpu_mod.o"))
+        fflags.append(f"-I{work}")
     for f in sorted(work.glob("*.f")):
         o = f.with_suffix(".o")
         r = run([FLANG, *fflags, "-c", str(f), "-o", str(o)])
@@ -137,12 +159,20 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
         if verbose:
             print("  compiled", f.name)
         objs.append(str(o))
+        if shim and f.name == "tracer.f":
+            # keep the reference routine reachable as `tracer_cpu` (diagnostic time steps)
+            rr = run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--redefine-sym", "tracer_=tracer_cpu_", str(o)])
+            if rr.returncode != 0:
+                raise SystemExit(rr.stderr)
     r = run(["gcc", "-O2", "-fPIC", "-c", str(HERE / "ref" / "harness.c"), "-o", str(work / "harness.o")])
     if r.returncode != 0:
         raise SystemExit(r.stderr)
     objs.append(str(work / "harness.o"))
     # 5. link
-    r = run([FLANG, "-shared", "-o", str(target), *objs, "-Wl,-z,lazy"])
+    extra = []
+    if shim:
+        extra = [f"-L{GPU_LIB_DIR}", "-luvic_gpu", "-Wl,-rpath,$ORIGIN/../../uvic2.9_amd/csrc"]
+    r = run([FLANG, "-shared", "-o", str(target), *objs, "-Wl,-z,lazy", *extra])
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-4000:])
         raise SystemExit("link failed")
@@ -161,8 +191,21 @@ DEFAULT_BUILDS = [
 ]
 
 
+SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19)]
+
+
 def build_default(force: bool = False, verbose: bool = False):
     built = []
+    if (GPU_LIB_DIR / "libuvic_gpu.so").exists():
+        for cfg, imt, jmt, km in SHIM_BUILDS:
+            t = shim_lib_name(cfg, imt, jmt, km)
+            srcs = [SHIM_DIR / "tracer_gpu.F", SHIM_DIR / "uvic_gpu_mod.F90"]
+            if t.exists() and not force and all(t.stat().st_mtime >= s_.stat().st_mtime for s_ in srcs):
+                built.append(t)
+                continue
+            if verbose:
+                print("building", t.name)
+            built.append(build(cfg, imt, jmt, km, shim=True))
     for cfg, imt, jmt, km in DEFAULT_BUILDS:
         t = lib_name(cfg, imt, jmt, km)
         if t.exists() and not force:

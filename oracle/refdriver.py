@@ -39,10 +39,10 @@ def trimmed_control_in(cfg_options) -> str:
 class RefOcean:
     """The reference model state initialised from a synthetic Ocean."""
 
-    def __init__(self, ocean, quiet: bool = True):
+    def __init__(self, ocean, quiet: bool = True, shim: bool = False):
         g, cfg = ocean.grid, ocean.cfg
         self.ocean = ocean
-        self.ref = RefLib(cfg.name, g.imt, g.jmt, g.km)
+        self.ref = RefLib(cfg.name, g.imt, g.jmt, g.km, shim=shim)
         self.v = self.ref.v
         self.quiet = quiet
         self._init(ocean)

@@ -23,17 +23,20 @@ _DT = {(1, 8): np.float64, (1, 4): np.float32, (2, 4): np.int32, (2, 8): np.int6
        (3, 4): np.int32, (3, 8): np.int64}
 
 
-def lib_path(cfg: str, imt: int, jmt: int, km: int) -> Path:
-    return HERE / "_ref" / f"libuvicref_{cfg}_{imt}x{jmt}x{km}.so"
+def lib_path(cfg: str, imt: int, jmt: int, km: int, shim: bool = False) -> Path:
+    """`shim=True`: the same reference build with `tracer` replaced by the package's
+    Fortran overlay (uvic2.9_amd/fortran/tracer_gpu.F) linked against libuvic_gpu.so."""
+    kind = "uvicshim" if shim else "uvicref"
+    return HERE / "_ref" / f"lib{kind}_{cfg}_{imt}x{jmt}x{km}.so"
 
 
-def available(cfg: str, imt: int, jmt: int, km: int) -> bool:
-    return lib_path(cfg, imt, jmt, km).exists()
+def available(cfg: str, imt: int, jmt: int, km: int, shim: bool = False) -> bool:
+    return lib_path(cfg, imt, jmt, km, shim).exists()
 
 
 class RefLib:
-    def __init__(self, cfg: str, imt: int, jmt: int, km: int):
-        path = lib_path(cfg, imt, jmt, km)
+    def __init__(self, cfg: str, imt: int, jmt: int, km: int, shim: bool = False):
+        path = lib_path(cfg, imt, jmt, km, shim)
         if not path.exists():
             raise FileNotFoundError(f"{path} missing: run `python oracle/build_ref.py` in the build container")
         self.cfg, self.imt, self.jmt, self.km = cfg, imt, jmt, km

@@ -42,7 +42,7 @@ EXPORTS = [
     "uvic_gpu_download", "uvic_gpu_upload_rows", "uvic_gpu_download_rows", "uvic_gpu_field_elems",
     "uvic_gpu_field_devptr", "uvic_gpu_stream", "uvic_gpu_set_params", "uvic_gpu_set_shard", "uvic_gpu_isopyc",
     "uvic_gpu_transport", "uvic_gpu_convect", "uvic_gpu_tracer", "uvic_gpu_rotate", "uvic_gpu_sync",
-    "uvic_gpu_profile", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_mobi",
+    "uvic_gpu_profile", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_set_mobi_flat", "uvic_gpu_mobi",
 ]
 
 
@@ -51,7 +51,8 @@ class Dims(ctypes.Structure):
 
 
 class Params(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_double) for n in ("c2dtts", "aidif", "diff_cet", "diff_cnt", "slmxr", "ahisop", "athkdf")]
+    _fields_ = ([(n, ctypes.c_double) for n in ("c2dtts", "aidif", "diff_cet", "diff_cnt", "slmxr", "ahisop", "athkdf")]
+                + [("diff_cbt_has_k33", ctypes.c_int32), ("pad_", ctypes.c_int32)])
 
 
 _lib = None

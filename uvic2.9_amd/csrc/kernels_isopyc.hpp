@@ -312,7 +312,8 @@ UVIC_DEV void isopyc_column(const uvic_ctx &c, int i, int j) {
     UV_CYC_STORE(c.tot_b, IDXF, i, c.adv_vbt[XF(i, k, j)] + v);
   }
 #undef IDXF
-  for (int k = 1; k <= km; ++k) c.diff_cbt[X3(i, k, j)] = c.diff_cbt_bg[X3(i, k, j)] + c.K33[X3(i, k, j)];
+  if (!c.diff_cbt_given)
+    for (int k = 1; k <= km; ++k) c.diff_cbt[X3(i, k, j)] = c.diff_cbt_bg[X3(i, k, j)] + c.K33[X3(i, k, j)];
 }
 
 }  // namespace uvic

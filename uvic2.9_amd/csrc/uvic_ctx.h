@@ -54,6 +54,8 @@ typedef struct uvic_ctx {
   int n0, nt_local;
   /* latitude slab handled by this context (rows js..je are computed) */
   int js, je;
+  /* 1: diff_cbt was uploaded with K33 already added (host vmixc); isopyc leaves it alone */
+  int diff_cbt_given;
 } uvic_ctx;
 
 #endif

@@ -404,6 +404,7 @@ extern "C" int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p) {
   h->ctx.c2dtts = p->c2dtts; h->ctx.aidif = p->aidif;
   h->ctx.diff_cet = p->diff_cet; h->ctx.diff_cnt = p->diff_cnt;
   h->ctx.slmxr = p->slmxr; h->ctx.ahisop = p->ahisop; h->ctx.athkdf = p->athkdf;
+  h->ctx.diff_cbt_given = p->diff_cbt_has_k33 ? 1 : 0;
   return 0;
 }
 extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je) {
@@ -613,6 +614,31 @@ extern "C" int uvic_gpu_set_mobi(uvic_gpu *h, const uvic_mobi_params *p, const u
   h->mobi_dtnpzd = p->dtnpzd;
   h->have_mobi = true;
   return 0;
+}
+extern "C" int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc, const int32_t *idx, const int32_t *tracer_of_mobi,
+                                      const int32_t *slot_of_mobi, const int32_t *itr, const double *scal, const double *prof,
+                                      const double *fsc, const double *tlat, const double *dnswr, const double *aice,
+                                      const double *hice, const double *hsno, const double *sg_bathy,
+                                      const double *fe_atmdep, const double *fe_hydr) {
+  if (!idx || !tracer_of_mobi || !slot_of_mobi || !itr || !scal || !prof || !fsc) return fail_msg("uvic_gpu_set_mobi_flat: null argument");
+  if (ntnpzd < 1 || ntnpzd > 40 || km < 1 || km > 64) return fail_msg("uvic_gpu_set_mobi_flat: ntnpzd or km out of range");
+  uvic_mobi_params P;
+  memset(&P, 0, sizeof P);
+  P.km = km; P.ntnpzd = ntnpzd; P.nsrc = nsrc;
+  memcpy(&P.im, idx, sizeof(uvic_mobi_index));
+  memcpy(&P.is, idx + 28, sizeof(uvic_mobi_index));
+  for (int m = 0; m < ntnpzd; ++m) { P.tracer_of_mobi[m] = tracer_of_mobi[m]; P.slot_of_mobi[m] = slot_of_mobi[m]; }
+  P.itemp = itr[0]; P.isalt = itr[1]; P.idic = itr[2]; P.ialk = itr[3]; P.io2 = itr[4]; P.ic14 = itr[5];
+  P.dtnpzd = scal[0];
+  const size_t nscal = (size_t)(&P.capr - &P.kw) + 1;   // contiguous doubles kw .. capr
+  memcpy(&P.kw, scal + 1, nscal * sizeof(double));
+  double *arr[7] = {P.wd, P.ztt, P.rcak, P.rcab, P.zt, P.dzt, P.dztr};
+  for (int a = 0; a < 7; ++a) memcpy(arr[a], prof + (size_t)a * km, (size_t)km * sizeof(double));
+  uvic_mobi_forcing F;
+  F.pi = fsc[0]; F.radian = fsc[1]; F.relyr = fsc[2]; F.co2ccn = fsc[3];
+  F.tlat = tlat; F.dnswr = dnswr; F.aice = aice; F.hice = hice; F.hsno = hsno;
+  F.sg_bathy = sg_bathy; F.fe_atmdep = fe_atmdep; F.fe_hydr = fe_hydr;
+  return uvic_gpu_set_mobi(h, &P, &F);
 }
 extern "C" int uvic_gpu_mobi(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");

@@ -1,0 +1,136 @@
+!=======================================================================
+!     uvic_gpu_mod -- ISO_C_BINDING interface of include/uvic_gpu.h
+!
+!     Bound by the overlay tracer_gpu.F.  Every dummy is either a C
+!     scalar by value or the base address of a COMMON array (assumed
+!     size), exactly what the C side declares: no descriptors cross the
+!     boundary.  Field ids are the enumerators of `enum uvic_field`.
+!=======================================================================
+      module uvic_gpu_mod
+      use iso_c_binding
+      implicit none
+
+      type, bind(C) :: uvic_dims
+        integer(c_int32_t) :: imt, jmt, km, nt, nsrc, ntnpzd
+      end type uvic_dims
+
+      type, bind(C) :: uvic_params
+        real(c_double) :: c2dtts, aidif, diff_cet, diff_cnt
+        real(c_double) :: slmxr, ahisop, athkdf
+        integer(c_int32_t) :: diff_cbt_has_k33, pad
+      end type uvic_params
+
+!     enum uvic_field (include/uvic_gpu.h) -- keep the order
+      integer(c_int), parameter :: F_DXT=0, F_DXTR=1, F_DXU=2, F_DXUR=3
+      integer(c_int), parameter :: F_DXT4R=4, F_DYT=5, F_DYTR=6, F_DYU=7
+      integer(c_int), parameter :: F_DYUR=8, F_DYT4R=9, F_CST=10
+      integer(c_int), parameter :: F_CSTR=11, F_CSU=12, F_CSTDYTR=13
+      integer(c_int), parameter :: F_CSTDYT2R=14, F_CSU_DYUR=15
+      integer(c_int), parameter :: F_DZT=16, F_DZTR=17, F_DZT2R=18
+      integer(c_int), parameter :: F_DZTUR=19, F_DZTLR=20, F_DZW=21
+      integer(c_int), parameter :: F_DZWR=22, F_DTXCEL=23, F_DTXSQR=24
+      integer(c_int), parameter :: F_DZTXCL=25, F_TO=26, F_SO=27, F_C=28
+      integer(c_int), parameter :: F_KMT=29, F_FISOP=30, F_ADDISOP=31
+      integer(c_int), parameter :: F_T_TAUM1=32, F_T_TAU=33
+      integer(c_int), parameter :: F_T_TAUP1=34, F_ADV_VET=35
+      integer(c_int), parameter :: F_ADV_VNT=36, F_ADV_VBT=37
+      integer(c_int), parameter :: F_DIFF_CBT_BG=38, F_STF=39, F_BTF=40
+      integer(c_int), parameter :: F_SRC=41, F_ITRC=42
+      integer(c_int), parameter :: F_DIFF_CBT=58
+
+      interface
+        function uvic_gpu_create(h, dims, device) bind(C,name='uvic_gpu_create') result(rc)
+          import
+          type(c_ptr) :: h
+          type(uvic_dims) :: dims
+          integer(c_int), value :: device
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_destroy(h) bind(C,name='uvic_gpu_destroy') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_upload(h, field, host, offset, count) bind(C,name='uvic_gpu_upload') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: field
+          type(*) :: host(*)
+          integer(c_int64_t), value :: offset, count
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_download(h, field, host, offset, count) bind(C,name='uvic_gpu_download') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: field
+          type(*) :: host(*)
+          integer(c_int64_t), value :: offset, count
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_upload_rows(h, field, host, jlo, jhi) bind(C,name='uvic_gpu_upload_rows') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: field, jlo, jhi
+          real(c_double) :: host(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_download_rows(h, field, host, jlo, jhi) bind(C,name='uvic_gpu_download_rows') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: field, jlo, jhi
+          real(c_double) :: host(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_params(h, p) bind(C,name='uvic_gpu_set_params') result(rc)
+          import
+          type(c_ptr), value :: h
+          type(uvic_params) :: p
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_mobi_flat(h, km, ntnpzd, nsrc, idx, tom, som, itr, scal, prof, fsc, tlat, dnswr,   &
+     &      aice, hice, hsno, sgb, fe_atmdep, fe_hydr) bind(C,name='uvic_gpu_set_mobi_flat') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: km, ntnpzd, nsrc
+          integer(c_int32_t) :: idx(*), tom(*), som(*), itr(*)
+          real(c_double) :: scal(*), prof(*), fsc(*), tlat(*), dnswr(*), aice(*), hice(*), hsno(*)
+          real(c_double) :: sgb(*), fe_atmdep(*), fe_hydr(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_isopyc(h) bind(C,name='uvic_gpu_isopyc') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_tracer(h) bind(C,name='uvic_gpu_tracer') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_last_error() bind(C,name='uvic_gpu_last_error') result(msg)
+          import
+          type(c_ptr) :: msg
+        end function
+      end interface
+
+      type(c_ptr), save :: uvic_handle = c_null_ptr
+
+      contains
+
+      subroutine uvic_check(rc, where)
+        integer(c_int), intent(in) :: rc
+        character(*), intent(in) :: where
+        character(kind=c_char), pointer :: msg(:)
+        integer :: n
+        if (rc .eq. 0) return
+        call c_f_pointer(uvic_gpu_last_error(), msg, [512])
+        n = 1
+        do while (n .lt. 512 .and. msg(n) .ne. c_null_char)
+          n = n + 1
+        enddo
+        write (*,'(4a)') '=> Error in ', where, ': ', msg(1:n-1)
+!       the reference's own error convention, updates/09/source/mom/tracer.F:1250
+        stop '=>tracer (gpu)'
+      end subroutine uvic_check
+
+      end module uvic_gpu_mod
