@@ -225,9 +225,10 @@ if __name__ == "__main__":
     ap.add_argument("--km", type=int, default=19)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--shim", action="store_true", help="link the package's Fortran overlay in place of `tracer`")
     a = ap.parse_args()
     if a.cfg is None:
         for t in build_default(force=a.force, verbose=True):
             print(t)
     else:
-        print(build(a.cfg, a.imt, a.jmt, a.km, keep=a.keep, verbose=True))
+        print(build(a.cfg, a.imt, a.jmt, a.km, keep=a.keep, verbose=True, shim=a.shim))
