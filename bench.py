@@ -135,9 +135,11 @@ def main():
         m.set_mobi(ocean)
     shard.apply(m)
 
+    from uvic29_amd.tracer import TimeLoop
+    loop = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, shard=shard if world > 1 else None)
+
     def one_step():
-        shard.step(m)
-        m.rotate()
+        loop.step()
 
     def barrier():
         m.sync()

@@ -183,6 +183,14 @@ int uvic_gpu_sync(uvic_gpu *h);
  * pair with uvic_gpu_sync): one whole step; or, for tracer-index sharding,
  * the part before the exchange of t(tau+1) and the convection after it */
 int uvic_gpu_step_async(uvic_gpu *h);
+/* start computing the MOBI sources of the NEXT step from t(tau) on a side stream,
+ * overlapped with this step's transport (the source terms of a leapfrog step depend only
+ * on t(tau-1), which is this step's t(tau)); call between uvic_gpu_step_async and
+ * uvic_gpu_rotate, only when the next step is a leapfrog step with `c2dtts_next` */
+int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
+/* forward ("mixing") time step: t(tau-1) := t(tau) (u09/mom/loadmw.F:107-111, 569-584) by
+ * aliasing the device buffers instead of copying; switch off again before the next step */
+int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);
 

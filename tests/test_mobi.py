@@ -171,3 +171,27 @@ def test_gpu_twenty_steps_with_mobi_drift_vs_reference_run():
         assert rel <= 1e-12, (name, rel)   # measured on MI355X: 2.9e-15
     print("worst relative drift after 20 steps", worst)
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_gpu_time_loop_with_source_prefetch_matches_golden_run(prefetch):
+    """The device-resident schedule (mixing step by buffer aliasing, MOBI sources one step
+    ahead on a side stream) reproduces the reference's 20-step run."""
+    from uvic29_amd.tracer import TracerModel, TimeLoop
+    oc = synthetic.make_ocean("c30", 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    g = np.load(GOLD / "run_c30_14x14x6_n20.npz")
+    m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.load_ocean(oc, to, so, c)
+    m.set_mobi(oc)
+    loop = TimeLoop(m, oc.params.dtts, oc.params.nmix, prefetch=prefetch)
+    for _ in range(20):
+        loop.step()
+    m.sync()
+    got = m.download("t_tau")
+    for n, name in enumerate(oc.cfg.tracers):
+        a, b = got[:, :, 1:13, n], g["t"][:, :, 1:13, n]
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (name, prefetch)
+    assert np.array_equal(got[:, :, 1:13, :2], g["t"][:, :, 1:13, :2])
+    m.close()

@@ -177,6 +177,11 @@ struct uvic_gpu {
   mobi_store mobi_st;
   bool have_mobi;
   double mobi_dtnpzd;
+  // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
+  hipStream_t side;
+  hipEvent_t ev_step_begin, ev_src_next;
+  void *src_alt;
+  bool prefetch_pending, src_from_prefetch, mixing;
   int nchunk, fct_threads, upd_threads;
   size_t fct_lds, upd_lds;
   // profiling
@@ -234,6 +239,7 @@ static void bind_ctx(uvic_gpu *h) {
   B(K11, UVIC_F_K11); B(K22, UVIC_F_K22); B(K33, UVIC_F_K33);
   B(adv_vetiso, UVIC_F_ADV_VETISO); B(adv_vntiso, UVIC_F_ADV_VNTISO); B(adv_vbtiso, UVIC_F_ADV_VBTISO);
 #undef B
+  if (h->mixing) c.t_taum1 = c.t_tau;  // forward step: both slots hold tau (updates/09/source/mom/loadmw.F:107-111)
   c.tot_e = h->work[0]; c.tot_n = h->work[1]; c.tot_b = h->work[2];
   c.adv_x = h->work[3]; c.adv_z = h->work[4]; c.RpY = h->work[5]; c.RmY = h->work[6];
 }
@@ -254,6 +260,11 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_src_next, hipEventDisableTiming));
+  h->src_alt = nullptr;
+  h->prefetch_pending = h->src_from_prefetch = h->mixing = false;
   for (int f = 0; f < UVIC_F_COUNT; ++f) {
     const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
     HIPCHK(hipMalloc(&h->buf[f], bytes));
@@ -315,6 +326,10 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
   }
   for (auto e : h->ev) (void)hipEventDestroy(e);
+  if (h->src_alt) (void)hipFree(h->src_alt);
+  (void)hipEventDestroy(h->ev_step_begin);
+  (void)hipEventDestroy(h->ev_src_next);
+  (void)hipStreamDestroy(h->side);
   (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -474,23 +489,29 @@ static int launch_convect(uvic_gpu *h) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+// per-step scalars, updates/09/source/mom/tracer.F:311-343
+static int mobi_step_scalars(uvic_gpu *h, double c2dtts, mobi_step &S) {
+  if (c2dtts == 0.0) return fail_msg("uvic_gpu_mobi: c2dtts not set (uvic_gpu_set_params)");
+  S.nbio = (int)(c2dtts / h->mobi_dtnpzd);
+  if (S.nbio < 1) return fail_msg("uvic_gpu_mobi: c2dtts/dtnpzd < 1");
+  S.dtbio = c2dtts / S.nbio;
+  S.rdtts = 1. / c2dtts;
+  S.rnbio = 1. / S.nbio;
+  const double yrtime = fmod(h->mobi.relyr, 1.);
+  S.month = 12;
+  for (int m = 1; m <= 12; ++m)
+    if (yrtime <= m / 12.) { S.month = m; break; }
+  S.declin = sin((fmod(h->mobi.relyr, 1.) - 0.22) * 2. * h->mobi.pi) * 0.4;
+  return 0;
+}
 static int launch_mobi(uvic_gpu *h) {
   if (!h->have_mobi) return 0;
-  {  // per-step scalars, updates/09/source/mom/tracer.F:311-343
-    const uvic_ctx &c = h->ctx;
-    if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_mobi: c2dtts not set (uvic_gpu_set_params)");
-    mobi_step &S = h->mobi.S;
-    S.nbio = (int)(c.c2dtts / h->mobi_dtnpzd);
-    if (S.nbio < 1) return fail_msg("uvic_gpu_mobi: c2dtts/dtnpzd < 1");
-    S.dtbio = c.c2dtts / S.nbio;
-    S.rdtts = 1. / c.c2dtts;
-    S.rnbio = 1. / S.nbio;
-    const double yrtime = fmod(h->mobi.relyr, 1.);
-    S.month = 12;
-    for (int m = 1; m <= 12; ++m)
-      if (yrtime <= m / 12.) { S.month = m; break; }
-    S.declin = sin((fmod(h->mobi.relyr, 1.) - 0.22) * 2. * h->mobi.pi) * 0.4;
+  if (h->src_from_prefetch) {  // sources of this step were computed one step ahead on the side stream
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
+    h->src_from_prefetch = false;
+    return 0;
   }
+  if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.S)) return rc;
   mark(h, "begin");
   hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi");
@@ -535,12 +556,45 @@ extern "C" int uvic_gpu_tracer(uvic_gpu *h) {
 // asynchronous variants used by the time loop of bench.py: no host sync
 extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
+  HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));  // everything the next step's sources may read is done
   if (int rc = launch_isopyc(h)) return rc;
   return launch_tracer(h);
+}
+// MOBI sources of the NEXT step from t(tau) (= next step's t(tau-1) on a leapfrog step) on
+// the side stream, overlapped with this step's transport.  Call after uvic_gpu_step_async
+// and before uvic_gpu_rotate; only valid when the next step is a leapfrog step.
+extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
+  if (!h) return fail_msg("null handle");
+  if (!h->have_mobi) return 0;
+  const size_t bytes = (size_t)field_elems(h->d, UVIC_F_SRC) * 8;
+  if (!h->src_alt) {
+    HIPCHK(hipMalloc(&h->src_alt, bytes));
+    HIPCHK(hipMemsetAsync(h->src_alt, 0, bytes, h->side));
+  }
+  uvic_ctx c = h->ctx;
+  mobi_dev m = h->mobi;
+  c.t_taum1 = h->ctx.t_tau;
+  c.src = (const double *)h->src_alt;
+  c.c2dtts = c2dtts_next;
+  if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
+  HIPCHK(hipStreamWaitEvent(h->side, h->ev_step_begin, 0));
+  hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev_src_next, h->side));
+  h->prefetch_pending = true;
+  return 0;
+}
+// forward (mixing) step: t(tau-1) aliases t(tau) until switched off again
+extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on) {
+  if (!h) return fail_msg("null handle");
+  h->mixing = on != 0;
+  bind_ctx(h);
+  return 0;
 }
 // sharded time loop: everything before the exchange of t(tau+1) ...
 extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
+  HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));
   if (int rc = launch_isopyc(h)) return rc;
   if (int rc = launch_mobi(h)) return rc;
   return launch_transport(h);
@@ -556,11 +610,19 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   h->buf[UVIC_F_T_TAUM1] = t0;
   h->buf[UVIC_F_T_TAU] = p1;
   h->buf[UVIC_F_T_TAUP1] = m1;
+  if (h->prefetch_pending) {  // the side stream filled the other source buffer for the step that starts now
+    void *s0 = h->buf[UVIC_F_SRC];
+    h->buf[UVIC_F_SRC] = h->src_alt;
+    h->src_alt = s0;
+    h->prefetch_pending = false;
+    h->src_from_prefetch = true;
+  }
   bind_ctx(h);
   return 0;
 }
 extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
+  HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }

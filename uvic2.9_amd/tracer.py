@@ -174,6 +174,12 @@ class TracerModel:
     def step_async(self):
         check(self.lib.uvic_gpu_step_async(self.h), "step_async")
 
+    def prefetch_sources(self, c2dtts_next):
+        check(self.lib.uvic_gpu_prefetch_sources(self.h, float(c2dtts_next)), "prefetch_sources")
+
+    def set_mixing(self, on):
+        check(self.lib.uvic_gpu_set_mixing(self.h, 1 if on else 0), "set_mixing")
+
     def rotate(self):
         check(self.lib.uvic_gpu_rotate(self.h), "rotate")
 
@@ -186,3 +192,35 @@ class TracerModel:
         n = ctypes.c_int()
         check(self.lib.uvic_gpu_profile(self.h, nrep, 32, names, ms, ctypes.byref(n)), "profile")
         return {names[i].decode(): ms[i] for i in range(n.value)}
+
+
+class TimeLoop:
+    """The ocean time-step schedule of `mom` for a device-resident model
+    (/root/reference/source/mom/mom.F:108-148): leapfrog steps with c2dtts = 2*dtts and a
+    forward "mixing" step with c2dtts = dtts every nmix-th step
+    (/root/reference/updates/09/source/common/switch.F:217-223), on which t(tau-1) := t(tau).
+    With MOBI, the source terms of the next leapfrog step are started one step ahead on a
+    side stream (they depend only on t(tau-1) of that step = t(tau) of this one)."""
+
+    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True):
+        self.m, self.dtts, self.nmix, self.shard, self.prefetch = model, float(dtts), int(nmix), shard, prefetch
+        self.itt = 0
+
+    def _mixing(self, itt):
+        return self.nmix > 0 and itt % self.nmix == 0
+
+    def step(self):
+        m = self.m
+        self.itt += 1
+        mixing = self._mixing(self.itt)
+        m.set_mixing(mixing)
+        m.set_params(c2dtts=self.dtts if mixing else 2.0 * self.dtts)
+        if self.shard is not None:
+            self.shard.step(m)
+        else:
+            m.step_async()
+        if self.prefetch and m.has_mobi and not self._mixing(self.itt + 1):
+            m.prefetch_sources(2.0 * self.dtts)
+        m.rotate()
+        if mixing:
+            m.set_mixing(False)
