@@ -157,6 +157,11 @@ void *uvic_gpu_field_devptr(uvic_gpu *h, int field);
 void *uvic_gpu_stream(uvic_gpu *h); /* hipStream_t the kernels are launched on */
 
 int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p);
+/* arithmetic of the transport kernels: 1 = every expression in the reference's order
+ * (bit-identical to the reference Fortran built without FMA contraction);
+ * 0 (default; env UVIC_EXACT overrides at create) = isopycnal coefficients folded once
+ * per step, agreement with the reference to rounding (<= 1e-12 relative, tests) */
+int uvic_gpu_set_exact(uvic_gpu *h, int exact);
 /* work decomposition: this instance computes tracers n0+1..n0+nt_local and rows
  * js..je (1-based, inclusive); defaults: all tracers, rows 2..jmt-1 */
 int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je);

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("c30", (102, 102, 19))])
-def test_overlay_tracer_matches_reference_tracer(cfg, dims):
+def test_overlay_tracer_matches_reference_tracer(cfg, dims, monkeypatch):
+    monkeypatch.setenv("UVIC_EXACT", "1")     # the overlay creates its own handle: bit-exact arithmetic
     if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
         pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
     import refdriver

@@ -21,6 +21,7 @@ def _model(oc, to, so, c, src=None):
     from uvic29_amd.tracer import TracerModel
     g = oc.grid
     m = TracerModel(g.imt, g.jmt, g.km, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd, device=0)
+    m.set_exact(True)        # this file checks the bit-exact formulation (kernels_fct.hpp)
     m.load_ocean(oc, to, so, c, src=src)
     return m
 

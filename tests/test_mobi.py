@@ -131,6 +131,7 @@ def test_gpu_full_step_with_mobi_vs_golden_and_oracle():
     to, so, c = synthetic.load_eos(6)
     g = np.load(GOLD / "step_c30_14x14x6.npz")
     m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.set_exact(True)
     m.load_ocean(oc, to, so, c)
     m.set_mobi(oc)
     m.isopyc(); m.tracer()
@@ -153,6 +154,7 @@ def test_gpu_twenty_steps_with_mobi_drift_vs_reference_run():
     to, so, c = synthetic.load_eos(6)
     g = np.load(GOLD / "run_c30_14x14x6_n20.npz")
     m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.set_exact(True)
     m.load_ocean(oc, to, so, c)
     m.set_mobi(oc)
     dtts, nmix = oc.params.dtts, oc.params.nmix
@@ -183,6 +185,7 @@ def test_gpu_time_loop_with_source_prefetch_matches_golden_run(prefetch):
     to, so, c = synthetic.load_eos(6)
     g = np.load(GOLD / "run_c30_14x14x6_n20.npz")
     m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.set_exact(True)
     m.load_ocean(oc, to, so, c)
     m.set_mobi(oc)
     loop = TimeLoop(m, oc.params.dtts, oc.params.nmix, prefetch=prefetch)

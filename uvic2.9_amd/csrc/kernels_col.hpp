@@ -1,0 +1,348 @@
+// kernels_col.hpp -- "lane per column" transport kernels (the production path).
+//
+// Same physics as kernels_fct.hpp (FCT adv_flux, isoflux, explicit update,
+// invtri; reference lines cited there), laid out for the CDNA4 wavefront:
+//
+//   one wave  = one latitude row r of one tracer, 64 adjacent columns
+//   one lane  = one (i) column; the lane marches down k = 1..km keeping the
+//               k-1,k,k+1 window of both time levels in registers
+//   x-neighbours come from the adjacent lanes by DPP shuffles (`__shfl_up/down`),
+//   rows r-1, r+1 from the lane's own coalesced loads; no LDS, no barriers.
+//   The two edge lanes on each side are halo (60 owned columns per wave),
+//   longitude wraps cyclically.
+//
+// The isopycnal flux terms are linear in the tracer with coefficients that do not
+// depend on the tracer: `coef_cell` folds Ai * slope (and metric factors, masks,
+// background diffusivities) into 19 per-face coefficients ONCE per step, so the
+// 24 fp64 divisions per cell update of the reference formulation disappear from
+// the per-tracer work.  This re-associates floating-point products:
+//     reference  ((Ai*dT)*drodx)/(drodz+eps)      here  (Ai*drodx/(drodz+eps))*dT
+// so results agree with the reference to rounding (tested: <= 1e-12 relative
+// after 20 and 100 steps, tests/test_gpu_fast.py), not bit for bit.  The
+// bit-exact formulation stays available (kernels_fct.hpp, UVIC_EXACT=1).
+//
+// Pass A (`colfct_wave`): low-order fluxes, t_lo, limiter ratios, limited x and z
+//   fluxes, all diffusive fluxes -> S = the explicit tendency except the y
+//   advection and the source term, and the y-limiter ratios R+-Y.
+// Pass B (`colupd_wave`): limited y fluxes from R+-Y(r-1..r+1), explicit update,
+//   tridiagonal solve -> t(tau+1).
+#ifndef UVIC_KERNELS_COL_HPP
+#define UVIC_KERNELS_COL_HPP
+
+#include "kernels_fct.hpp"
+
+namespace uvic {
+
+enum {  // planes of the coefficient buffer, each (imt,km,jmt)
+  CF_AE = 0, CF_CE = 1,   // east face:   A, C[ip + 2*kr]
+  CF_AN = 5, CF_CN = 6,   // north face
+  CF_BV = 10, CF_CBX = 11, CF_CBY = 15,  // bottom face
+  CF_COUNT = 19
+};
+
+// ---------------------------------------------------------------------------
+// per-step coefficient folding; one thread per cell, i = 2..imt-1
+// ---------------------------------------------------------------------------
+UVIC_DEV void coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
+  UV_DIMS(c);
+  const size_t q = X3(i, k, j);
+  const double dzt4r = 0.5 * c.dzt2r[k - 1];
+  if (j >= 2 && j <= jmt - 1) {  // east face: tracer.F:930-942, isopyc.F:953-1002, fdift.h:61-62
+    const double m = TMASK(i, k, j) * TMASK(i + 1, k, j);
+    const double cstdxur = c.cstr[j - 1] * c.dxur[i - 1];
+    cf[q + (size_t)CF_AE * N3] = (c.diff_cet * cstdxur + c.K11[q] * cstdxur) * m;
+    for (int kr = 0; kr <= 1; ++kr)
+      for (int ip = 0; ip <= 1; ++ip)
+        cf[q + (size_t)(CF_CE + ip + 2 * kr) * N3] =
+            -dzt4r * (c.Ai_ez[q + (size_t)(ip + 2 * kr) * N3] * drodxe(i, k, j, ip) / (drodze(i, k, j, ip, kr) + UV_EPSLN));
+  }
+  if (j <= jmt - 1) {  // north face: tracer.F:948-961, isopyc.F:1008-1053, fdift.h:77-78
+    const double m = TMASK(i, k, j) * TMASK(i, k, j + 1);
+    cf[q + (size_t)CF_AN * N3] = (c.diff_cnt * c.csu_dyur[j - 1] + c.K22[q] * c.csu_dyur[j - 1]) * m;
+    const double csu_dzt4r = c.csu[j - 1] * dzt4r;
+    for (int kr = 0; kr <= 1; ++kr)
+      for (int jq = 0; jq <= 1; ++jq)
+        cf[q + (size_t)(CF_CN + jq + 2 * kr) * N3] =
+            -csu_dzt4r * (c.Ai_nz[q + (size_t)(jq + 2 * kr) * N3] * drodyn(i, k, j, jq) / (drodzn(i, k, j, jq, kr) + UV_EPSLN));
+  }
+  if (j >= 2 && j <= jmt - 1) {  // bottom face: tracer.F:1025-1032, isopyc.F:1062-1107, fdift.h:83-88
+    if (k <= km - 1) {
+      cf[q + (size_t)CF_BV * N3] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
+      for (int ip = 0; ip <= 1; ++ip)
+        for (int kr = 0; kr <= 1; ++kr)
+          cf[q + (size_t)(CF_CBX + ip + 2 * kr) * N3] =
+              -c.dxt4r[i - 1] * (c.Ai_bx[q + (size_t)(ip + 2 * kr) * N3] * c.cstr[j - 1] * drodxb(i, k, j, ip, kr) /
+                                 (drodzb(i, k, j, kr) + UV_EPSLN));
+      for (int jq = 0; jq <= 1; ++jq)
+        for (int kr = 0; kr <= 1; ++kr)
+          cf[q + (size_t)(CF_CBY + jq + 2 * kr) * N3] =
+              -c.dyt4r[j - 1] * c.cstr[j - 1] *
+              (c.Ai_by[q + (size_t)(jq + 2 * kr) * N3] * c.csu[j - 1 + jq - 1] * drodyb(i, k, j, jq, kr) /
+               (drodzb(i, k, j, kr) + UV_EPSLN));
+    } else {
+      for (int p = CF_BV; p < CF_COUNT; ++p) cf[q + (size_t)p * N3] = 0.0;
+    }
+  }
+}
+
+#if defined(__HIPCC__)
+struct ColGrid {
+  int r0, nrows, nseg, total;  // total = nrows * nt_local * nseg work items (one wave each)
+};
+#define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
+
+__device__ __forceinline__ double shfl_w(double v) { return __shfl_up(v, 1); }    // value of lane-1 (west)
+__device__ __forceinline__ double shfl_e(double v) { return __shfl_down(v, 1); }  // value of lane+1 (east)
+__device__ __forceinline__ double upstream(double v, double a, double b) { return v * (a + b) + dabs(v) * (a - b); }
+__device__ __forceinline__ double limited(double cpos, double cneg, double f) {
+  return 0.5 * ((cpos + cneg) * f + (cpos - cneg) * dabs(f));
+}
+// R+ and R- of Zalesak's limiter for one cell (tracer_adv_flx.F:672-690)
+__device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, double scale, double flxlft, double flxrgt,
+                                          double mask, double &rp, double &rm) {
+  const double trmax = dmax(dmax(fxa, fxb), tlo), trmin = dmin(dmin(fxa, fxb), tlo);
+  const double pplus = scale * (dmax(0.0, flxlft) - dmin(0.0, flxrgt));
+  const double pminus = scale * (dmax(0.0, flxrgt) - dmin(0.0, flxlft));
+  rp = dmin(1., mask * (trmax - tlo) / (pplus + UV_EPSLN));
+  rm = dmin(1., mask * (tlo - trmin) / (pminus + UV_EPSLN));
+}
+
+__device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
+  if (item >= g.total) return false;
+  const int seg = item % g.nseg;
+  const int rest = item / g.nseg;
+  n1 = c.n0 + rest % c.nt_local + 1;
+  r = g.r0 + rest / c.nt_local;
+  i0 = 2 + seg * COL_OWN;
+  i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
+  return true;
+}
+__device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..imt-1, cyclic
+  const int p = imt - 2;
+  int y = (x - 2) % p;
+  if (y < 0) y += p;
+  return y + 2;
+}
+
+// ===========================================================================
+// pass A
+// ===========================================================================
+__device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
+                                            int r, int n1, int i0, int i1) {
+  UV_DIMS(c);
+  const int lane = threadIdx.x;
+  const int i = col_wrap(i0 - 2 + lane, imt);
+  const bool owned = lane >= 2 && lane <= 2 + (i1 - i0);
+  const size_t nloc = (size_t)(n1 - 1 - c.n0);
+  const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
+  const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
+  double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
+  double *Sn = S + nloc * N3;
+  const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
+  const int kz_w = __shfl_up(kz, 1), kz_e = __shfl_down(kz, 1);
+  const double cstr_r = c.cstr[r - 1];
+  const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
+  const double cstdyt2r = c.cstdyt2r[r - 1], cstdytr = c.cstdytr[r - 1];
+  const double c2dtts = c.c2dtts;
+  const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
+  const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
+  const size_t rowstride = (size_t)imt * km;
+  const size_t base = X3(i, 1, r);  // level k at base + (k-1)*imt
+#define LD(p, k, dj) (p)[base + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride]
+#define CF(pl, k, dj) cf[base + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride + (size_t)(pl) * N3]
+  // rolling windows: index 0 = level s-1, 1 = level s, 2 = level s+1
+  double mc[3], ms[3], mn[3], tc[3];
+  mc[0] = mc[1] = LD(tm, 1, 0); ms[0] = ms[1] = LD(tm, 1, -1); mn[0] = mn[1] = LD(tm, 1, 1);
+  tc[0] = tc[1] = LD(tt, 1, 0);
+  // surface faces
+  const double vb0 = c.adv_vbt[XF(i, 0, r)];
+  double fblo_up = vb0 * 2.0 * mc[1];            // low-order flux through the face above level s
+  double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
+  double fbfin_up2 = vb0 * (tc[1] + tc[1]);      // FINAL advective flux through the face above level s-1 ... (top: tracer.F:1063)
+  double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
+  double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
+  double fbfin_up = fbfin_up2;                   // final flux through the face above the level being finalised
+  for (int s = 1; s <= km; ++s) {
+    const bool last = (s == km);
+    const int sp = last ? km : s + 1;
+    mc[2] = LD(tm, sp, 0); ms[2] = LD(tm, sp, -1); mn[2] = LD(tm, sp, 1); tc[2] = LD(tt, sp, 0);
+    const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
+    const double mk = (s <= kz) ? 1.0 : 0.0, mk_w = (s <= kz_w) ? 1.0 : 0.0, mk_e = (s <= kz_e) ? 1.0 : 0.0;
+    const double mk_s = (s <= kz_s) ? 1.0 : 0.0, mk_n = (s <= kz_n) ? 1.0 : 0.0;
+    const double mk_up = (s - 1 >= 1 && s - 1 <= kz) ? 1.0 : 0.0, mk_dn = (s + 1 <= kz) ? 1.0 : 0.0;
+    const double m_c = mc[1], tt_c = tc[1];
+    const double m_e = shfl_e(m_c), tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
+    // ---- advection, low order and raw antidiffusive (adv_flx:500-619) ----------
+    const double ve = c.tot_e[base + (size_t)(s - 1) * imt];
+    const double vn = c.tot_n[base + (size_t)(s - 1) * imt], vs = c.tot_n[base + (size_t)(s - 1) * imt - rowstride];
+    const double felo = upstream(ve, m_c, m_e);
+    const double afe = ve * (tt_c + tt_e) - felo;
+    const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
+    const double fnlo_n = upstream(vn, m_c, mn[1]), fnlo_s = upstream(vs, ms[1], m_c);
+    double fblo = 0.0, afb = 0.0;
+    if (!last) {
+      const double vb = c.tot_b[XF(i, s, r)];
+      fblo = vb * (mc[2] + m_c) + dabs(vb) * (mc[2] - m_c);
+      afb = vb * (tt_c + tc[2]) - fblo * mk;
+    }
+    const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
+    const double advz = (fblo_up - fblo) * c.dzt2r[s - 1];
+    const double tlo = m_c - (c2dtts * c.dtxcel[s - 1]) * (advx + advy + advz) * mk;
+    // ---- limiter ratios ---------------------------------------------------------
+    double rxp, rxm, ryp, rym, rzp, rzm;
+    {
+      const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
+      fct_ratio(mk_w * mw + (1.0 - mk_w) * tlo, mk_e * me + (1.0 - mk_e) * tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
+    }
+    {
+      const double afn_n = vn * (tt_c + t_n) - fnlo_n;
+      const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
+      fct_ratio(0.5 * mk_s * (t_s + tt_c) + (1.0 - mk_s) * tlo, 0.5 * mk_n * (tt_c + t_n) + (1.0 - mk_n) * tlo, tlo,
+                c2dtts * cstdyt2r, afn_s, afn_n, mk, ryp, rym);
+    }
+    {
+      const double fxa = (s > 1) ? 0.5 * mk_up * (tc[0] + tt_c) + (1.0 - mk_up) * tlo : tlo;
+      const double fxb = (!last) ? 0.5 * mk_dn * (tt_c + tc[2]) + (1.0 - mk_dn) * tlo : tlo;
+      fct_ratio(fxa, fxb, tlo, c2dtts * c.dzt2r[s - 1], afb, afb_up, mk, rzp, rzm);
+    }
+    if (owned) {
+      RpY[base + (size_t)(s - 1) * imt] = ryp;
+      RmY[base + (size_t)(s - 1) * imt] = rym;
+    }
+    // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
+    const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
+    const double fefin = limited(dmin(rxp_e, rxm), dmin(rxp, rxm_e), afe) + felo;
+    const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
+    // ---- diffusive fluxes (coefficients folded by coef_cell) ---------------------------
+    const double dz_up = (s > 1) ? mc[0] - m_c : 0.0, dz_dn = (!last) ? m_c - mc[2] : 0.0;       // own column
+    const double dze_up = shfl_e(dz_up), dze_dn = shfl_e(dz_dn);                                     // east column
+    const double dzs_up = (s > 1) ? ms[0] - ms[1] : 0.0, dzs_dn = (!last) ? ms[1] - ms[2] : 0.0;  // south row
+    const double dzn_up = (s > 1) ? mn[0] - mn[1] : 0.0, dzn_dn = (!last) ? mn[1] - mn[2] : 0.0;  // north row
+    const double dfe = CF(CF_AE, s, 0) * (m_e - m_c) + CF(CF_CE + 0, s, 0) * dz_up + CF(CF_CE + 1, s, 0) * dze_up +
+                       CF(CF_CE + 2, s, 0) * dz_dn + CF(CF_CE + 3, s, 0) * dze_dn;
+    const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
+    const double dfn_n = CF(CF_AN, s, 0) * (mn[1] - m_c) + CF(CF_CN + 0, s, 0) * dz_up + CF(CF_CN + 1, s, 0) * dzn_up +
+                         CF(CF_CN + 2, s, 0) * dz_dn + CF(CF_CN + 3, s, 0) * dzn_dn;
+    const double dfn_s = CF(CF_AN, s, -1) * (m_c - ms[1]) + CF(CF_CN + 0, s, -1) * dzs_up + CF(CF_CN + 1, s, -1) * dz_up +
+                         CF(CF_CN + 2, s, -1) * dzs_dn + CF(CF_CN + 3, s, -1) * dz_dn;
+    const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
+    double dfb = 0.0, dfbi = 0.0;  // through the face below level s
+    if (!last) {
+      const double dx_c = m_e - m_c, dx_d = shfl_e(mc[2]) - mc[2];  // T(i+1)-T(i) at levels s, s+1
+      const double dxw_c = shfl_w(dx_c), dxw_d = shfl_w(dx_d);      // T(i)-T(i-1)
+      dfb = CF(CF_BV, s, 0) * (m_c - mc[2]);
+      dfbi = CF(CF_CBX + 0, s, 0) * dxw_c + CF(CF_CBX + 1, s, 0) * dx_c + CF(CF_CBX + 2, s, 0) * dxw_d + CF(CF_CBX + 3, s, 0) * dx_d +
+             CF(CF_CBY + 0, s, 0) * (m_c - ms[1]) + CF(CF_CBY + 1, s, 0) * (mn[1] - m_c) + CF(CF_CBY + 2, s, 0) * (mc[2] - ms[2]) +
+             CF(CF_CBY + 3, s, 0) * (mn[2] - mc[2]);
+    }
+    if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
+    if (kz == 0 && s == 1) dfb_up = btf;
+    const double DIFF_Tz = (dfb_up - dfb) * c.dztr[s - 1] + (dfbi_up - dfbi) * c.dztr[s - 1];
+    const double spart = DIFF_Tx + DIFF_Ty + DIFF_Tz - ADV_Tx;
+    // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
+    if (s >= 2) {
+      const double fbfin = (limited(dmin(rzp_prev, rzm), dmin(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
+      const double ADV_Tz = (fbfin_up - fbfin) * c.dzt2r[s - 2];
+      if (owned) Sn[base + (size_t)(s - 2) * imt] = spart_prev - ADV_Tz;
+      fbfin_up = fbfin;
+    }
+    if (last) {  // bottom face of the column (tracer.F:1065)
+      const double fbfin = c.adv_vbt[XF(i, km, r)] * tt_c;
+      const double ADV_Tz = (fbfin_up - fbfin) * c.dzt2r[km - 1];
+      if (owned) Sn[base + (size_t)(km - 1) * imt] = spart - ADV_Tz;
+    }
+    // ---- roll ---------------------------------------------------------------------------
+    rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
+    fblo_up = fblo; afb_up = afb; dfb_up = dfb; dfbi_up = dfbi;
+    mc[0] = mc[1]; mc[1] = mc[2]; ms[0] = ms[1]; ms[1] = ms[2]; mn[0] = mn[1]; mn[1] = mn[2]; tc[0] = tc[1]; tc[1] = tc[2];
+  }
+#undef LD
+#undef CF
+  (void)fbfin_up2;
+}
+
+// ===========================================================================
+// pass B: y advection, explicit update, implicit vertical diffusion (invtri.F)
+// `ework` is a per-lane scratch of km doubles in LDS laid out [k][lane]
+// ===========================================================================
+__device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int r, int n1,
+                                            int i0, int i1) {
+  UV_DIMS(c);
+  const int lane = threadIdx.x;
+  const int i = i0 + lane;
+  if (i > i1) return;
+  const size_t nloc = (size_t)(n1 - 1 - c.n0);
+  const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
+  const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
+  double *tp = c.t_taup1 + (size_t)(n1 - 1) * N3;
+  const double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
+  const double *Sn = S + nloc * N3;
+  // the source term is read here, not in pass A: with MOBI computed one step ahead on the side
+  // stream only this pass has to wait for it
+  const double *source = 0;
+  if (c.src && c.itrc[n1 - 1] != 0) source = c.src + (size_t)(c.itrc[n1 - 1] - 1) * N3;
+  const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)];
+  const double cstdyt2r = c.cstdyt2r[r - 1];
+  const size_t rowstride = (size_t)imt * km;
+  const size_t base = X3(i, 1, r);
+  const double topbc = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt], botbc = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt];
+  const double aidif = c.aidif, eps = 1.e-30;
+  const int kb = imax(2, kz);
+  double bet = 0.0, zprev = 0.0, cprev = 0.0;
+  const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
+  for (int k = 1; k <= km; ++k) {
+    const size_t q = base + (size_t)(k - 1) * imt;
+    const double m_c = tm[q], m_s = tm[q - rowstride], m_n = tm[q + rowstride];
+    const double t_c = tt[q], t_s = tt[q - rowstride], t_n = tt[q + rowstride];
+    const double vn = c.tot_n[q], vs = c.tot_n[q - rowstride];
+    const double mk = (k <= kz) ? 1.0 : 0.0, mk_s = (k <= kz_s) ? 1.0 : 0.0;
+    const double lo_n = upstream(vn, m_c, m_n), lo_s = upstream(vs, m_s, m_c);
+    const double f_n = vn * (t_c + t_n) - lo_n;
+    const double f_s = (r - 1 == 1) ? 0.0 : vs * (t_s + t_c) - lo_s;
+    const double rp0 = RpY[q], rm0 = RmY[q], rps = RpY[q - rowstride], rms = RmY[q - rowstride];
+    const double rpn = RpY[q + rowstride], rmn = RmY[q + rowstride];
+    const double fn_n = (limited(dmin(rpn, rm0), dmin(rp0, rmn), f_n) + lo_n) * mk;
+    const double fn_s = (limited(dmin(rp0, rms), dmin(rps, rm0), f_s) + lo_s) * mk_s;
+    const double ADV_Ty = (fn_n - fn_s) * cstdyt2r;
+    const double tdt = c.c2dtts * c.dtxcel[k - 1];
+    const double z = m_c + tdt * (Sn[q] - ADV_Ty + (source ? source[q] : 0.0)) * mk;
+    // Thomas forward sweep, invtri.F:57-100
+    const int km1 = imax(1, k - 1), kp1 = imin(k + 1, km);
+    const double factu = c.dztur[k - 1] * tdt * aidif, factl = c.dztlr[k - 1] * tdt * aidif;
+    double a = -c.diff_cbt[base + (size_t)(km1 - 1) * imt] * factu * mk;
+    double cc = -c.diff_cbt[q] * factl * ((kp1 <= kz) ? 1.0 : 0.0);
+    double f = z * mk;
+    if (k == 1) a = 0.0;
+    if (k == km) cc = 0.0;
+    const double b = 1.0 - a - cc;
+    if (k == 1) f = z + topbc * tdt * c.dztr[0] * aidif * mk;
+    if (k == kb) f = z - botbc * tdt * c.dztr[k - 1] * aidif * mk;
+    double znew;
+    if (k == 1) {
+      bet = mk / (b + eps);
+      znew = f * bet;
+    } else {
+      const double e = cprev * bet;
+      ework[(size_t)k * 64 + lane] = e;
+      bet = mk / (b - a * e + eps);
+      znew = (f - a * zprev) * bet;
+    }
+    tp[q] = znew;
+    zprev = znew;
+    cprev = cc;
+  }
+  // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155)
+  double znext = zprev;
+  if (ic) tp[X3(ic, km, r)] = znext;
+  for (int k = km - 1; k >= 1; --k) {
+    const size_t q = base + (size_t)(k - 1) * imt;
+    const double zk = tp[q] - ework[(size_t)(k + 1) * 64 + lane] * znext;
+    tp[q] = zk;
+    if (ic) tp[X3(ic, k, r)] = zk;
+    znext = zk;
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace uvic
+#endif

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/uvic_gpu.h"
+#include "kernels_col.hpp"
 #include "kernels_fct.hpp"
 #include "kernels_isopyc.hpp"
 #include "kernels_mobi.hpp"
@@ -91,6 +92,27 @@ __global__ void __launch_bounds__(1024) k_update_rows(const uvic_ctx c, const Ti
   GpuEnv env;
   update_rows_block(env, c, n1, row, chunk, g.nchunk, lds);
 }
+// ---- lane-per-column production path (kernels_col.hpp) ------------------------------
+__global__ void __launch_bounds__(256) k_coef(const uvic_ctx c, double *cf) {
+  CELL_DECODE(c);
+  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  coef_cell(c, cf, i, k, j);
+}
+__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  const int nblk = (g.total + 3) / 4;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  int r, n1, i0, i1;
+  if (blk >= nblk || !col_decode(c, g, blk * 4 + threadIdx.y, r, n1, i0, i1)) return;
+  colfct_wave(c, cf, S, r, n1, i0, i1);
+}
+__global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int nblk = (g.total + 3) / 4;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  int r, n1, i0, i1;
+  if (blk >= nblk || !col_decode(c, g, blk * 4 + threadIdx.y, r, n1, i0, i1)) return;
+  colupd_wave(c, S, lds + (size_t)threadIdx.y * (c.km + 1) * 64, r, n1, i0, i1);
+}
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -101,6 +123,9 @@ __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m)
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  // few, long, latency-bound waves: let them win issue arbitration over the streaming kernels
+  // that share their SIMDs when the sources are computed one step ahead on the side stream
+  __builtin_amdgcn_s_setprio(3);
   mobi_column_kernel(c, m, i, j);
 }
 
@@ -171,7 +196,9 @@ struct uvic_gpu {
   int device;
   hipStream_t stream;
   void *buf[UVIC_F_COUNT];
-  double *work[8];  // tot_e, tot_n, tot_b, adv_x, adv_z, RpY, RmY
+  double *work[8];  // tot_e, tot_n, tot_b, adv_x (also S of the column path), adv_z, RpY, RmY
+  double *coef;     // folded isopycnal coefficients, CF_COUNT planes (kernels_col.hpp)
+  bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
   uvic_ctx ctx;
   mobi_dev mobi;
   mobi_store mobi_st;
@@ -276,6 +303,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
     HIPCHK(hipMalloc((void **)&h->work[w], wsz[w] * 8));
     HIPCHK(hipMemset(h->work[w], 0, wsz[w] * 8));
   }
+  HIPCHK(hipMalloc((void **)&h->coef, N3 * 8 * CF_COUNT));
+  HIPCHK(hipMemset(h->coef, 0, N3 * 8 * CF_COUNT));
+  h->exact = false;
+  if (const char *e = getenv("UVIC_EXACT")) h->exact = atoi(e) != 0;
   // tmask lives in its own buffer (derived data)
   double *tmask;
   HIPCHK(hipMalloc((void **)&tmask, N3 * 8));
@@ -321,6 +352,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
+  (void)hipFree(h->coef);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
@@ -422,6 +454,11 @@ extern "C" int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p) {
   h->ctx.diff_cbt_given = p->diff_cbt_has_k33 ? 1 : 0;
   return 0;
 }
+extern "C" int uvic_gpu_set_exact(uvic_gpu *h, int exact) {
+  if (!h) return fail_msg("uvic_gpu_set_exact: null handle");
+  h->exact = exact != 0;
+  return 0;
+}
 extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je) {
   if (!h) return fail_msg("uvic_gpu_set_shard: null handle");
   if (n0 < 0 || nt_local < 0 || n0 + nt_local > h->d.nt) return fail_msg("uvic_gpu_set_shard: tracer range outside 1..nt");
@@ -459,6 +496,10 @@ static int launch_isopyc(uvic_gpu *h) {
   mark(h, "isopyc_adv");
   hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, c);
   mark(h, "isopyc_column");
+  if (!h->exact) {
+    hipLaunchKernelGGL(k_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c, h->coef);
+    mark(h, "coef");
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -466,6 +507,29 @@ static int launch_transport(uvic_gpu *h) {
   const uvic_ctx &c = h->ctx;
   if (c.nt_local <= 0) return 0;
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
+  if (!h->exact) {  // lane-per-column path
+    ColGrid a, b;
+    a.r0 = c.js - 1 < 2 ? 2 : c.js - 1;
+    const int ra = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
+    a.nrows = ra - a.r0 + 1;
+    a.nseg = (c.imt - 2 + COL_OWN - 1) / COL_OWN;
+    a.total = a.nrows * c.nt_local * a.nseg;
+    b = a;
+    b.r0 = c.js; b.nrows = c.je - c.js + 1; b.total = b.nrows * c.nt_local * b.nseg;
+    double *S = h->work[3];
+    mark(h, "begin");
+    const unsigned na = (unsigned)((((a.total + 3) / 4 + 7) / 8) * 8), nb = (unsigned)((((b.total + 3) / 4 + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_colfct, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+    mark(h, "colfct");
+    if (h->src_from_prefetch) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
+      h->src_from_prefetch = false;
+    }
+    hipLaunchKernelGGL(k_colupd, dim3(nb), dim3(64, 4), (size_t)4 * (c.km + 1) * 64 * 8, h->stream, c, (const double *)S, b);
+    mark(h, "colupd");
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   TileGrid g1, g2;
   g1.r0 = c.js - 1 < 2 ? 2 : c.js - 1;
   const int r1 = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
@@ -477,6 +541,10 @@ static int launch_transport(uvic_gpu *h) {
   mark(h, "begin");
   hipLaunchKernelGGL(k_fct_rows, dim3((unsigned)(((g1.total + 7) / 8) * 8)), dim3(h->fct_threads), h->fct_lds, h->stream, c, g1);
   mark(h, "fct_rows");
+  if (h->src_from_prefetch) {  // the FCT kernel does not read the sources; only the update does
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
+    h->src_from_prefetch = false;
+  }
   hipLaunchKernelGGL(k_update_rows, dim3((unsigned)(((g2.total + 7) / 8) * 8)), dim3(h->upd_threads), h->upd_lds, h->stream, c, g2);
   mark(h, "update_rows");
   HIPCHK(hipGetLastError());
@@ -506,11 +574,7 @@ static int mobi_step_scalars(uvic_gpu *h, double c2dtts, mobi_step &S) {
 }
 static int launch_mobi(uvic_gpu *h) {
   if (!h->have_mobi) return 0;
-  if (h->src_from_prefetch) {  // sources of this step were computed one step ahead on the side stream
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
-    h->src_from_prefetch = false;
-    return 0;
-  }
+  if (h->src_from_prefetch) return 0;  // computed one step ahead on the side stream; launch_transport waits for it
   if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.S)) return rc;
   mark(h, "begin");
   hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);

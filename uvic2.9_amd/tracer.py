@@ -177,6 +177,10 @@ class TracerModel:
     def prefetch_sources(self, c2dtts_next):
         check(self.lib.uvic_gpu_prefetch_sources(self.h, float(c2dtts_next)), "prefetch_sources")
 
+    def set_exact(self, on):
+        """True: bit-exact row kernels; False: lane-per-column kernels with folded coefficients."""
+        check(self.lib.uvic_gpu_set_exact(self.h, 1 if on else 0), "set_exact")
+
     def set_mixing(self, on):
         check(self.lib.uvic_gpu_set_mixing(self.h, 1 if on else 0), "set_mixing")
 
