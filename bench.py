@@ -43,6 +43,10 @@ def kernel_alg_bytes(name, nt, nsrc):
         return 16.0 + 32.0 / nt
     if name == "update_rows":    # reads t(tau-1), t(tau), source; writes t(tau+1); shared isopyc fields + metrics
         return 24.0 + 8.0 * nsrc / nt + 248.0 / nt
+    if name == "colfct":         # reads t(tau-1), t(tau); shared: 3 total velocities, 19 folded coefficients, kmt
+        return 16.0 + 184.0 / nt
+    if name == "colupd":         # reads t(tau-1), t(tau), source; writes t(tau+1); shared: tot_n, diff_cbt
+        return 24.0 + 8.0 * nsrc / nt + 16.0 / nt
     return None
 
 

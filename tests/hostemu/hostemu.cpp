@@ -77,6 +77,11 @@ extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uv
   for (int m = 1; m <= 12; ++m)
     if (yrtime <= m / 12.) { S.month = m; break; }
   S.declin = sin((fmod(F->relyr, 1.) - 0.22) * 2. * F->pi) * 0.4;
+  std::vector<double> ac13b((size_t)c.imt * c.km * c.jmt, 0.0);
+  M.ac13b = ac13b.data();
+  for (int j = c.js; j <= c.je; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) mobi_co2_cell(c, M, i, k, j);
   for (int j = c.js; j <= c.je; ++j)
     for (int i = 2; i <= c.imt - 1; ++i) mobi_column_kernel(c, M, i, j);
 }

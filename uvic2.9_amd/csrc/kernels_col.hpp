@@ -109,10 +109,12 @@ __device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, do
 
 __device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
   if (item >= g.total) return false;
-  const int seg = item % g.nseg;
-  const int rest = item / g.nseg;
-  n1 = c.n0 + rest % c.nt_local + 1;
-  r = g.r0 + rest / c.nt_local;
+  // tracer index fastest: the four waves of a workgroup work on four tracers of the same
+  // row and longitude segment and share its coefficient lines in L1
+  n1 = c.n0 + item % c.nt_local + 1;
+  const int rest = item / c.nt_local;
+  const int seg = rest % g.nseg;
+  r = g.r0 + rest / g.nseg;
   i0 = 2 + seg * COL_OWN;
   i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
   return true;

@@ -40,6 +40,7 @@ struct mobi_dev {
   const uvic_mobi_params *P;   // device copy
   const double *tlat, *dnswr, *aice, *hice, *hsno, *sg_bathy, *fe_atmdep, *fe_hydr;
   double pi, radian, relyr, co2ccn;
+  double *ac13b;               // (imt,km,jmt) carbon-13 fractionation factor of photosynthesis, from mobi_co2_cell
   mobi_step S;
 };
 
@@ -559,6 +560,31 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
 
 
 // ---------------------------------------------------------------------------
+// carbonate chemistry of one cell (co2calc_SWS, called at mobi.F:772 for every level of
+// every column): it depends on T, S, DIC and alkalinity of the cell only, not on the
+// vertical sequence of mobi_driver, so it runs cell-parallel ahead of the column kernel.
+// Of its outputs option set C uses only CO2* through the 13C fractionation factor
+// ac13b = ac13_aq_POC / ac13_DIC_aq (mobi.F:775-789).  One thread per cell.
+// ---------------------------------------------------------------------------
+UVIC_DEV void mobi_co2_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
+  UV_DIMS(c);
+  const uvic_mobi_params *P = M.P;
+  if (k > c.kmt[X2(i, j)]) return;
+#define TM(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
+  const double t_in = TM(k, P->itemp);
+  const double s_in = 1.e3 * TM(k, P->isalt) + 35.0;
+  const double dic_in = TM(k, P->idic), alk_in = TM(k, P->ialk);
+#undef TM
+  const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
+  double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
+  mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3,
+                   &Omega_c, &Omega_a);
+  const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
+  const double ac13_aq_POC = -0.017 * log10(dmin(dmax(co2star * 1000., 2.), 74.)) + 1.0034;
+  M.ac13b[X3(i, k, j)] = ac13_aq_POC / ac13_DIC_aq;
+}
+
+// ---------------------------------------------------------------------------
 // mobi_driver (mobi.F:519-1482) fused with its caller (tracer.F:355-545) for
 // the column (i,j): writes src(i,:,j,:) of every source slot.
 // ---------------------------------------------------------------------------
@@ -613,13 +639,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
       o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
       aou_in = o2sat - o2_in;
     }
-    const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
-    double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
-    mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3,
-                     &Omega_c, &Omega_a);
-    const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
-    const double ac13_aq_POC = -0.017 * log10(dmin(dmax(co2star * 1000., 2.), 74.)) + 1.0034;
-    const double ac13b = ac13_aq_POC / ac13_DIC_aq;
+    const double ac13b = M.ac13b[X3(i, k, j)];
     rc13impo = rc13expo * P->dztr[k - 1];
     swr = swr * exp(-P->kc * phin);
     phin = TNC(k, MI::phyt) * P->dzt[k - 1] + TNC(k, MI::diaz) * P->dzt[k - 1];
@@ -744,6 +764,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
 struct mobi_store {
   void *params;
   double *f[8];
+  double *ac13b, *ac13b_side;   // one per stream: the side stream works one step ahead
 };
 static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp, const uvic_mobi_forcing *hf, mobi_dev *dev,
                             mobi_store *st, hipStream_t stream, std::string &err) {
@@ -767,6 +788,10 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
     if ((e = hipMalloc(&st->params, sizeof(uvic_mobi_params))) != hipSuccess) { err = hipGetErrorString(e); return 1; }
     for (int q = 0; q < 8; ++q)
       if ((e = hipMalloc((void **)&st->f[q], sz[q] * 8)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMalloc((void **)&st->ac13b, NS * km * 8)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMemsetAsync(st->ac13b, 0, NS * km * 8, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMalloc((void **)&st->ac13b_side, NS * km * 8)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMemsetAsync(st->ac13b_side, 0, NS * km * 8, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
   }
   if ((e = hipMemcpyAsync(st->params, hp, sizeof(uvic_mobi_params), hipMemcpyHostToDevice, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
   for (int q = 0; q < 8; ++q) {
@@ -777,6 +802,7 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
   dev->P = (const uvic_mobi_params *)st->params;
   dev->tlat = st->f[0]; dev->dnswr = st->f[1]; dev->aice = st->f[2]; dev->hice = st->f[3]; dev->hsno = st->f[4];
   dev->sg_bathy = st->f[5]; dev->fe_atmdep = st->f[6]; dev->fe_hydr = st->f[7];
+  dev->ac13b = st->ac13b;
   dev->pi = hf->pi; dev->radian = hf->radian; dev->relyr = hf->relyr; dev->co2ccn = hf->co2ccn;
   return 0;
 }

@@ -119,6 +119,11 @@ __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
   convect_column(c, i, j);
 }
+__global__ void __launch_bounds__(128) k_mobi_co2(const uvic_ctx c, const mobi_dev m) {
+  CELL_DECODE(c);
+  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  mobi_co2_cell(c, m, i, k, j);
+}
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -355,6 +360,8 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->coef);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
+    (void)hipFree(h->mobi_st.ac13b);
+    (void)hipFree(h->mobi_st.ac13b_side);
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
   }
   for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -577,6 +584,8 @@ static int launch_mobi(uvic_gpu *h) {
   if (h->src_from_prefetch) return 0;  // computed one step ahead on the side stream; launch_transport waits for it
   if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.S)) return rc;
   mark(h, "begin");
+  hipLaunchKernelGGL(k_mobi_co2, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
+  mark(h, "mobi_co2");
   hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi");
   HIPCHK(hipGetLastError());
@@ -638,10 +647,12 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   uvic_ctx c = h->ctx;
   mobi_dev m = h->mobi;
   c.t_taum1 = h->ctx.t_tau;
+  m.ac13b = h->mobi_st.ac13b_side;
   c.src = (const double *)h->src_alt;
   c.c2dtts = c2dtts_next;
   if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_step_begin, 0));
+  hipLaunchKernelGGL(k_mobi_co2, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
   hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev_src_next, h->side));
