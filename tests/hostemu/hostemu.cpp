@@ -59,6 +59,17 @@ extern "C" void emu_convect(const uvic_ctx *cp) {
     for (int i = 2; i <= c.imt - 1; ++i) convect_column(c, i, j);
 }
 
+// the two-pass form used on the GPU
+extern "C" void emu_convect_twopass(const uvic_ctx *cp) {
+  const uvic_ctx &c = *cp;
+  std::vector<double> col(2 * (size_t)c.km);
+  for (int j = c.js; j <= c.je; ++j)
+    for (int i = 2; i <= c.imt - 1; ++i) convect_ts_column(c, i, j, col.data(), col.data() + c.km, 1);
+  for (int n = 3; n <= c.nt; ++n)
+    for (int j = c.js; j <= c.je; ++j)
+      for (int i = 2; i <= c.imt - 1; ++i) convect_apply_cell(c, i, j, n);
+}
+
 // MOBI column kernel on the host: same source as the GPU kernel, libm instead of ocml
 extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uvic_mobi_forcing *F) {
   const uvic_ctx &c = *cp;

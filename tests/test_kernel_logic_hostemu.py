@@ -34,5 +34,11 @@ def test_emulated_kernels_equal_oracle(cfg, dims, nchunk, nth):
     assert np.array_equal(em.a["adv_vntiso"][:imt - 1], orc.a["adv_vntiso"][:imt - 1])
     tp = orc.transport()
     em.transport(nchunk=nchunk, nthreads=nth)
+    before = em.a["t_taup1"].copy(order="F")
     em.convect()
     assert np.array_equal(em.a["t_taup1"][:, :, 1:jmt - 1], tp[:, :, 1:jmt - 1])
+    # the two-pass convection used on the GPU (segments from T,S, replay per tracer)
+    em.a["t_taup1"][...] = before
+    em.convect(twopass=True)
+    assert np.array_equal(em.a["t_taup1"][:, :, 1:jmt - 1], tp[:, :, 1:jmt - 1])
+    assert (em.a["cv_nseg"] > 0).any() or cfg == "c30"

@@ -579,5 +579,128 @@ UVIC_DEV void convect_column(const uvic_ctx &c, int i, int j) {
 #undef DENS
 }
 
+// ===========================================================================
+// convct2 split in two (same arithmetic, same order as convect_column above):
+//   convect_ts_column : one thread per column walks T and S (staged in a small
+//                       per-thread scratch, LDS on the GPU), mixes them and records
+//                       every mixed segment (kt, kb, total thickness zsm) in order;
+//   convect_apply_cell: one thread per (column, tracer n >= 3) replays the segments
+//                       (tsm = sum_{k=kt..kb} t*dztxcl in that order, / zsm).
+// The mixing ranges depend on T and S only (convect.F:189-255), the other tracers
+// are mixed over them afterwards (:257-271), so the replay is exact and exposes
+// nt-2 times more parallelism; most columns have no unstable segment at all.
+// ===========================================================================
+UVIC_DEV void convect_ts_column(const uvic_ctx &c, int i, int j, double *colT, double *colS, int stride) {
+  UV_DIMS(c);
+  double *ts = c.t_taup1;
+#define DENS(tq, sq, k) eos_dens(c.c, km, tq, sq, k)
+#define CT(k) colT[(size_t)((k)-1) * stride]
+#define CS(k) colS[(size_t)((k)-1) * stride]
+  const double *to = c.to, *so = c.so, *dz = c.dztxcl;
+  const int kbo = c.kmt[X2(i, j)];
+  for (int k = 1; k <= km; ++k) {
+    CT(k) = ts[X3(i, k, j)];
+    CS(k) = ts[X3(i, k, j) + N3];
+  }
+  int nseg = 0;
+  int kt = 1, kb = 2;
+  while (kt < kbo) {
+    double ru = DENS(CT(kt) - to[kb - 1], CS(kt) - so[kb - 1], kb);
+    double rl = DENS(CT(kb) - to[kb - 1], CS(kb) - so[kb - 1], kb);
+    if (ru > rl) {
+      bool chk_la = true, chk_lb = true;
+      double zsm = dz[kt - 1] + dz[kb - 1];
+      double tsm1 = CT(kt) * dz[kt - 1] + CT(kb) * dz[kb - 1];
+      double tmx1 = tsm1 / zsm;
+      double tsm2 = CS(kt) * dz[kt - 1] + CS(kb) * dz[kb - 1];
+      double tmx2 = tsm2 / zsm;
+      while (chk_lb || chk_la) {
+        if (kb >= kbo) chk_lb = false;
+        while (chk_lb) {
+          chk_lb = false;
+          const int lb = kb + 1;
+          ru = DENS(tmx1 - to[lb - 1], tmx2 - so[lb - 1], lb);
+          rl = DENS(CT(lb) - to[lb - 1], CS(lb) - so[lb - 1], lb);
+          if (ru > rl) {
+            kb = lb;
+            zsm = zsm + dz[kb - 1];
+            tsm1 = tsm1 + CT(kb) * dz[kb - 1];
+            tmx1 = tsm1 / zsm;
+            tsm2 = tsm2 + CS(kb) * dz[kb - 1];
+            tmx2 = tsm2 / zsm;
+            chk_la = true;
+            if (kb < kbo) chk_lb = true;
+          }
+        }
+        chk_la = true;
+        if (kt <= 1) chk_la = false;
+        while (chk_la) {
+          chk_la = false;
+          const int la = kt - 1;
+          ru = DENS(CT(la) - to[kt - 1], CS(la) - so[kt - 1], kt);
+          rl = DENS(tmx1 - to[kt - 1], tmx2 - so[kt - 1], kt);
+          if (ru > rl) {
+            kt = la;
+            zsm = zsm + dz[kt - 1];
+            tsm1 = tsm1 + CT(kt) * dz[kt - 1];
+            tmx1 = tsm1 / zsm;
+            tsm2 = tsm2 + CS(kt) * dz[kt - 1];
+            tmx2 = tsm2 / zsm;
+            chk_lb = true;
+          }
+        }
+      }
+      for (int k = kt; k <= kb; ++k) {
+        CT(k) = tmx1;
+        CS(k) = tmx2;
+      }
+      c.cv_kt[X3(i, nseg + 1, j)] = kt;
+      c.cv_kb[X3(i, nseg + 1, j)] = kb;
+      c.cv_z[X3(i, nseg + 1, j)] = zsm;
+      ++nseg;
+      kt = kb + 1;
+    } else {
+      kt = kb;
+    }
+    kb = kt + 1;
+  }
+  c.cv_nseg[X2(i, j)] = nseg;
+  if (nseg > 0) {
+    const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
+    for (int k = 1; k <= km; ++k) {
+      const double a = CT(k), b = CS(k);
+      ts[X3(i, k, j)] = a;
+      ts[X3(i, k, j) + N3] = b;
+      if (ic) {
+        ts[X3(ic, k, j)] = a;
+        ts[X3(ic, k, j) + N3] = b;
+      }
+    }
+  }
+#undef DENS
+#undef CT
+#undef CS
+}
+
+// tracer n (>= 3) of column (i,j): replay the recorded segments, convect.F:263-271
+UVIC_DEV void convect_apply_cell(const uvic_ctx &c, int i, int j, int n) {
+  UV_DIMS(c);
+  const int nseg = c.cv_nseg[X2(i, j)];
+  if (nseg == 0) return;
+  double *t = c.t_taup1 + (size_t)(n - 1) * N3;
+  const double *dz = c.dztxcl;
+  for (int s = 1; s <= nseg; ++s) {
+    const int kt = c.cv_kt[X3(i, s, j)], kb = c.cv_kb[X3(i, s, j)];
+    const double zsm = c.cv_z[X3(i, s, j)];
+    double tsm3 = 0.0;
+    for (int k = kt; k <= kb; ++k) tsm3 = tsm3 + t[X3(i, k, j)] * dz[k - 1];
+    const double tmx3 = tsm3 / zsm;
+    for (int k = kt; k <= kb; ++k) t[X3(i, k, j)] = tmx3;
+  }
+  const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
+  if (ic)
+    for (int k = 1; k <= km; ++k) t[X3(ic, k, j)] = t[X3(i, k, j)];
+}
+
 }  // namespace uvic
 #endif

@@ -50,6 +50,10 @@ typedef struct uvic_ctx {
   double *tot_b;                                                  /* (imt,km+1,jmt) */
   double *adv_x, *adv_z;                                          /* ADV_Tx, ADV_Tz (imt,km,jmt,nt) */
   double *RpY, *RmY;                                              /* y-limiter ratios (imt,km,jmt,nt) */
+  /* convection: mixed segments found from T,S by convect_ts_column, applied to the other
+   * tracers by convect_apply_cell.  cv_nseg (imt,jmt); cv_kt, cv_kb, cv_z (imt,km,jmt) */
+  int *cv_nseg, *cv_kt, *cv_kb;
+  double *cv_z;
   /* tracer-index shard handled by this context: global tracers n0+1 .. n0+nt_local */
   int n0, nt_local;
   /* latitude slab handled by this context (rows js..je are computed) */

@@ -119,6 +119,22 @@ __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
   convect_column(c, i, j);
 }
+// convection in two passes (kernels_fct.hpp): T,S walk with the column staged in LDS, then replay
+__global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
+  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
+}
+__global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(gid % c.imt) + 1;
+  const int j = (int)((gid / c.imt) % c.jmt) + 1;
+  const int n = (int)(gid / ((long long)c.imt * c.jmt)) + 3;
+  if (n > c.nt || j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  convect_apply_cell(c, i, j, n);
+}
 __global__ void __launch_bounds__(128) k_mobi_co2(const uvic_ctx c, const mobi_dev m) {
   CELL_DECODE(c);
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
@@ -202,6 +218,9 @@ struct uvic_gpu {
   hipStream_t stream;
   void *buf[UVIC_F_COUNT];
   double *work[8];  // tot_e, tot_n, tot_b, adv_x (also S of the column path), adv_z, RpY, RmY
+  int *cv_int[3];   // convection segments: nseg, kt, kb
+  double *cv_z;
+  bool exact_convect;  // single-kernel convct2 (debug: UVIC_CONVECT_ONEPASS=1)
   double *coef;     // folded isopycnal coefficients, CF_COUNT planes (kernels_col.hpp)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
   uvic_ctx ctx;
@@ -308,6 +327,18 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
     HIPCHK(hipMalloc((void **)&h->work[w], wsz[w] * 8));
     HIPCHK(hipMemset(h->work[w], 0, wsz[w] * 8));
   }
+  {
+    const size_t NS = (size_t)dims->imt * dims->jmt;
+    const size_t isz[3] = {NS, N3, N3};
+    for (int q = 0; q < 3; ++q) {
+      HIPCHK(hipMalloc((void **)&h->cv_int[q], isz[q] * 4));
+      HIPCHK(hipMemset(h->cv_int[q], 0, isz[q] * 4));
+    }
+    HIPCHK(hipMalloc((void **)&h->cv_z, N3 * 8));
+    HIPCHK(hipMemset(h->cv_z, 0, N3 * 8));
+    h->exact_convect = false;
+    if (const char *e = getenv("UVIC_CONVECT_ONEPASS")) h->exact_convect = atoi(e) != 0;
+  }
   HIPCHK(hipMalloc((void **)&h->coef, N3 * 8 * CF_COUNT));
   HIPCHK(hipMemset(h->coef, 0, N3 * 8 * CF_COUNT));
   h->exact = false;
@@ -318,6 +349,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipMemset(tmask, 0, N3 * 8));
   memset(&h->ctx, 0, sizeof h->ctx);
   h->ctx.tmask = tmask;
+  h->ctx.cv_nseg = h->cv_int[0]; h->ctx.cv_kt = h->cv_int[1]; h->ctx.cv_kb = h->cv_int[2]; h->ctx.cv_z = h->cv_z;
   bind_ctx(h);
   h->ctx.n0 = 0; h->ctx.nt_local = dims->nt; h->ctx.js = 2; h->ctx.je = dims->jmt - 1;
   h->ctx.c2dtts = 0.0; h->ctx.aidif = 0.5;
@@ -358,6 +390,8 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
   (void)hipFree(h->coef);
+  for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
+  (void)hipFree(h->cv_z);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
     (void)hipFree(h->mobi_st.ac13b);
@@ -559,8 +593,18 @@ static int launch_transport(uvic_gpu *h) {
 }
 static int launch_convect(uvic_gpu *h) {
   mark(h, "begin");
-  hipLaunchKernelGGL(k_convect, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx);
-  mark(h, "convect");
+  if (h->exact_convect) {
+    hipLaunchKernelGGL(k_convect, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx);
+    mark(h, "convect");
+  } else {
+    hipLaunchKernelGGL(k_convect_ts, dim3(col_blocks(h, 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx);
+    mark(h, "convect_ts");
+    if (h->d.nt > 2) {
+      const long long n = (long long)h->d.imt * h->d.jmt * (h->d.nt - 2);
+      hipLaunchKernelGGL(k_convect_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx);
+      mark(h, "convect_apply");
+    }
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
