@@ -2,7 +2,7 @@
 # rocprofv3 counter passes for the bench workload (separate passes per counter group,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots"); writes CSVs under gpurun_out/pmc/
 R=$PWD
-mkdir -p $R/gpurun_out/pmc
+rm -rf $R/gpurun_out/pmc; mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
@@ -13,4 +13,3 @@ run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run tcc TCC_HIT_sum TCC_MISS_sum
-ls -R $R/gpurun_out/pmc | head -40

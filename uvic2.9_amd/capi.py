@@ -64,10 +64,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not LIBPATH.exists():
-        raise UvicGpuError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    import os
+    path = Path(os.environ.get("UVIC_GPU_LIB", LIBPATH))   # development override (kernel variants)
+    if not path.exists():
+        raise UvicGpuError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-    lib = ctypes.CDLL(str(LIBPATH))
+    lib = ctypes.CDLL(str(path))
     lib.uvic_gpu_last_error.restype = ctypes.c_char_p
     lib.uvic_gpu_field_elems.restype = ctypes.c_int64
     lib.uvic_gpu_field_elems.argtypes = [ctypes.c_void_p, ctypes.c_int]

@@ -91,8 +91,21 @@ struct ColGrid {
 };
 #define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
 
-__device__ __forceinline__ double shfl_w(double v) { return __shfl_up(v, 1); }    // value of lane-1 (west)
-__device__ __forceinline__ double shfl_e(double v) { return __shfl_down(v, 1); }  // value of lane+1 (east)
+// Neighbour exchange by DPP whole-wave shifts (gfx9 `wave_shr:1` / `wave_shl:1`): one
+// v_mov_b32_dpp per dword at VALU latency instead of an LDS round trip (ds_bpermute) --
+// several of these sit on the dependency chain of every level.  The lane without a
+// source (lane 0 / lane 63) keeps its own value; those lanes are halo.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+#define DPP_WAVE_SHL1 0x130 /* lane i <- lane i+1 */
+#define DPP_WAVE_SHR1 0x138 /* lane i <- lane i-1 */
+__device__ __forceinline__ double shfl_w(double v) { return dpp_d<DPP_WAVE_SHR1>(v); }  // value of lane-1 (west)
+__device__ __forceinline__ double shfl_e(double v) { return dpp_d<DPP_WAVE_SHL1>(v); }  // value of lane+1 (east)
 __device__ __forceinline__ double upstream(double v, double a, double b) { return v * (a + b) + dabs(v) * (a - b); }
 __device__ __forceinline__ double limited(double cpos, double cneg, double f) {
   return 0.5 * ((cpos + cneg) * f + (cpos - cneg) * dabs(f));
@@ -141,7 +154,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
   double *Sn = S + nloc * N3;
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
-  const int kz_w = __shfl_up(kz, 1), kz_e = __shfl_down(kz, 1);
+  const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
   const double cstr_r = c.cstr[r - 1];
   const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
   const double cstdyt2r = c.cstdyt2r[r - 1], cstdytr = c.cstdytr[r - 1];

@@ -314,6 +314,10 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
   const double rn15hi = 2. * UV_RN15STD / (1 + UV_RN15STD), rn15lo = UV_RN15STD / (1 + UV_RN15STD) / 2.;
   const double rc13hi = 2. * UV_RC13STD / (1 + UV_RC13STD), rc13lo = 0.5 * UV_RC13STD / (1 + UV_RC13STD);
 
+  // loop invariants of the sub-step loop (o2 and aou do not change inside it): same values,
+  // evaluated once instead of nbio times
+  const double o2flag = tanh(dmax(o2, 0.));
+  const double aou_term = pow(dmax(aou, 40.), 0.8) / 66.;
   for (int n = 1; n <= S.nbio; ++n) { /* mobi.F:2148-3252 */
     p1 = dmin(biophyt, P->pmax);
     p2 = dmax(0.0, biophyt - P->pmax);
@@ -360,8 +364,7 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
     double expo_phos = wwd * biodetr_phos;
     double remife = nud * bct * biodetrfe;
     /* iron scavenging, mobi.F:2313-2342 */
-    const double o2flag = tanh(dmax(o2, 0.));
-    const double ligand = dmax(pow(dmax(aou, 40.), 0.8) / 66. + pow(biodon, 0.8) / 4.8, 0.5) / 1000.;
+    const double ligand = dmax(aou_term + pow(biodon, 0.8) / 4.8, 0.5) / 1000.;
     const double fepa = (1.0 + P->kfeleq * (ligand - biodfe)) * o2flag;
     const double feprime = ((-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe)) / (2.0 * P->kfeleq)) * o2flag;
     double feorgads = (P->kfeorg * (pow((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
