@@ -7,7 +7,10 @@
 // halos, cyclic wrap, evaluation order) bit-for-bit against the oracle.  The
 // product never loads this library and has no CPU path (uvic2.9_amd/capi.py
 // fails loudly when libuvic_gpu.so or a GPU is missing).
+#include <pthread.h>
+
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../../uvic2.9_amd/csrc/kernels_fct.hpp"
@@ -95,4 +98,76 @@ extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uv
       for (int i = 2; i <= c.imt - 1; ++i) mobi_co2_cell(c, M, i, k, j);
   for (int j = c.js; j <= c.je; ++j)
     for (int i = 2; i <= c.imt - 1; ++i) mobi_column_kernel(c, M, i, j);
+}
+
+
+// ---- MOBI column kernel in TEAM form: four "waves" x 64 lanes per team, real threads and a
+// pthread barrier stand in for the workgroup (state lives in registers across barriers, so the
+// phase-loop emulation of HostEnv does not apply here)
+struct HostTeam {
+  static constexpr bool team = true;
+  int wave, lane;
+  double *xs;
+  unsigned xc;
+  pthread_barrier_t *bar;
+  void sync() { pthread_barrier_wait(bar); }
+};
+
+extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, const uvic_mobi_forcing *F) {
+  const uvic_ctx &c = *cp;
+  mobi_dev M;
+  M.P = P;
+  M.tlat = F->tlat; M.dnswr = F->dnswr; M.aice = F->aice; M.hice = F->hice; M.hsno = F->hsno;
+  M.sg_bathy = F->sg_bathy; M.fe_atmdep = F->fe_atmdep; M.fe_hydr = F->fe_hydr;
+  M.pi = F->pi; M.radian = F->radian; M.relyr = F->relyr; M.co2ccn = F->co2ccn;
+  mobi_step &S = M.S;
+  S.nbio = (int)(c.c2dtts / P->dtnpzd);
+  S.dtbio = c.c2dtts / S.nbio;
+  S.rdtts = 1. / c.c2dtts;
+  S.rnbio = 1. / S.nbio;
+  const double yrtime = fmod(F->relyr, 1.);
+  S.month = 12;
+  for (int m = 1; m <= 12; ++m)
+    if (yrtime <= m / 12.) { S.month = m; break; }
+  S.declin = sin((fmod(F->relyr, 1.) - 0.22) * 2. * F->pi) * 0.4;
+  std::vector<double> ac13b((size_t)c.imt * c.km * c.jmt, 0.0);
+  M.ac13b = ac13b.data();
+  for (int j = c.js; j <= c.je; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) mobi_co2_cell(c, M, i, k, j);
+  const int ncol = c.imt * c.jmt;
+  for (int g0 = 0; g0 < ncol; g0 += 64) {
+    auto decode = [&](int lane, int &i, int &j) {
+      const int gid = g0 + lane;
+      i = gid % c.imt + 1; j = gid / c.imt + 1;
+      return gid < ncol && j >= c.js && j <= c.je && i >= 2 && i <= c.imt - 1;
+    };
+    int kmax = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+      int i, j;
+      if (decode(lane, i, j)) kmax = std::max(kmax, c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)]);
+    }
+    if (kmax == 0) {  // nothing but land: the writers still zero their columns
+      for (int lane = 0; lane < 64; ++lane) {
+        int i, j;
+        if (decode(lane, i, j)) { NoTeam T; mobi_column_body(T, c, M, i, j, true, 0); }
+      }
+      continue;
+    }
+    std::vector<double> xs(UV_MOBI_LDS_DOUBLES, -3.0e33);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, 256);
+    std::vector<std::thread> th;
+    for (int wave = 0; wave < 4; ++wave)
+      for (int lane = 0; lane < 64; ++lane)
+        th.emplace_back([&, wave, lane] {
+          int i, j;
+          const bool live = decode(lane, i, j);
+          if (!live) { i = 2; j = c.js; }
+          HostTeam T{wave, lane, xs.data(), 0u, &bar};
+          mobi_column_body(T, c, M, i, j, live, kmax);
+        });
+    for (auto &t : th) t.join();
+    pthread_barrier_destroy(&bar);
+  }
 }

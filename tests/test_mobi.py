@@ -94,6 +94,10 @@ def test_mobi_kernel_source_under_host_emulation_equals_oracle(dims):
     src_o = mobi_c.mobi_sources(oc, prm, oc.t_taum1, 2 * oc.params.dtts)
     em = emu.EmuOcean(oc, to, so, c)
     assert np.array_equal(em.mobi(prm), src_o)
+    # the four-wave team form (threads + barrier stand in for the workgroup): same bits
+    em.a["src"][...] = -1.0
+    got = em.mobi(prm, team=True)
+    assert np.array_equal(got[1:-1, :, 1:-1], src_o[1:-1, :, 1:-1])   # columns 2..imt-1, rows 2..jmt-1 are computed
 
 
 MOBI_RTOL = 1e-11  # per source slot, relative to the slot max; measured on MI355X: 4.7e-13 (102x102x19), 5.8e-15 (14x14x6)

@@ -236,7 +236,34 @@ UVIC_DEV double clamp_ratio(double r, double hi, double lo) {
   return r;
 }
 
-UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bioin, double gl, double bct, double impo, double dzt, double impo_phos,
+// ---------------------------------------------------------------------------
+// Team execution of the sub-step loop.  One ocean column is a strictly sequential chain of
+// km levels x nbio Euler sub-steps (~2000 fp64 instructions each) and there are only ~7000
+// columns, so a one-thread-per-column kernel is bound by the latency of that chain, not by
+// throughput.  A team of four waves (one per SIMD of a CU) therefore works on the SAME 64
+// columns: inside a sub-step each wave evaluates one independent group of rates
+//   role 0 growth and nutrient limitation, 15N assimilation fractionation
+//   role 1 grazing, mortality, remineralisation, export, 15N recycling fractionation
+//   role 2 iron speciation and scavenging
+//   role 3 isotope ratios (15N, 13C)
+// publishes them in LDS, and after one workgroup barrier every wave applies the identical
+// pool update, so all four hold the same state again.  Every quantity is still computed by
+// the same expression as in the one-thread form (bit-identical results); only wave 0 stores.
+// `NoTeam` runs all roles in one thread (host oracle comparison, single-wave kernel).
+// ---------------------------------------------------------------------------
+#define UV_MOBI_XN 36  /* rates exchanged per column and sub-step */
+#define UV_MOBI_YN 51  /* pools, flags and P:N ratios exchanged per column and sub-step */
+#define UV_MOBI_LDS_DOUBLES ((size_t)2 * (UV_MOBI_XN + UV_MOBI_YN) * 64)
+struct NoTeam {
+  static constexpr bool team = false;
+  int wave = 0, lane = 0;
+  double *xs = nullptr;
+  unsigned xc = 0;
+  UVIC_DEV void sync() const {}
+};
+
+template <class Team>
+UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, double *bioin, double gl, double bct, double impo, double dzt, double impo_phos,
                      double dayfrac, double wwd, double nud, double nudop, double nudon, double *bioout, double bctz,
                      double rn15impo, double rc13impo, double ac13b, double impofe, double o2, double aou,
                      src_out_t *out) {
@@ -319,79 +346,146 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
   const double o2flag = tanh(dmax(o2, 0.));
   const double aou_term = pow(dmax(aou, 40.), 0.8) / 66.;
   for (int n = 1; n <= S.nbio; ++n) { /* mobi.F:2148-3252 */
-    p1 = dmin(biophyt, P->pmax);
-    p2 = dmax(0.0, biophyt - P->pmax);
-    const double k1n = (P->knmin * p1 + P->knmax * p2) / (p1 + p2);
-    const double k1p_P = k1n * ptn_P;
-    kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
-    deffe = biodfe / (kfevar + biodfe);
-    jmax = P->abio_P * bct * deffe;
-    deffe_D = biodfe / (P->kfe_D + biodfe);
-    jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
-    const double limP_dop = P->hdop * biodop / (k1p_P + biodop);
-    const double limP_po4 = biopo4 / (k1p_P + biopo4);
-    const double dopupt_flag = flag01(limP_dop - limP_po4);
-    const double limP = limP_dop * dopupt_flag + limP_po4 * (1. - dopupt_flag);
-    double u_P = dmin(avej, jmax * limP);
-    u_P = dmin(u_P, jmax * biono3 / (k1n + biono3));
-    const double u_D = dmin(avej_D, jmax_D * limP);
-    const double dopupt_D_flag = dopupt_flag;
-    const double thetaZ = P->zprefP * biophyt + P->zprefDet * biodetr + P->zprefZ * biozoop + P->zprefDiaz * biodiaz + P->kzoo;
-    const double ing_P = P->zprefP / thetaZ, ing_Det = P->zprefDet / thetaZ, ing_Z = P->zprefZ / thetaZ;
-    const double ing_D = P->zprefDiaz / thetaZ;
-    double npp = u_P * biophyt;
-    const double dopupt = npp * dopupt_flag; /* NB: from the unflagged npp, mobi.F:2236 */
-    double npp_D = dmax(0., u_D * biodiaz);
-    const double g_D = gmax * ing_D * biodiaz;
-    double graz_D = g_D * biozoop;
-    double morpt_D = nupt_D * biodiaz;
-    double morp_D = P->nup_D * biodiaz * biodiaz;
-    double no3upt_D = (0.5 + 0.5 * tanh(biono3 - 5.)) * npp_D;
-    const double dopupt_D = npp_D * dopupt_D_flag;
-    const double g_P = gmax * ing_P * biophyt;
-    double graz = g_P * biozoop;
-    const double g_Z = gmax * ing_Z * biozoop;
-    double graz_Z = g_Z * biozoop;
-    const double g_Det = gmax * ing_Det * biodetr;
-    double graz_Det = g_Det * biozoop;
-    double morp = P->nup * biophyt;
-    double morpt = nupt * biophyt;
-    double recy_don = nudon * bct * biodon;
-    double recy_dop = nudop * bct * biodop;
-    double morz = P->nuz * biozoop * biozoop;
-    double remi = nud * bct * biodetr;
-    double expo = wwd * biodetr;
-    double expo_phos = wwd * biodetr_phos;
-    double remife = nud * bct * biodetrfe;
-    /* iron scavenging, mobi.F:2313-2342 */
-    const double ligand = dmax(aou_term + pow(biodon, 0.8) / 4.8, 0.5) / 1000.;
-    const double fepa = (1.0 + P->kfeleq * (ligand - biodfe)) * o2flag;
-    const double feprime = ((-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe)) / (2.0 * P->kfeleq)) * o2flag;
-    double feorgads = (P->kfeorg * (pow((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
-    double fecol = P->kfecol * (feprime * feprime) * o2flag;
-    double expofe = wwd * biodetrfe;
-    /* negative prevention, mobi.F:2343-2445 */
-    graz = graz * phytflag * phyt_phosflag * sf_P_phosflag * phytn15flag;
-    graz_Z = graz_Z * zoopflag * zoopn15flag;
-    graz_Det = graz_Det * detrflag * detr_phosflag * sf_detr_phosflag * detrn15flag;
-    morp = morp * phytflag * phyt_phosflag * phytn15flag;
-    morpt = morpt * phytflag * phyt_phosflag * phytn15flag;
-    morz = morz * zoopflag * zoopn15flag;
-    remi = remi * detrflag * detr_phosflag * detrn15flag;
-    expo = expo * detrflag * detrn15flag;
-    expo_phos = expo_phos * detr_phosflag;
-    recy_dop = recy_dop * dopflag;
-    npp = npp * no3flag * (dopupt_flag * dopflag + (1. - dopupt_flag) * po4flag) * din15flag;
-    npp_D = npp_D * (dopupt_D_flag * dopflag + (1. - dopupt_D_flag) * po4flag) * din15flag;
-    graz_D = graz_D * diazflag * diazn15flag;
-    morpt_D = morpt_D * diazflag * diazn15flag;
-    morp_D = morp_D * diazflag * diazn15flag;
-    no3upt_D = no3upt_D * no3flag * din15flag;
-    recy_don = recy_don * donflag * don15flag;
-    remife = remife * detrfeflag;
-    feorgads = feorgads * dfeflag;
-    expofe = expofe * detrfeflag;
-    fecol = fecol * dfeflag;
+#define ROLE(r) (!Team::team || T.wave == (r))
+    // outputs of the four roles
+    double npp = 0., npp_D = 0., no3upt_D = 0., dopupt = 0., dopupt_D = 0., fcassim = 0.;
+    double graz = 0., graz_Z = 0., graz_Det = 0., graz_D = 0., morp = 0., morpt = 0., morz = 0., remi = 0., expo = 0.;
+    double expo_phos = 0., recy_dop = 0., recy_don = 0., morp_D = 0., morpt_D = 0., fcrecy = 0.;
+    double feorgads = 0., fecol = 0., expofe = 0., remife = 0.;
+    double fcexcr = 0., rtphytn15 = 0., rtzoopn15 = 0., rtdetrn15 = 0., rtdiazn15 = 0., fcnpp = 0.;
+    double rtphytc13 = 0., rtzoopc13 = 0., rtdetrc13 = 0., rtdoc13 = 0., rtdiazc13 = 0.;
+    if (ROLE(0)) {  // ---- growth and nutrient limitation (mobi.F:2150-2236), 15N assimilation (:2589-2600)
+      p1 = dmin(biophyt, P->pmax);
+      p2 = dmax(0.0, biophyt - P->pmax);
+      const double k1n = (P->knmin * p1 + P->knmax * p2) / (p1 + p2);
+      const double k1p_P = k1n * ptn_P;
+      kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
+      deffe = biodfe / (kfevar + biodfe);
+      jmax = P->abio_P * bct * deffe;
+      deffe_D = biodfe / (P->kfe_D + biodfe);
+      jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
+      const double limP_dop = P->hdop * biodop / (k1p_P + biodop);
+      const double limP_po4 = biopo4 / (k1p_P + biopo4);
+      const double dopupt_flag = flag01(limP_dop - limP_po4);
+      const double limP = limP_dop * dopupt_flag + limP_po4 * (1. - dopupt_flag);
+      double u_P = dmin(avej, jmax * limP);
+      u_P = dmin(u_P, jmax * biono3 / (k1n + biono3));
+      const double u_D = dmin(avej_D, jmax_D * limP);
+      const double dopupt_D_flag = dopupt_flag;
+      npp = u_P * biophyt;
+      dopupt = npp * dopupt_flag; /* NB: from the unflagged npp, mobi.F:2236 */
+      npp_D = dmax(0., u_D * biodiaz);
+      no3upt_D = (0.5 + 0.5 * tanh(biono3 - 5.)) * npp_D;
+      dopupt_D = npp_D * dopupt_D_flag;
+      npp = npp * no3flag * (dopupt_flag * dopflag + (1. - dopupt_flag) * po4flag) * din15flag;
+      npp_D = npp_D * (dopupt_D_flag * dopflag + (1. - dopupt_D_flag) * po4flag) * din15flag;
+      no3upt_D = no3upt_D * no3flag * din15flag;
+      double uno3 = npp * dtbio / biono3;
+      uno3 = dmin(uno3, 0.999);
+      uno3 = dmax(uno3, UV_TRCMIN);
+      const double rno3 = clamp_ratio(biodin15 / (biono3 - biodin15), 2 * UV_RN15STD, UV_RN15STD / 2.);
+      const double bassim = rayleigh(rno3, P->eps_assim, uno3);
+      fcassim = bassim / (1 + bassim);
+    }
+    if (ROLE(1)) {  // ---- grazing, mortality, remineralisation, export (mobi.F:2223-2312), 15N recycling
+      const double thetaZ = P->zprefP * biophyt + P->zprefDet * biodetr + P->zprefZ * biozoop + P->zprefDiaz * biodiaz + P->kzoo;
+      const double ing_P = P->zprefP / thetaZ, ing_Det = P->zprefDet / thetaZ, ing_Z = P->zprefZ / thetaZ;
+      const double ing_D = P->zprefDiaz / thetaZ;
+      const double g_D = gmax * ing_D * biodiaz;
+      graz_D = g_D * biozoop;
+      morpt_D = nupt_D * biodiaz;
+      morp_D = P->nup_D * biodiaz * biodiaz;
+      const double g_P = gmax * ing_P * biophyt;
+      graz = g_P * biozoop;
+      const double g_Z = gmax * ing_Z * biozoop;
+      graz_Z = g_Z * biozoop;
+      const double g_Det = gmax * ing_Det * biodetr;
+      graz_Det = g_Det * biozoop;
+      morp = P->nup * biophyt;
+      morpt = nupt * biophyt;
+      recy_don = nudon * bct * biodon;
+      recy_dop = nudop * bct * biodop;
+      morz = P->nuz * biozoop * biozoop;
+      remi = nud * bct * biodetr;
+      expo = wwd * biodetr;
+      expo_phos = wwd * biodetr_phos;
+      /* negative prevention, mobi.F:2343-2445 */
+      graz = graz * phytflag * phyt_phosflag * sf_P_phosflag * phytn15flag;
+      graz_Z = graz_Z * zoopflag * zoopn15flag;
+      graz_Det = graz_Det * detrflag * detr_phosflag * sf_detr_phosflag * detrn15flag;
+      morp = morp * phytflag * phyt_phosflag * phytn15flag;
+      morpt = morpt * phytflag * phyt_phosflag * phytn15flag;
+      morz = morz * zoopflag * zoopn15flag;
+      remi = remi * detrflag * detr_phosflag * detrn15flag;
+      expo = expo * detrflag * detrn15flag;
+      expo_phos = expo_phos * detr_phosflag;
+      recy_dop = recy_dop * dopflag;
+      graz_D = graz_D * diazflag * diazn15flag;
+      morpt_D = morpt_D * diazflag * diazn15flag;
+      morp_D = morp_D * diazflag * diazn15flag;
+      recy_don = recy_don * donflag * don15flag;
+      double udon = recy_don * dtbio / biodon;
+      udon = dmin(udon, 0.999);
+      udon = dmax(udon, UV_TRCMIN);
+      const double rdon = clamp_ratio(biodon15 / (biodon - biodon15), 2 * UV_RN15STD, UV_RN15STD / 2.);
+      const double brecy = rayleigh(rdon, P->eps_recy, udon);
+      fcrecy = brecy / (1 + brecy);
+    }
+    if (ROLE(2)) {  // ---- iron speciation and scavenging, mobi.F:2313-2342
+      remife = nud * bct * biodetrfe;
+      const double ligand = dmax(aou_term + pow(biodon, 0.8) / 4.8, 0.5) / 1000.;
+      const double fepa = (1.0 + P->kfeleq * (ligand - biodfe)) * o2flag;
+      const double feprime = ((-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe)) / (2.0 * P->kfeleq)) * o2flag;
+      feorgads = (P->kfeorg * (pow((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
+      fecol = P->kfecol * (feprime * feprime) * o2flag;
+      expofe = wwd * biodetrfe;
+      remife = remife * detrfeflag;
+      feorgads = feorgads * dfeflag;
+      expofe = expofe * detrfeflag;
+      fecol = fecol * dfeflag;
+    }
+    if (ROLE(3)) {  // ---- isotope ratios, mobi.F:2601-2695
+      const double rzoop = clamp_ratio(biozoopn15 / (biozoop - biozoopn15), 2. * UV_RN15STD, UV_RN15STD / 2.);
+      const double bexcr = rzoop - P->eps_excr * rzoop / 1000.;
+      fcexcr = bexcr / (1 + bexcr);
+      rtphytn15 = clamp_ratio(biophytn15 / biophyt, rn15hi, rn15lo);
+      rtzoopn15 = clamp_ratio(biozoopn15 / biozoop, rn15hi, rn15lo);
+      rtdetrn15 = clamp_ratio(biodetrn15 / biodetr, rn15hi, rn15lo);
+      rtdiazn15 = clamp_ratio(biodiazn15 / biodiaz, rn15hi, rn15lo);
+      const double rdic13 = clamp_ratio(biodic13 / (biodic - biodic13), 2. * UV_RC13STD, 0.5 * UV_RC13STD);
+      const double bc13npp = ac13b * rdic13;
+      fcnpp = bc13npp / (1 + bc13npp);
+      rtphytc13 = clamp_ratio(biophytc13 / (biophyt * redctn), rc13hi, rc13lo);
+      rtzoopc13 = clamp_ratio(biozoopc13 / (biozoop * redctn), rc13hi, rc13lo);
+      rtdetrc13 = clamp_ratio(biodetrc13 / (biodetr * redctn), rc13hi, rc13lo);
+      rtdoc13 = clamp_ratio(biodoc13 / (biodon * redctn), rc13hi, rc13lo);
+      rtdiazc13 = clamp_ratio(biodiazc13 / (biodiaz * redctn), rc13hi, rc13lo);
+    }
+    if (Team::team) {  // publish own group, one barrier, fetch the other three
+      double *xb = T.xs + (size_t)(T.xc & 1u) * UV_MOBI_XN * 64 + T.lane;
+      ++T.xc;
+#define XA(X) X(0, npp) X(1, npp_D) X(2, no3upt_D) X(3, dopupt) X(4, dopupt_D) X(5, fcassim)
+#define XB(X) X(6, graz) X(7, graz_Z) X(8, graz_Det) X(9, graz_D) X(10, morp) X(11, morpt) X(12, morz) X(13, remi) \
+  X(14, expo) X(15, expo_phos) X(16, recy_dop) X(17, recy_don) X(18, morp_D) X(19, morpt_D) X(20, fcrecy)
+#define XC(X) X(21, feorgads) X(22, fecol) X(23, expofe) X(24, remife)
+#define XD(X) X(25, fcexcr) X(26, rtphytn15) X(27, rtzoopn15) X(28, rtdetrn15) X(29, rtdiazn15) X(30, fcnpp) \
+  X(31, rtphytc13) X(32, rtzoopc13) X(33, rtdetrc13) X(34, rtdoc13) X(35, rtdiazc13)
+#define XPUT(sl, v) xb[(size_t)(sl) * 64] = v;
+#define XGET(sl, v) v = xb[(size_t)(sl) * 64];
+      if (T.wave == 0) { XA(XPUT) } else if (T.wave == 1) { XB(XPUT) } else if (T.wave == 2) { XC(XPUT) } else { XD(XPUT) }
+      T.sync();
+      if (T.wave != 0) { XA(XGET) }
+      if (T.wave != 1) { XB(XGET) }
+      if (T.wave != 2) { XC(XGET) }
+      if (T.wave != 3) { XD(XGET) }
+#undef XA
+#undef XB
+#undef XC
+#undef XD
+#undef XPUT
+#undef XGET
+    }
+#undef ROLE
     /* zooplankton budget, mobi.F:2446-2530 */
     const double dig_P = gamma1 * graz, dig_Z = gamma1 * graz_Z, dig_Det = gamma1 * graz_Det;
     double dig = dig_Z + dig_P + dig_Det;
@@ -411,106 +505,86 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
     const double sf_D = (1 - gamma1) * graz_D * rnd;
     sf = sf + sf_D;
     sf_phos = sf_phos + sf_D * redptn;
-    /* nitrogen-15 fractionation, mobi.F:2589-2650 */
-    double uno3 = npp * dtbio / biono3;
-    uno3 = dmin(uno3, 0.999);
-    uno3 = dmax(uno3, UV_TRCMIN);
-    double rno3 = clamp_ratio(biodin15 / (biono3 - biodin15), 2 * UV_RN15STD, UV_RN15STD / 2.);
-    const double bassim = rayleigh(rno3, P->eps_assim, uno3);
-    const double fcassim = bassim / (1 + bassim);
-    double udon = recy_don * dtbio / biodon;
-    udon = dmin(udon, 0.999);
-    udon = dmax(udon, UV_TRCMIN);
-    const double rdon = clamp_ratio(biodon15 / (biodon - biodon15), 2 * UV_RN15STD, UV_RN15STD / 2.);
-    const double brecy = rayleigh(rdon, P->eps_recy, udon);
-    const double fcrecy = brecy / (1 + brecy);
-    const double rzoop = clamp_ratio(biozoopn15 / (biozoop - biozoopn15), 2. * UV_RN15STD, UV_RN15STD / 2.);
-    const double bexcr = rzoop - P->eps_excr * rzoop / 1000.;
-    const double fcexcr = bexcr / (1 + bexcr);
     const double bnfix = UV_RN15STD - P->eps_nfix * UV_RN15STD / 1000.;
     const double fcnfix = bnfix / (1 + bnfix);
-    const double rtphytn15 = clamp_ratio(biophytn15 / biophyt, rn15hi, rn15lo);
-    const double rtzoopn15 = clamp_ratio(biozoopn15 / biozoop, rn15hi, rn15lo);
-    const double rtdetrn15 = clamp_ratio(biodetrn15 / biodetr, rn15hi, rn15lo);
-    const double rtdiazn15 = clamp_ratio(biodiazn15 / biodiaz, rn15hi, rn15lo);
-    /* carbon-13 fractionation, mobi.F:2651-2695 */
-    const double rdic13 = clamp_ratio(biodic13 / (biodic - biodic13), 2. * UV_RC13STD, 0.5 * UV_RC13STD);
-    const double bc13npp = ac13b * rdic13;
-    const double fcnpp = bc13npp / (1 + bc13npp);
-    const double rtphytc13 = clamp_ratio(biophytc13 / (biophyt * redctn), rc13hi, rc13lo);
-    const double rtzoopc13 = clamp_ratio(biozoopc13 / (biozoop * redctn), rc13hi, rc13lo);
-    const double rtdetrc13 = clamp_ratio(biodetrc13 / (biodetr * redctn), rc13hi, rc13lo);
-    const double rtdoc13 = clamp_ratio(biodoc13 / (biodon * redctn), rc13hi, rc13lo);
-    const double rtdiazc13 = clamp_ratio(biodiazc13 / (biodiaz * redctn), rc13hi, rc13lo);
     const double calpro = (morp + morz + (graz + graz_Z) * (1. - gamma1)) * P->capr * redctn * 1.e3;
     /* variable P:C of new production (Galbraith & Martiny 2015), mobi.F:2721-2724 */
     const double GM15ptc = 0.0060 + 0.0069 * biopo4;
     const double GM15ptn = GM15ptc * redctn * 1.e3;
     const double diazptn = P->diazptn, rfeton = P->rfeton;
-    /* prognostic updates, mobi.F:2738-3085; every right-hand side uses the OLD state */
-    const double n_po4 = biopo4 + dtbio * (dopupt * ptn_P - GM15ptn * npp + (1. - dfrt) * morpt * ptn_P +
+    /* prognostic updates, mobi.F:2738-3085; every right-hand side uses the OLD state.  In a team each
+       wave advances the pools it owns (0: nutrients and producers, 1: zooplankton, detritus, iron,
+       2: 15N, 3: 13C), refreshes their flags and publishes both; every wave then holds the full state. */
+#define OWN(r) (!Team::team || T.wave == (r))
+    if (OWN(0)) {
+      const double n_po4 = biopo4 + dtbio * (dopupt * ptn_P - GM15ptn * npp + (1. - dfrt) * morpt * ptn_P +
                                            (1. - pfr) * remi * ptn_detr + diazptn * (morpt_D - (npp_D - dopupt_D)) +
                                            recy_dop + redptn * (excr));
-    const double n_dop = biodop + dtbio * (dfr * morp * ptn_P + dfrt * morpt * ptn_P + pfr * remi * ptn_detr -
+      const double n_dop = biodop + dtbio * (dfr * morp * ptn_P + dfrt * morpt * ptn_P + pfr * remi * ptn_detr -
                                            ptn_P * dopupt - diazptn * dopupt_D - recy_dop);
-    const double n_phyt = biophyt + dtbio * (npp - morp - graz - morpt);
-    const double n_phyt_phos = biophyt_phos + dtbio * (npp * GM15ptn - morp * ptn_P - graz * ptn_P - morpt * ptn_P);
-    const double n_zoop = biozoop + dtbio * (dig - morz - graz_Z - excr);
-    const double n_detr = biodetr + dtbio * ((1. - dfr) * morp + sf + morz - remi - graz_Det - expo + impo + morp_D * rnd);
-    const double n_detr_phos = biodetr_phos + dtbio * ((1. - dfr) * morp * ptn_P + sf_phos + morz * redptn - remi * ptn_detr -
-                                                       graz_Det * ptn_detr - expo_phos + impo_phos + morp_D * rnd * redptn);
-    const double n_dic = biodic + dtbio * redctn * (excr + (1. - pfr) * remi + (1. - dfrt) * morpt - npp + morpt_D - npp_D +
+      const double n_phyt = biophyt + dtbio * (npp - morp - graz - morpt);
+      const double n_phyt_phos = biophyt_phos + dtbio * (npp * GM15ptn - morp * ptn_P - graz * ptn_P - morpt * ptn_P);
+      const double n_dic = biodic + dtbio * redctn * (excr + (1. - pfr) * remi + (1. - dfrt) * morpt - npp + morpt_D - npp_D +
                                                     recy_don + nr_excr_D + nr_excr_P + nr_excr_detr + morp_D * (1. - rnd));
-    const double n_no3 = biono3 + dtbio * (excr + (1. - pfr) * remi + (1. - dfrt) * morpt - npp + morpt_D - no3upt_D +
+      const double n_no3 = biono3 + dtbio * (excr + (1. - pfr) * remi + (1. - dfrt) * morpt - npp + morpt_D - no3upt_D +
                                            recy_don + nr_excr_D + nr_excr_P + nr_excr_detr + morp_D * (1. - rnd));
-    const double n_don = biodon + dtbio * (dfr * morp + dfrt * morpt + pfr * remi - recy_don);
-    const double n_diaz = biodiaz + dtbio * (npp_D - morp_D - morpt_D - graz_D);
-    /* the P:N ratios are refreshed HERE, from the new phyt/detr (mobi.F:2846-2849), and the
-       remaining updates still use the old pools but see no ptn_* */
-    const double n_dfe = biodfe + dtbio * (rfeton * (excr + (1. - dfrt) * morpt - npp + morpt_D - npp_D + recy_don +
+      const double n_don = biodon + dtbio * (dfr * morp + dfrt * morpt + pfr * remi - recy_don);
+      const double n_diaz = biodiaz + dtbio * (npp_D - morp_D - morpt_D - graz_D);
+      biopo4 = n_po4; biodop = n_dop; biophyt = n_phyt; biophyt_phos = n_phyt_phos; biodic = n_dic; biono3 = n_no3;
+      biodon = n_don; biodiaz = n_diaz;
+    }
+    if (OWN(1)) {
+      const double n_zoop = biozoop + dtbio * (dig - morz - graz_Z - excr);
+      const double n_detr = biodetr + dtbio * ((1. - dfr) * morp + sf + morz - remi - graz_Det - expo + impo + morp_D * rnd);
+      const double n_detr_phos = biodetr_phos + dtbio * ((1. - dfr) * morp * ptn_P + sf_phos + morz * redptn - remi * ptn_detr -
+                                                       graz_Det * ptn_detr - expo_phos + impo_phos + morp_D * rnd * redptn);
+      const double n_dfe = biodfe + dtbio * (rfeton * (excr + (1. - dfrt) * morpt - npp + morpt_D - npp_D + recy_don +
                                                      nr_excr_D + nr_excr_P + nr_excr_detr + morp_D * (1. - rnd)) -
                                            feorgads + remife - fecol);
-    const double n_detrfe = biodetrfe + dtbio * (rfeton * (sf + (1. - dfr) * morp + morp_D * rnd + morz - graz_Det) +
+      const double n_detrfe = biodetrfe + dtbio * (rfeton * (sf + (1. - dfr) * morp + morp_D * rnd + morz - graz_Det) +
                                                  feorgads + P->iscr * fecol - remife - expofe + impofe);
-    const double n_din15 =
+      biozoop = n_zoop; biodetr = n_detr; biodetr_phos = n_detr_phos; biodfe = n_dfe; biodetrfe = n_detrfe;
+    }
+    if (OWN(2)) {
+      const double n_din15 =
         biodin15 + dtbio * (rtphytn15 * (1. - dfrt) * morpt + rtphytn15 * nr_excr_P + fcexcr * excr + rtdiazn15 * morpt_D +
                             rtdiazn15 * nr_excr_D + rtdiazn15 * morp_D * (1. - rnd) + rtdetrn15 * (1. - pfr) * remi +
                             rtdetrn15 * nr_excr_detr + fcrecy * recy_don - fcassim * npp - fcassim * no3upt_D);
-    const double n_don15 =
+      const double n_don15 =
         biodon15 + dtbio * (dfr * rtphytn15 * morp + dfrt * rtphytn15 * morpt + rtdetrn15 * pfr * remi - fcrecy * recy_don);
-    const double n_phytn15 = biophytn15 + dtbio * (fcassim * npp - rtphytn15 * morp - rtphytn15 * graz - rtphytn15 * morpt);
-    const double n_zoopn15 = biozoopn15 + dtbio * (rtphytn15 * dig_P + rtzoopn15 * dig_Z + rtdetrn15 * dig_Det +
+      const double n_phytn15 = biophytn15 + dtbio * (fcassim * npp - rtphytn15 * morp - rtphytn15 * graz - rtphytn15 * morpt);
+      const double n_zoopn15 = biozoopn15 + dtbio * (rtphytn15 * dig_P + rtzoopn15 * dig_Z + rtdetrn15 * dig_Det +
                                                    rtdiazn15 * dig_D - rtzoopn15 * morz - rtzoopn15 * graz_Z - fcexcr * excr);
-    const double n_detrn15 =
+      const double n_detrn15 =
         biodetrn15 + dtbio * (rtphytn15 * (1. - dfr) * morp + rtphytn15 * sf_P + rtzoopn15 * sf_Z + rtdetrn15 * sf_Det +
                               rtdiazn15 * sf_D + rtzoopn15 * morz - rtdetrn15 * remi - rtdetrn15 * graz_Det -
                               rtdetrn15 * expo + rn15impo * impo + rtdiazn15 * morp_D * rnd);
-    const double n_diazn15 = biodiazn15 + dtbio * (fcnfix * (npp_D - no3upt_D) + fcassim * no3upt_D - rtdiazn15 * morp_D -
+      const double n_diazn15 = biodiazn15 + dtbio * (fcnfix * (npp_D - no3upt_D) + fcassim * no3upt_D - rtdiazn15 * morp_D -
                                                    rtdiazn15 * graz_D - rtdiazn15 * morpt_D);
-    const double n_dic13 =
+      biodin15 = n_din15; biodon15 = n_don15; biophytn15 = n_phytn15; biozoopn15 = n_zoopn15; biodetrn15 = n_detrn15;
+      biodiazn15 = n_diazn15;
+    }
+    if (OWN(3)) {
+      const double n_dic13 =
         biodic13 + dtbio * redctn * (rtphytc13 * (1. - dfrt) * morpt + rtphytc13 * nr_excr_P + rtzoopc13 * excr +
                                      rtdiazc13 * morpt_D + rtdiazc13 * nr_excr_D + rtdiazc13 * morp_D * (1 - rnd) +
                                      rtdetrc13 * (1. - pfr) * remi + rtdetrc13 * nr_excr_detr + rtdoc13 * recy_don -
                                      fcnpp * npp - fcnpp * npp_D);
-    const double n_doc13 = biodoc13 + dtbio * redctn * (dfr * rtphytc13 * morp + rtphytc13 * dfrt * morpt +
+      const double n_doc13 = biodoc13 + dtbio * redctn * (dfr * rtphytc13 * morp + rtphytc13 * dfrt * morpt +
                                                         rtdetrc13 * pfr * remi - rtdoc13 * recy_don);
-    const double n_phytc13 =
+      const double n_phytc13 =
         biophytc13 + dtbio * redctn * (fcnpp * npp - rtphytc13 * morp - rtphytc13 * graz - rtphytc13 * morpt);
-    const double n_zoopc13 =
+      const double n_zoopc13 =
         biozoopc13 + dtbio * redctn * (rtphytc13 * dig_P + rtzoopc13 * dig_Z + rtdetrc13 * dig_Det + rtdiazc13 * dig_D -
                                        rtzoopc13 * morz - rtzoopc13 * graz_Z - rtzoopc13 * excr);
-    const double n_detrc13 =
+      const double n_detrc13 =
         biodetrc13 + dtbio * redctn * (rtphytc13 * (1. - dfr) * morp + rtphytc13 * sf_P + rtzoopc13 * sf_Z + rtdetrc13 * sf_Det +
                                        rtdiazc13 * sf_D + rtzoopc13 * morz - rtdetrc13 * remi - rtdetrc13 * graz_Det -
                                        rtdetrc13 * expo + rc13impo + rtdiazc13 * morp_D * rnd);
-    const double n_diazc13 = biodiazc13 + dtbio * redctn * (fcnpp * npp_D - rtdiazc13 * (morp_D + graz_D + morpt_D));
-    biopo4 = n_po4; biodop = n_dop; biophyt = n_phyt; biophyt_phos = n_phyt_phos; biozoop = n_zoop; biodetr = n_detr;
-    biodetr_phos = n_detr_phos; biodic = n_dic; biono3 = n_no3; biodon = n_don; biodiaz = n_diaz;
-    ptn_P = biophyt_phos / biophyt;
-    ptn_detr = biodetr_phos / biodetr;
-    biodfe = n_dfe; biodetrfe = n_detrfe; biodin15 = n_din15; biodon15 = n_don15; biophytn15 = n_phytn15;
-    biozoopn15 = n_zoopn15; biodetrn15 = n_detrn15; biodiazn15 = n_diazn15; biodic13 = n_dic13; biodoc13 = n_doc13;
-    biophytc13 = n_phytc13; biozoopc13 = n_zoopc13; biodetrc13 = n_detrc13; biodiazc13 = n_diazc13;
+      const double n_diazc13 = biodiazc13 + dtbio * redctn * (fcnpp * npp_D - rtdiazc13 * (morp_D + graz_D + morpt_D));
+      biodic13 = n_dic13; biodoc13 = n_doc13; biophytc13 = n_phytc13; biozoopc13 = n_zoopc13; biodetrc13 = n_detrc13;
+      biodiazc13 = n_diazc13;
+    }
     /* accumulate, mobi.F:3088-3172 */
     expoout = expoout + expo;
     expo_phosout = expo_phosout + expo_phos;
@@ -520,31 +594,68 @@ UVIC_DEV void mobi_src(const uvic_mobi_params *P, const mobi_step &S, double *bi
     nfixout = nfixout + npp_D - no3upt_D;
     expofeout = expofeout + expofe;
     remifeout = remifeout + remife;
-    /* refresh flags that are still set, mobi.F:3175-3251 */
-    if (po4flag == 1) po4flag = flag01(biopo4 - UV_TRCMIN);
-    if (phytflag == 1) phytflag = flag01(biophyt - UV_TRCMIN);
-    if (zoopflag == 1) zoopflag = flag01(biozoop - UV_TRCMIN);
-    if (detrflag == 1) detrflag = flag01(biodetr - UV_TRCMIN);
-    if (phyt_phosflag == 1) phyt_phosflag = flag01(biophyt_phos - UV_TRCMIN);
-    if (detr_phosflag == 1) detr_phosflag = flag01(biodetr_phos - UV_TRCMIN);
-    if (no3flag == 1) no3flag = flag01(biono3 - UV_TRCMIN);
-    if (dopflag == 1) dopflag = flag01(biodop - UV_TRCMIN);
-    if (donflag == 1) donflag = flag01(biodon - UV_TRCMIN);
-    if (diazflag == 1) diazflag = flag01(biodiaz - UV_TRCMIN);
-    if (din15flag == 1) din15flag = flag01(biodin15 - UV_TRCMIN);
-    if (don15flag == 1) don15flag = flag01(biodon15 - UV_TRCMIN);
-    if (phytn15flag == 1) phytn15flag = flag01(biophytn15 - UV_TRCMIN);
-    if (zoopn15flag == 1) zoopn15flag = flag01(biozoopn15 - UV_TRCMIN);
-    if (detrn15flag == 1) detrn15flag = flag01(biodetrn15 - UV_TRCMIN);
-    if (diazn15flag == 1) diazn15flag = flag01(biodiazn15 - UV_TRCMIN);
-    if (dfeflag == 1) dfeflag = flag01(biodfe - UV_TRCMIN);
-    if (detrfeflag == 1) detrfeflag = flag01(biodetrfe - UV_TRCMIN);
-    if (dic13flag == 1) dic13flag = flag01(biodic13 - UV_TRCMIN);
-    if (phytc13flag == 1) phytc13flag = flag01(biophytc13 - UV_TRCMIN);
-    if (zoopc13flag == 1) zoopc13flag = flag01(biozoopc13 - UV_TRCMIN);
-    if (detrc13flag == 1) detrc13flag = flag01(biodetrc13 - UV_TRCMIN);
-    if (doc13flag == 1) doc13flag = flag01(biodoc13 - UV_TRCMIN);
-    if (diazc13flag == 1) diazc13flag = flag01(biodiazc13 - UV_TRCMIN);
+    /* the P:N ratios are refreshed from the new pools (mobi.F:2846-2849); flags that are still set are
+       refreshed (mobi.F:3175-3251) */
+    if (OWN(0)) {
+      ptn_P = biophyt_phos / biophyt;
+      if (po4flag == 1) po4flag = flag01(biopo4 - UV_TRCMIN);
+      if (phytflag == 1) phytflag = flag01(biophyt - UV_TRCMIN);
+      if (phyt_phosflag == 1) phyt_phosflag = flag01(biophyt_phos - UV_TRCMIN);
+      if (no3flag == 1) no3flag = flag01(biono3 - UV_TRCMIN);
+      if (dopflag == 1) dopflag = flag01(biodop - UV_TRCMIN);
+      if (donflag == 1) donflag = flag01(biodon - UV_TRCMIN);
+      if (diazflag == 1) diazflag = flag01(biodiaz - UV_TRCMIN);
+    }
+    if (OWN(1)) {
+      ptn_detr = biodetr_phos / biodetr;
+      if (zoopflag == 1) zoopflag = flag01(biozoop - UV_TRCMIN);
+      if (detrflag == 1) detrflag = flag01(biodetr - UV_TRCMIN);
+      if (detr_phosflag == 1) detr_phosflag = flag01(biodetr_phos - UV_TRCMIN);
+      if (dfeflag == 1) dfeflag = flag01(biodfe - UV_TRCMIN);
+      if (detrfeflag == 1) detrfeflag = flag01(biodetrfe - UV_TRCMIN);
+    }
+    if (OWN(2)) {
+      if (din15flag == 1) din15flag = flag01(biodin15 - UV_TRCMIN);
+      if (don15flag == 1) don15flag = flag01(biodon15 - UV_TRCMIN);
+      if (phytn15flag == 1) phytn15flag = flag01(biophytn15 - UV_TRCMIN);
+      if (zoopn15flag == 1) zoopn15flag = flag01(biozoopn15 - UV_TRCMIN);
+      if (detrn15flag == 1) detrn15flag = flag01(biodetrn15 - UV_TRCMIN);
+      if (diazn15flag == 1) diazn15flag = flag01(biodiazn15 - UV_TRCMIN);
+    }
+    if (OWN(3)) {
+      if (dic13flag == 1) dic13flag = flag01(biodic13 - UV_TRCMIN);
+      if (phytc13flag == 1) phytc13flag = flag01(biophytc13 - UV_TRCMIN);
+      if (zoopc13flag == 1) zoopc13flag = flag01(biozoopc13 - UV_TRCMIN);
+      if (detrc13flag == 1) detrc13flag = flag01(biodetrc13 - UV_TRCMIN);
+      if (doc13flag == 1) doc13flag = flag01(biodoc13 - UV_TRCMIN);
+      if (diazc13flag == 1) diazc13flag = flag01(biodiazc13 - UV_TRCMIN);
+    }
+    if (Team::team) {  // second exchange: new pools, their flags, the P:N ratios
+      double *yb = T.xs + (size_t)2 * UV_MOBI_XN * 64 + (size_t)((T.xc - 1u) & 1u) * UV_MOBI_YN * 64 + T.lane;
+#define YA(X) X(0, biopo4) X(1, biodop) X(2, biophyt) X(3, biophyt_phos) X(4, biodic) X(5, biono3) X(6, biodon) X(7, biodiaz) \
+  X(8, ptn_P) X(9, po4flag) X(10, phytflag) X(11, phyt_phosflag) X(12, no3flag) X(13, dopflag) X(14, donflag) X(15, diazflag)
+#define YB(X) X(16, biozoop) X(17, biodetr) X(18, biodetr_phos) X(19, biodfe) X(20, biodetrfe) X(21, ptn_detr) \
+  X(22, zoopflag) X(23, detrflag) X(24, detr_phosflag) X(25, dfeflag) X(26, detrfeflag)
+#define YC(X) X(27, biodin15) X(28, biodon15) X(29, biophytn15) X(30, biozoopn15) X(31, biodetrn15) X(32, biodiazn15) \
+  X(33, din15flag) X(34, don15flag) X(35, phytn15flag) X(36, zoopn15flag) X(37, detrn15flag) X(38, diazn15flag)
+#define YD(X) X(39, biodic13) X(40, biodoc13) X(41, biophytc13) X(42, biozoopc13) X(43, biodetrc13) X(44, biodiazc13) \
+  X(45, dic13flag) X(46, phytc13flag) X(47, zoopc13flag) X(48, detrc13flag) X(49, doc13flag) X(50, diazc13flag)
+#define YPUT(sl, v) yb[(size_t)(sl) * 64] = v;
+#define YGET(sl, v) v = yb[(size_t)(sl) * 64];
+      if (T.wave == 0) { YA(YPUT) } else if (T.wave == 1) { YB(YPUT) } else if (T.wave == 2) { YC(YPUT) } else { YD(YPUT) }
+      T.sync();
+      if (T.wave != 0) { YA(YGET) }
+      if (T.wave != 1) { YB(YGET) }
+      if (T.wave != 2) { YC(YGET) }
+      if (T.wave != 3) { YD(YGET) }
+#undef YA
+#undef YB
+#undef YC
+#undef YD
+#undef YPUT
+#undef YGET
+    }
+#undef OWN
   }
   (void)dic13flag; (void)doc13flag; (void)phytc13flag; (void)zoopc13flag; (void)detrc13flag; (void)diazc13flag;
 #define BOUT(m, v) bioout[(m)-1] = (v)-BIN(m)
@@ -591,20 +702,27 @@ UVIC_DEV void mobi_co2_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, 
 // mobi_driver (mobi.F:519-1482) fused with its caller (tracer.F:355-545) for
 // the column (i,j): writes src(i,:,j,:) of every source slot.
 // ---------------------------------------------------------------------------
-UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
+template <class Team>
+UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, int i, int j, bool live, int kmax) {
   UV_DIMS(c);
   const uvic_mobi_params *P = M.P;
   const mobi_step &S = M.S;
   const uvic_mobi_index *Q = &P->is;
-  const int kmx = c.kmt[X2(i, j)];
+  const int kmx = live ? c.kmt[X2(i, j)] : 0;
+  const bool writer = live && T.wave == 0;      // in a team only wave 0 stores
   double *src = const_cast<double *>(c.src);
-#define SRC(k, s) src[X3(i, k, j) + (size_t)((s)-1) * N3]
+  double sink = 0.0;
+  bool store = writer;
+  // every thread of a team walks the same loops (workgroup barriers inside): threads that have
+  // nothing to store (other waves, land, levels below the sea floor) write into `sink`
+#define SRC(k, s) (*(store ? (src + X3(i, k, j) + (size_t)((s)-1) * N3) : &sink))
 #define TM(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
 #define TNC(k, m) dmax(TM(k, P->tracer_of_mobi[(m)-1]), UV_TRCMIN) /* clamped column value */
   if (kmx <= 0) {  // the reference leaves src of land columns at zero (static local, tracer.F:121)
-    for (int s = 1; s <= c.nsrc; ++s)
-      for (int k = 1; k <= km; ++k) SRC(k, s) = 0.0;
-    return;
+    if (writer)
+      for (int s = 1; s <= c.nsrc; ++s)
+        for (int k = 1; k <= km; ++k) SRC(k, s) = 0.0;
+    if (!Team::team) return;
   }
   const size_t ij = X2(i, j);
   const size_t NS = (size_t)imt * jmt;
@@ -622,10 +740,12 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
   double snpzd[MI::count], bioin[MI::count];
   const double redctn = P->redctn;
   const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
-  for (int s = 1; s <= c.nsrc; ++s)
-    for (int k = kmx + 1; k <= km; ++k) SRC(k, s) = 0.0;
+  if (writer && kmx > 0)
+    for (int s = 1; s <= c.nsrc; ++s)
+      for (int k = kmx + 1; k <= km; ++k) SRC(k, s) = 0.0;
 #define SN(m) snpzd[(m)-1]
-  for (int k = 1; k <= kmx; ++k) {
+  for (int k = 1; k <= kmax; ++k) {
+    store = writer && k <= kmx;
     rn15impo = rn15expo;
     const double t_in = TM(k, P->itemp);
     const double o2_in = TM(k, P->io2) * 1000.;
@@ -655,7 +775,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     const double nud = P->nud0 * (0.6 + 0.4 * tanh(0.22 * dmax(o2_in, 0.)));
     _Pragma("unroll") for (int m = 1; m <= MI::count; ++m) bioin[m - 1] = TM(k, P->tracer_of_mobi[m - 1]);
     src_out_t so;
-    mobi_src(P, S, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, P->nudop0, P->nudon0, snpzd, bctz,
+    mobi_src(T, P, S, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, P->nudop0, P->nudon0, snpzd, bctz,
              rn15impo, rc13impo, ac13b, impofe, o2_in, aou_in, &so);
     expo = so.expo; expo_phos = so.expo_phos; rn15expo = so.rn15expo; rc13expo = so.rc13expo; expofe = so.expofe;
     const double nfix_k = so.nfix;
@@ -706,13 +826,13 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     // DIC / alkalinity / 13C bookkeeping, mobi.F:1228-1266
     const double dic_sms = SN(MI::dic);
     const double dprca = rcalpro_k * 1e-3;
-    prca = prca + dprca * dztk;
+    if (k <= kmx) prca = prca + dprca * dztk;   // levels below the sea floor are walked only for the team's barriers
     SRC(k, Q->dic) = SN(MI::dic) - dprca;
     const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
     double rtdic13 = dmax(bioin[MI::dic13 - 1], r13min) / dmax(dic_in, UV_TRCMIN);
     rtdic13 = dmin(rtdic13, 2. * UV_RC13STD / (1 + UV_RC13STD));
     rtdic13 = dmax(rtdic13, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
-    prca13 = prca13 + dprca * dztk * rtdic13;
+    if (k <= kmx) prca13 = prca13 + dprca * dztk * rtdic13;
     SRC(k, Q->dic13) = SRC(k, Q->dic13) - rtdic13 * dprca;
     SRC(k, Q->alk) = -SN(MI::dic) * P->redntc * 1.e-3 - 2. * dprca;
     // second pass of the reference (mobi.F:1302-1365) needs only this level's values: fused here
@@ -742,6 +862,8 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
     expofe = expofe * dztk;
   }
   // calcite dissolution profile (mobi.F:1373-1436), iron inputs (tracer.F:538-545), 14C (tracer.F:853-867)
+  store = writer;
+  if (writer)
   for (int k = 1; k <= kmx; ++k) {
     const double rc = (k < kmx) ? P->rcak[k - 1] : P->rcab[k - 1];
     SRC(k, Q->dic) = SRC(k, Q->dic) + prca * rc;
@@ -757,6 +879,12 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
 #undef SRC
 #undef TM
 #undef TNC
+}
+
+// one thread per column, all roles in the thread
+UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
+  NoTeam T;
+  mobi_column_body(T, c, M, i, j, true, c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)]);
 }
 
 }  // namespace uvic

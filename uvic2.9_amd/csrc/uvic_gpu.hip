@@ -140,6 +140,27 @@ __global__ void __launch_bounds__(128) k_mobi_co2(const uvic_ctx c, const mobi_d
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
   mobi_co2_cell(c, m, i, k, j);
 }
+// team form: four waves (one per SIMD of a CU) share 64 columns, see kernels_mobi.hpp
+struct GpuTeam {
+  static constexpr bool team = true;
+  int wave, lane;
+  double *xs;
+  unsigned xc;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+__global__ void __launch_bounds__(256) k_mobi_team(const uvic_ctx c, const mobi_dev m) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int gid = blockIdx.x * 64 + threadIdx.x;
+  int i = gid % c.imt + 1, j = gid / c.imt + 1;
+  const bool live = j >= c.js && j <= c.je && i >= 2 && i <= c.imt - 1;
+  if (!live) { i = 2; j = c.js; }
+  int kmax = live ? c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)] : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+  __builtin_amdgcn_s_setprio(3);
+  GpuTeam T{(int)threadIdx.y, (int)threadIdx.x, lds, 0u};
+  mobi_column_body(T, c, m, i, j, live, kmax);
+}
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -228,6 +249,7 @@ struct uvic_gpu {
   mobi_store mobi_st;
   bool have_mobi;
   double mobi_dtnpzd;
+  bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
   // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
   hipStream_t side;
   hipEvent_t ev_step_begin, ev_src_next;
@@ -315,6 +337,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_src_next, hipEventDisableTiming));
   h->src_alt = nullptr;
+  h->mobi_team = true;
+  if (const char *e = getenv("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
   h->prefetch_pending = h->src_from_prefetch = h->mixing = false;
   for (int f = 0; f < UVIC_F_COUNT; ++f) {
     const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
@@ -630,7 +654,10 @@ static int launch_mobi(uvic_gpu *h) {
   mark(h, "begin");
   hipLaunchKernelGGL(k_mobi_co2, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi_co2");
-  hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
+  if (h->mobi_team)
+    hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->stream, h->ctx, h->mobi);
+  else
+    hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi");
   HIPCHK(hipGetLastError());
   return 0;
@@ -697,7 +724,10 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_step_begin, 0));
   hipLaunchKernelGGL(k_mobi_co2, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
-  hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
+  if (h->mobi_team)
+    hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->side, c, m);
+  else
+    hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev_src_next, h->side));
   h->prefetch_pending = true;
