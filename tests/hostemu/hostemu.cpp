@@ -91,13 +91,16 @@ extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uv
   for (int m = 1; m <= 12; ++m)
     if (yrtime <= m / 12.) { S.month = m; break; }
   S.declin = sin((fmod(F->relyr, 1.) - 0.22) * 2. * F->pi) * 0.4;
-  std::vector<double> ac13b((size_t)c.imt * c.km * c.jmt, 0.0);
-  M.ac13b = ac13b.data();
+  std::vector<double> work(mobi_work_doubles(c.imt, c.jmt, c.km), 0.0);
+  mobi_set_work(&M, work.data(), c.imt, c.jmt, c.km);
   for (int j = c.js; j <= c.je; ++j)
     for (int k = 1; k <= c.km; ++k)
-      for (int i = 2; i <= c.imt - 1; ++i) mobi_co2_cell(c, M, i, k, j);
+      for (int i = 2; i <= c.imt - 1; ++i) mobi_pre_cell(c, M, i, k, j);
   for (int j = c.js; j <= c.je; ++j)
     for (int i = 2; i <= c.imt - 1; ++i) mobi_column_kernel(c, M, i, j);
+  for (int j = c.js; j <= c.je; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) mobi_post_cell(c, M, i, k, j);
 }
 
 
@@ -130,11 +133,11 @@ extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, con
   for (int m = 1; m <= 12; ++m)
     if (yrtime <= m / 12.) { S.month = m; break; }
   S.declin = sin((fmod(F->relyr, 1.) - 0.22) * 2. * F->pi) * 0.4;
-  std::vector<double> ac13b((size_t)c.imt * c.km * c.jmt, 0.0);
-  M.ac13b = ac13b.data();
+  std::vector<double> work(mobi_work_doubles(c.imt, c.jmt, c.km), 0.0);
+  mobi_set_work(&M, work.data(), c.imt, c.jmt, c.km);
   for (int j = c.js; j <= c.je; ++j)
     for (int k = 1; k <= c.km; ++k)
-      for (int i = 2; i <= c.imt - 1; ++i) mobi_co2_cell(c, M, i, k, j);
+      for (int i = 2; i <= c.imt - 1; ++i) mobi_pre_cell(c, M, i, k, j);
   const int ncol = c.imt * c.jmt;
   for (int g0 = 0; g0 < ncol; g0 += 64) {
     auto decode = [&](int lane, int &i, int &j) {
@@ -147,13 +150,7 @@ extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, con
       int i, j;
       if (decode(lane, i, j)) kmax = std::max(kmax, c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)]);
     }
-    if (kmax == 0) {  // nothing but land: the writers still zero their columns
-      for (int lane = 0; lane < 64; ++lane) {
-        int i, j;
-        if (decode(lane, i, j)) { NoTeam T; mobi_column_body(T, c, M, i, j, true, 0); }
-      }
-      continue;
-    }
+    if (kmax == 0) continue;  // nothing but land
     std::vector<double> xs(UV_MOBI_LDS_DOUBLES, -3.0e33);
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, nullptr, 256);
@@ -170,4 +167,7 @@ extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, con
     for (auto &t : th) t.join();
     pthread_barrier_destroy(&bar);
   }
+  for (int j = c.js; j <= c.je; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) mobi_post_cell(c, M, i, k, j);
 }

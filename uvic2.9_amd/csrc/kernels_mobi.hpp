@@ -40,9 +40,24 @@ struct mobi_dev {
   const uvic_mobi_params *P;   // device copy
   const double *tlat, *dnswr, *aice, *hice, *hsno, *sg_bathy, *fe_atmdep, *fe_hydr;
   double pi, radian, relyr, co2ccn;
-  double *ac13b;               // (imt,km,jmt) carbon-13 fractionation factor of photosynthesis, from mobi_co2_cell
+  // work planes of one MOBI pass (one set per stream that may run it):
+  //   pre  MP_COUNT x (imt,km,jmt)  what mobi_pre_cell hands to the column kernel
+  //   aux  MA_COUNT x (imt,km,jmt)  what the column kernel hands to mobi_post_cell
+  //   col  2 x (imt,jmt)            calcite production of the column (prca, prca13)
+  double *pre, *aux, *col;
   mobi_step S;
 };
+enum { MP_BCT, MP_BCTZ, MP_NUD, MP_AOUT, MP_O2F, MP_AVEJ, MP_AVEJD, MP_AC13B, MP_COUNT };
+enum { MA_EXPO, MA_EXPOP, MA_RN15, MA_RC13, MA_CALPRO, MA_NFIX, MA_COUNT };
+static inline void mobi_set_work(mobi_dev *m, double *w, int imt, int jmt, int km) {
+  const size_t n3 = (size_t)imt * km * jmt;
+  m->pre = w;
+  m->aux = w + MP_COUNT * n3;
+  m->col = w + (MP_COUNT + MA_COUNT) * n3;
+}
+static inline size_t mobi_work_doubles(int imt, int jmt, int km) {
+  return (size_t)(MP_COUNT + MA_COUNT) * imt * km * jmt + (size_t)2 * imt * jmt;
+}
 
 // positions of the MOBI column tracers for option set C, fixed at compile time so that the
 // column vectors live in registers (mobi.F:440-504 assigns them in this order);
@@ -263,10 +278,10 @@ struct NoTeam {
 };
 
 template <class Team>
-UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, double *bioin, double gl, double bct, double impo, double dzt, double impo_phos,
-                     double dayfrac, double wwd, double nud, double nudop, double nudon, double *bioout, double bctz,
-                     double rn15impo, double rc13impo, double ac13b, double impofe, double o2, double aou,
-                     src_out_t *out) {
+UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, double *bioin, double bct, double impo, double impo_phos,
+                     double wwd, double nud, double nudop, double nudon, double *bioout, double bctz,
+                     double rn15impo, double rc13impo, double ac13b, double impofe, double o2flag, double aou_term,
+                     double avej, double avej_D, src_out_t *out) {
 #define BIN(m) bioin[(m)-1]
   double biopo4 = BIN(MI::po4), biophyt = BIN(MI::phyt), biophyt_phos = BIN(MI::phyt_phos), biozoop = BIN(MI::zoop);
   double biodetr = BIN(MI::detr), biodetr_phos = BIN(MI::detr_phos);
@@ -302,35 +317,8 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
   biophytc13 = dmax(biophytc13, UV_TRCMIN); biozoopc13 = dmax(biozoopc13, UV_TRCMIN); biodetrc13 = dmax(biodetrc13, UV_TRCMIN);
   biodoc13 = dmax(biodoc13, UV_TRCMIN); biodiazc13 = dmax(biodiazc13, UV_TRCMIN); biodfe = dmax(biodfe, UV_TRCMIN);
   biodetrfe = dmax(biodetrfe, UV_TRCMIN);
-  /* light-limited growth, Evans & Parslow, with iron-dependent Chl:C, mobi.F:1984-2061 */
-  double p1 = dmin(biophyt, P->pmax);
-  double p2 = dmax(0.0, biophyt - P->pmax);
-  double kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
-  double deffe = biodfe / (kfevar + biodfe);
-  const double thetamax = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe;
-  const double alpha_O = P->alphamin + (P->alphamax - P->alphamin) * deffe;
-  const double gl_O = gl * thetamax * alpha_O;
-  double deffe_D = biodfe / (P->kfe_D + biodfe);
-  const double thetamax_D = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe_D;
-  const double alpha_D = P->alphamin + (P->alphamax - P->alphamin) * deffe_D;
-  const double gl_D = gl * thetamax_D * alpha_D;
-  const double kirr = -P->kw - P->kc * (biophyt + biodiaz);
-  const double f1 = exp(kirr * dzt);
-  double jmax = P->abio_P * bct * deffe;
-  const double gd = jmax * dayfrac;
-  double u1 = dmax(gl_O / gd, 1.e-6);
-  double u2 = u1 * f1;
-  double phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
-  double phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
-  const double avej = gd * (phi1 - phi2) / (-kirr * dzt);
+  /* the light-limited growth rates avej, avej_D (mobi.F:1984-2061) depend on the inputs only: mobi_pre_cell */
   const double gmax = P->gbio * bctz;
-  double jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
-  const double gd_D = dmax(1.e-14, jmax_D * dayfrac);
-  u1 = dmax(gl_D / gd_D, 1.e-6);
-  u2 = u1 * f1;
-  phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
-  phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
-  const double avej_D = gd_D * (phi1 - phi2) / (-kirr * dzt);
   const double nupt = P->nupt0 * bct;
   const double nupt_D = P->nupt0_D * bct;
   double nfixout = 0.0, expoout = 0.0, expo_phosout = 0.0, rn15expoout = 0.0, rc13expoout = 0.0, calproout = 0.0;
@@ -341,10 +329,6 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
   const double rn15hi = 2. * UV_RN15STD / (1 + UV_RN15STD), rn15lo = UV_RN15STD / (1 + UV_RN15STD) / 2.;
   const double rc13hi = 2. * UV_RC13STD / (1 + UV_RC13STD), rc13lo = 0.5 * UV_RC13STD / (1 + UV_RC13STD);
 
-  // loop invariants of the sub-step loop (o2 and aou do not change inside it): same values,
-  // evaluated once instead of nbio times
-  const double o2flag = tanh(dmax(o2, 0.));
-  const double aou_term = pow(dmax(aou, 40.), 0.8) / 66.;
   for (int n = 1; n <= S.nbio; ++n) { /* mobi.F:2148-3252 */
 #define ROLE(r) (!Team::team || T.wave == (r))
     // outputs of the four roles
@@ -355,15 +339,15 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
     double fcexcr = 0., rtphytn15 = 0., rtzoopn15 = 0., rtdetrn15 = 0., rtdiazn15 = 0., fcnpp = 0.;
     double rtphytc13 = 0., rtzoopc13 = 0., rtdetrc13 = 0., rtdoc13 = 0., rtdiazc13 = 0.;
     if (ROLE(0)) {  // ---- growth and nutrient limitation (mobi.F:2150-2236), 15N assimilation (:2589-2600)
-      p1 = dmin(biophyt, P->pmax);
-      p2 = dmax(0.0, biophyt - P->pmax);
+      const double p1 = dmin(biophyt, P->pmax);
+      const double p2 = dmax(0.0, biophyt - P->pmax);
       const double k1n = (P->knmin * p1 + P->knmax * p2) / (p1 + p2);
       const double k1p_P = k1n * ptn_P;
-      kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
-      deffe = biodfe / (kfevar + biodfe);
-      jmax = P->abio_P * bct * deffe;
-      deffe_D = biodfe / (P->kfe_D + biodfe);
-      jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
+      const double kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
+      const double deffe = biodfe / (kfevar + biodfe);
+      const double jmax = P->abio_P * bct * deffe;
+      const double deffe_D = biodfe / (P->kfe_D + biodfe);
+      const double jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
       const double limP_dop = P->hdop * biodop / (k1p_P + biodop);
       const double limP_po4 = biopo4 / (k1p_P + biopo4);
       const double dopupt_flag = flag01(limP_dop - limP_po4);
@@ -674,58 +658,49 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
 
 
 // ---------------------------------------------------------------------------
-// carbonate chemistry of one cell (co2calc_SWS, called at mobi.F:772 for every level of
-// every column): it depends on T, S, DIC and alkalinity of the cell only, not on the
-// vertical sequence of mobi_driver, so it runs cell-parallel ahead of the column kernel.
-// Of its outputs option set C uses only CO2* through the 13C fractionation factor
-// ac13b = ac13_aq_POC / ac13_DIC_aq (mobi.F:775-789).  One thread per cell.
+// MOBI runs in three passes.  mobi_driver walks a column top-down because the export of
+// level k is the import of level k+1, but most of what it evaluates per level depends only
+// on the level's own inputs at tau-1 (or on the light that reaches it, a function of the
+// inputs above).  Only the nbio Euler sub-steps and the hand-down of the export are a true
+// vertical sequence, so
+//   mobi_pre_cell    one thread per cell: carbonate chemistry, light, temperature and oxygen
+//                    functions, light-limited growth rates            -> `pre` planes
+//   mobi_column_body one thread (or team of waves) per column: the sub-steps -> src, `aux`, `col`
+//   mobi_post_cell   one thread per cell: benthic and water-column denitrification, sedimentary
+//                    iron, bottom remineralisation, DIC/alkalinity/13C/14C bookkeeping -> src
+// Every quantity keeps the reference's expression and operation order.
 // ---------------------------------------------------------------------------
-UVIC_DEV void mobi_co2_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
-  UV_DIMS(c);
-  const uvic_mobi_params *P = M.P;
-  if (k > c.kmt[X2(i, j)]) return;
+#define UV_MOBI_LOCALS(c, M)                                   \
+  UV_DIMS(c);                                                  \
+  const uvic_mobi_params *P = M.P;                             \
+  const mobi_step &S = M.S;                                    \
+  const uvic_mobi_index *Q = &P->is;                           \
+  const size_t ij = X2(i, j), NS = (size_t)imt * jmt;          \
+  (void)S; (void)Q; (void)ij; (void)NS
 #define TM(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
+#define TNC(k, m) dmax(TM(k, P->tracer_of_mobi[(m)-1]), UV_TRCMIN) /* clamped column value, mobi.F:1894 */
+#define PRE(q) M.pre[(size_t)(q) * N3 + X3(i, k, j)]
+#define AUX(q) M.aux[(size_t)(q) * N3 + X3(i, k, j)]
+
+// co2calc_SWS (called at mobi.F:772 for every level) needs T, S, DIC and alkalinity of the
+// cell only; of its outputs option set C uses CO2* through the 13C fractionation factor
+// ac13b = ac13_aq_POC / ac13_DIC_aq (mobi.F:775-789).  Light: tracer.F:381-390, mobi.F:735-760.
+UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
+  UV_MOBI_LOCALS(c, M);
+  if (k > c.kmt[ij]) return;
   const double t_in = TM(k, P->itemp);
   const double s_in = 1.e3 * TM(k, P->isalt) + 35.0;
   const double dic_in = TM(k, P->idic), alk_in = TM(k, P->ialk);
-#undef TM
-  const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
-  double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
-  mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3,
-                   &Omega_c, &Omega_a);
-  const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
-  const double ac13_aq_POC = -0.017 * log10(dmin(dmax(co2star * 1000., 2.), 74.)) + 1.0034;
-  M.ac13b[X3(i, k, j)] = ac13_aq_POC / ac13_DIC_aq;
-}
-
-// ---------------------------------------------------------------------------
-// mobi_driver (mobi.F:519-1482) fused with its caller (tracer.F:355-545) for
-// the column (i,j): writes src(i,:,j,:) of every source slot.
-// ---------------------------------------------------------------------------
-template <class Team>
-UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, int i, int j, bool live, int kmax) {
-  UV_DIMS(c);
-  const uvic_mobi_params *P = M.P;
-  const mobi_step &S = M.S;
-  const uvic_mobi_index *Q = &P->is;
-  const int kmx = live ? c.kmt[X2(i, j)] : 0;
-  const bool writer = live && T.wave == 0;      // in a team only wave 0 stores
-  double *src = const_cast<double *>(c.src);
-  double sink = 0.0;
-  bool store = writer;
-  // every thread of a team walks the same loops (workgroup barriers inside): threads that have
-  // nothing to store (other waves, land, levels below the sea floor) write into `sink`
-#define SRC(k, s) (*(store ? (src + X3(i, k, j) + (size_t)((s)-1) * N3) : &sink))
-#define TM(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
-#define TNC(k, m) dmax(TM(k, P->tracer_of_mobi[(m)-1]), UV_TRCMIN) /* clamped column value */
-  if (kmx <= 0) {  // the reference leaves src of land columns at zero (static local, tracer.F:121)
-    if (writer)
-      for (int s = 1; s <= c.nsrc; ++s)
-        for (int k = 1; k <= km; ++k) SRC(k, s) = 0.0;
-    if (!Team::team) return;
+  const double o2_in = TM(k, P->io2) * 1000.;
+  {
+    const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
+    double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
+    mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3,
+                     &Omega_c, &Omega_a);
+    const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
+    const double ac13_aq_POC = -0.017 * log10(dmin(dmax(co2star * 1000., 2.), 74.)) + 1.0034;
+    PRE(MP_AC13B) = ac13_aq_POC / ac13_DIC_aq;
   }
-  const size_t ij = X2(i, j);
-  const size_t NS = (size_t)imt * jmt;
   // light geometry, tracer.F:381-390
   const double ai = M.aice[ij], hi = M.hice[ij], hs = M.hsno[ij];
   double rctheta = dmax(-1.5, dmin(1.5, M.tlat[ij] / M.radian - S.declin));
@@ -733,52 +708,94 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
   double dayfrac = dmin(1., -tan(M.tlat[ij] / M.radian) * tan(S.declin));
   dayfrac = dmax(1e-12, acos(dmax(-1., dayfrac)) / M.pi);
   double swr = P->tap * M.dnswr[ij] * 1e-3 * (1. + ai * (exp(-P->ki * (hi + hs)) - 1.));
-  const double twodt = c.c2dtts;
+  // attenuation by the phytoplankton above, the same running product as mobi.F:735-740
+  double phin = 0.0;
+  for (int m = 1; m <= k; ++m) {
+    swr = swr * exp(-P->kc * phin);
+    phin = TNC(m, MI::phyt) * P->dzt[m - 1] + TNC(m, MI::diaz) * P->dzt[m - 1];
+  }
+  const double gl = swr * exp(P->ztt[k - 1] * rctheta);
+  // oxygen saturation -> apparent oxygen utilisation, tracer.F:456-476
+  double aou_in;
+  {
+    const double f1 = log((298.15 - t_in) / (273.15 + t_in));
+    const double f2 = f1 * f1, f3 = f2 * f1, f4 = f3 * f1, f5 = f4 * f1;
+    double o2sat = exp(2.00907 + 3.22014 * f1 + 4.05010 * f2 + 4.94457 * f3 - 2.56847E-1 * f4 + 3.88767 * f5 +
+                       s_in * (-6.24523e-3 - 7.37614e-3 * f1 - 1.03410e-2 * f2 - 8.17083E-3 * f3) - 4.88682E-7 * s_in * s_in);
+    o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
+    aou_in = o2sat - o2_in;
+  }
+  const double bct = pow(P->bbio, P->cbio * t_in);
+  const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * pow(P->bbio, P->cbio * t_in);
+  PRE(MP_BCT) = bct;
+  PRE(MP_BCTZ) = bctz;
+  PRE(MP_NUD) = P->nud0 * (0.6 + 0.4 * tanh(0.22 * dmax(o2_in, 0.)));
+  PRE(MP_O2F) = tanh(dmax(o2_in, 0.));                 // o2flag, mobi.F:2313
+  PRE(MP_AOUT) = pow(dmax(aou_in, 40.), 0.8) / 66.;    // the AOU term of the ligand concentration, mobi.F:2316
+  /* light-limited growth, Evans & Parslow, with iron-dependent Chl:C, mobi.F:1984-2061 */
+  const double biophyt = TNC(k, MI::phyt), biodiaz = TNC(k, MI::diaz), biodfe = TNC(k, MI::dfe), dzt = P->dzt[k - 1];
+  const double p1 = dmin(biophyt, P->pmax);
+  const double p2 = dmax(0.0, biophyt - P->pmax);
+  const double kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
+  const double deffe = biodfe / (kfevar + biodfe);
+  const double thetamax = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe;
+  const double alpha_O = P->alphamin + (P->alphamax - P->alphamin) * deffe;
+  const double gl_O = gl * thetamax * alpha_O;
+  const double deffe_D = biodfe / (P->kfe_D + biodfe);
+  const double thetamax_D = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe_D;
+  const double alpha_D = P->alphamin + (P->alphamax - P->alphamin) * deffe_D;
+  const double gl_D = gl * thetamax_D * alpha_D;
+  const double kirr = -P->kw - P->kc * (biophyt + biodiaz);
+  const double f1 = exp(kirr * dzt);
+  const double jmax = P->abio_P * bct * deffe;
+  const double gd = jmax * dayfrac;
+  double u1 = dmax(gl_O / gd, 1.e-6);
+  double u2 = u1 * f1;
+  double phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
+  double phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
+  PRE(MP_AVEJ) = gd * (phi1 - phi2) / (-kirr * dzt);
+  const double jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
+  const double gd_D = dmax(1.e-14, jmax_D * dayfrac);
+  u1 = dmax(gl_D / gd_D, 1.e-6);
+  u2 = u1 * f1;
+  phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
+  phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
+  PRE(MP_AVEJD) = gd_D * (phi1 - phi2) / (-kirr * dzt);
+}
 
-  double expo = 0.0, impo, expo_phos = 0.0, impo_phos, phin = 0.0, prca = 0.0;
+// ---------------------------------------------------------------------------
+// the vertical sequence of mobi_driver (mobi.F:519-1482) for the column (i,j): per level the
+// nbio sub-steps of mobi_src, the raw source terms (mobi.F:1149-1205), and the hand-down of
+// the export (mobi.F:1124-1134, 1268-1287).
+// ---------------------------------------------------------------------------
+template <class Team>
+UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, int i, int j, bool live, int kmax) {
+  UV_MOBI_LOCALS(c, M);
+  const int kmx = live ? c.kmt[ij] : 0;
+  const bool writer = live && T.wave == 0;      // in a team only wave 0 stores
+  double *src = const_cast<double *>(c.src);
+  double sink = 0.0;
+  // every thread of a team walks the same loops (workgroup barriers inside): threads that have
+  // nothing to store (other waves, land, levels below the sea floor) write into `sink`
+  double expo = 0.0, impo, expo_phos = 0.0, impo_phos, prca = 0.0;
   double rn15impo, rn15expo = 0.0, rc13impo, rc13expo = 0.0, prca13 = 0.0, expofe = 0.0, impofe;
   double snpzd[MI::count], bioin[MI::count];
-  const double redctn = P->redctn;
-  const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
-  if (writer && kmx > 0)
-    for (int s = 1; s <= c.nsrc; ++s)
-      for (int k = kmx + 1; k <= km; ++k) SRC(k, s) = 0.0;
-#define SN(m) snpzd[(m)-1]
   for (int k = 1; k <= kmax; ++k) {
-    store = writer && k <= kmx;
+    const bool store = writer && k <= kmx;
+#define OUT(ptr) (*(store ? (ptr) : &sink))
     rn15impo = rn15expo;
-    const double t_in = TM(k, P->itemp);
-    const double o2_in = TM(k, P->io2) * 1000.;
-    const double s_in = 1.e3 * TM(k, P->isalt) + 35.0;
-    const double dic_in = TM(k, P->idic), alk_in = TM(k, P->ialk);
+    const double dic_in = TM(k, P->idic);
     const double sgb = M.sg_bathy[ij + NS * (k - 1)];
-    // oxygen saturation -> apparent oxygen utilisation, tracer.F:456-476
-    double aou_in;
-    {
-      const double f1 = log((298.15 - t_in) / (273.15 + t_in));
-      const double f2 = f1 * f1, f3 = f2 * f1, f4 = f3 * f1, f5 = f4 * f1;
-      double o2sat = exp(2.00907 + 3.22014 * f1 + 4.05010 * f2 + 4.94457 * f3 - 2.56847E-1 * f4 + 3.88767 * f5 +
-                         s_in * (-6.24523e-3 - 7.37614e-3 * f1 - 1.03410e-2 * f2 - 8.17083E-3 * f3) - 4.88682E-7 * s_in * s_in);
-      o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
-      aou_in = o2sat - o2_in;
-    }
-    const double ac13b = M.ac13b[X3(i, k, j)];
+    const double dztk = P->dzt[k - 1];
     rc13impo = rc13expo * P->dztr[k - 1];
-    swr = swr * exp(-P->kc * phin);
-    phin = TNC(k, MI::phyt) * P->dzt[k - 1] + TNC(k, MI::diaz) * P->dzt[k - 1];
-    const double gl = swr * exp(P->ztt[k - 1] * rctheta);
     impo = expo * P->dztr[k - 1];
     impo_phos = expo_phos * P->dztr[k - 1];
     impofe = expofe * P->dztr[k - 1];
-    const double bct = pow(P->bbio, P->cbio * t_in);
-    const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * pow(P->bbio, P->cbio * t_in);
-    const double nud = P->nud0 * (0.6 + 0.4 * tanh(0.22 * dmax(o2_in, 0.)));
     _Pragma("unroll") for (int m = 1; m <= MI::count; ++m) bioin[m - 1] = TM(k, P->tracer_of_mobi[m - 1]);
     src_out_t so;
-    mobi_src(T, P, S, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, P->nudop0, P->nudon0, snpzd, bctz,
-             rn15impo, rc13impo, ac13b, impofe, o2_in, aou_in, &so);
+    mobi_src(T, P, S, bioin, PRE(MP_BCT), impo, impo_phos, P->wd[k - 1], PRE(MP_NUD), P->nudop0, P->nudon0, snpzd, PRE(MP_BCTZ),
+             rn15impo, rc13impo, PRE(MP_AC13B), impofe, PRE(MP_O2F), PRE(MP_AOUT), PRE(MP_AVEJ), PRE(MP_AVEJD), &so);
     expo = so.expo; expo_phos = so.expo_phos; rn15expo = so.rn15expo; rc13expo = so.rc13expo; expofe = so.expofe;
-    const double nfix_k = so.nfix;
     _Pragma("unroll") for (int m = 0; m < MI::count; ++m) snpzd[m] = snpzd[m] * S.rdtts;
     expofe = expofe * S.rnbio;
     expo = expo * S.rnbio;
@@ -786,99 +803,36 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     rn15expo = rn15expo * S.rnbio;
     rc13expo = rc13expo * S.rnbio;
     const double rcalpro_k = so.calpro * S.rnbio;
-    // benthic denitrification on the sub-grid bathymetry, mobi.F:1033-1085 (bioin is clamped now)
-    const double tn_no3 = bioin[MI::no3 - 1], tn_din15 = bioin[MI::din15 - 1];
-    const double no3flag = flag01(tn_no3 - UV_TRCMIN);
-    const double din15flag = flag01(tn_din15 - UV_TRCMIN);
-    const double lno3 = 0.5 * tanh(tn_no3 * 10 - 5.0);
-    double sg_bdeni =
-        (0.06 + 0.19 * pow(0.99, dmax(o2_in, UV_TRCMIN) - dmax(tn_no3, UV_TRCMIN))) * dmax(expo * sgb, UV_TRCMIN) * redctn * 1.e3;
-    sg_bdeni = dmin(sg_bdeni, sgb * expo);
-    sg_bdeni = dmax(sg_bdeni, 0.);
-    sg_bdeni = sg_bdeni * (0.5 + lno3) * no3flag * din15flag;
-    SN(MI::no3) = SN(MI::no3) + sgb * expo - sg_bdeni;
-    double rno3 = dmax(tn_din15, r15min) / dmax(tn_no3 - tn_din15, r15min);
-    rno3 = dmin(rno3, 2. * UV_RN15STD);
-    rno3 = dmax(rno3, UV_RN15STD / 2.);
-    const double eps_bdeni = P->eps_bdeni0 * exp(-2.5e-6 * (P->zt[k - 1]));
-    const double bbdeni = rno3 - eps_bdeni * rno3 / 1000.;
-    SN(MI::din15) = SN(MI::din15) + rn15expo * sgb * expo - bbdeni / (1 + bbdeni) * sg_bdeni;
-    // sedimentary iron release, mobi.F:1086-1123
-    const double coxdepth = dmin(dmax(P->zt[k - 1], 50000.), 150000.);
-    const double oblinc = -1.26e-6 * coxdepth + 0.203;
-    const double obexpc = -6.e-7 * coxdepth + 1.14;
-    const double dztk = P->dzt[k - 1];
-    const double nburial = (oblinc * pow(expo * sgb * dztk / 100 * 86400. * 365. * redctn * 1000., obexpc)) /
-                           (86400. * 365. * dztk / 100 * redctn * 1000.);
-    const double coxsed = expo * sgb - nburial;
-    const double fesedmax = 85.;
-    const double fesed = fesedmax * tanh(coxsed * redctn * 1000 * dztk / 100 * 86400. / o2_in) / (dztk / 100 * 86400 * 1000);
-    SN(MI::dfe) = SN(MI::dfe) + fesed;
-    // bottom remineralisation, mobi.F:1124-1134
-    SN(MI::po4) = SN(MI::po4) + sgb * expo_phos;
-    SN(MI::dic) = SN(MI::dic) + sgb * expo * redctn;
-    SN(MI::dic13) = SN(MI::dic13) + rc13expo * sgb * redctn;
-    rc13expo = rc13expo - sgb * rc13expo;
-    expo = expo - sgb * expo;
-    expo_phos = expo_phos - sgb * expo_phos;
-    // scatter, mobi.F:1149-1205: every MOBI tracer owns the source slot of its prognostic tracer
-    _Pragma("unroll") for (int m = 1; m <= MI::count; ++m) SRC(k, P->slot_of_mobi[m - 1]) = snpzd[m - 1];
-    // DIC / alkalinity / 13C bookkeeping, mobi.F:1228-1266
-    const double dic_sms = SN(MI::dic);
+    // raw source terms into the slot of each MOBI tracer (mobi.F:1149-1205) and what the cell pass needs
+    _Pragma("unroll") for (int m = 1; m <= MI::count; ++m)
+      OUT(src + X3(i, k, j) + (size_t)(P->slot_of_mobi[m - 1] - 1) * N3) = snpzd[m - 1];
+    OUT(&AUX(MA_EXPO)) = expo; OUT(&AUX(MA_EXPOP)) = expo_phos; OUT(&AUX(MA_RN15)) = rn15expo; OUT(&AUX(MA_RC13)) = rc13expo;
+    OUT(&AUX(MA_CALPRO)) = rcalpro_k; OUT(&AUX(MA_NFIX)) = so.nfix;
+    // calcite production of the column, mobi.F:1228-1266 (bioin is clamped now)
     const double dprca = rcalpro_k * 1e-3;
-    if (k <= kmx) prca = prca + dprca * dztk;   // levels below the sea floor are walked only for the team's barriers
-    SRC(k, Q->dic) = SN(MI::dic) - dprca;
     const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
     double rtdic13 = dmax(bioin[MI::dic13 - 1], r13min) / dmax(dic_in, UV_TRCMIN);
     rtdic13 = dmin(rtdic13, 2. * UV_RC13STD / (1 + UV_RC13STD));
     rtdic13 = dmax(rtdic13, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
-    if (k <= kmx) prca13 = prca13 + dprca * dztk * rtdic13;
-    SRC(k, Q->dic13) = SRC(k, Q->dic13) - rtdic13 * dprca;
-    SRC(k, Q->alk) = -SN(MI::dic) * P->redntc * 1.e-3 - 2. * dprca;
-    // second pass of the reference (mobi.F:1302-1365) needs only this level's values: fused here
-    {
-      const double fo2 = tanh(0.22 * dmax(o2_in, 0.));
-      const double so2 = dic_sms * P->redotc + nfix_k * S.rnbio * 1.25e-3;
-      const double lno3b = 0.5 * tanh(tn_no3 - 2.5);
-      double wcdeni = 800. * no3flag * so2 * (1.0 - fo2) * (0.5 + lno3b) * din15flag;
-      wcdeni = dmax(wcdeni, 0.);
-      SRC(k, Q->no3) = SRC(k, Q->no3) - wcdeni;
-      double uno3 = wcdeni * twodt / tn_no3;
-      uno3 = dmin(uno3, 0.999);
-      uno3 = dmax(uno3, UV_TRCMIN);
-      const double bwcdeni = rayleigh(rno3, P->eps_wcdeni, uno3);
-      SRC(k, Q->din15) = SRC(k, Q->din15) - (bwcdeni / (1 + bwcdeni)) * wcdeni;
-      double a = SRC(k, Q->alk);
-      a = a + wcdeni * 1.e-3;
-      a = a + sg_bdeni * 1.e-3;
-      a = a - nfix_k * S.rnbio * 1.e-3;
-      SRC(k, Q->alk) = a;
-      SRC(k, Q->o2) = -so2 * fo2;
+    if (k <= kmx) {   // levels below the sea floor are walked only for the team's barriers
+      prca = prca + dprca * dztk;
+      prca13 = prca13 + dprca * dztk * rtdic13;
     }
-    // export of this level becomes the import of the next, mobi.F:1268-1287
+    // bottom remineralisation takes its share (mobi.F:1124-1134); the rest is the import of
+    // the next level, mobi.F:1268-1287
+    rc13expo = rc13expo - sgb * rc13expo;
+    expo = expo - sgb * expo;
+    expo_phos = expo_phos - sgb * expo_phos;
     expo = expo * dztk;
     expo_phos = expo_phos * dztk;
     rc13expo = rc13expo * dztk;
     expofe = expofe * dztk;
+#undef OUT
   }
-  // calcite dissolution profile (mobi.F:1373-1436), iron inputs (tracer.F:538-545), 14C (tracer.F:853-867)
-  store = writer;
-  if (writer)
-  for (int k = 1; k <= kmx; ++k) {
-    const double rc = (k < kmx) ? P->rcak[k - 1] : P->rcab[k - 1];
-    SRC(k, Q->dic) = SRC(k, Q->dic) + prca * rc;
-    SRC(k, Q->dic13) = SRC(k, Q->dic13) + prca13 * rc;
-    SRC(k, Q->alk) = SRC(k, Q->alk) + 2. * prca * rc;
-    double fe = SRC(k, Q->dfe);
-    if (k == 1) fe = fe + M.fe_atmdep[ij + NS * (S.month - 1)] * 1000 / (P->dzt[0] / 100.);
-    fe = fe + M.fe_hydr[ij + NS * (k - 1)];
-    SRC(k, Q->dfe) = fe;
-    if (Q->c14 > 0) SRC(k, Q->c14) = SRC(k, Q->dic) * UV_RC14STD - 3.836e-12 * TM(k, P->ic14);
+  if (writer) {
+    M.col[ij] = prca;
+    M.col[NS + ij] = prca13;
   }
-#undef SN
-#undef SRC
-#undef TM
-#undef TNC
 }
 
 // one thread per column, all roles in the thread
@@ -886,6 +840,108 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
   NoTeam T;
   mobi_column_body(T, c, M, i, j, true, c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)]);
 }
+
+// ---------------------------------------------------------------------------
+// the part of mobi_driver after mobi_src that stays inside the cell (mobi.F:1033-1134,
+// 1228-1266, 1302-1436) and the caller's iron inputs and 14C (tracer.F:538-545, 853-867).
+// Land and the levels below the sea floor get zero sources (static local src, tracer.F:121).
+// ---------------------------------------------------------------------------
+UVIC_DEV void mobi_post_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
+  UV_MOBI_LOCALS(c, M);
+  double *src = const_cast<double *>(c.src);
+#define SRC(s) src[X3(i, k, j) + (size_t)((s)-1) * N3]
+#define SN(m) SRC(P->slot_of_mobi[(m)-1])
+  const int kmx = c.kmt[ij];
+  if (k > kmx) {
+    for (int s = 1; s <= c.nsrc; ++s) SRC(s) = 0.0;
+    return;
+  }
+  const double twodt = c.c2dtts, redctn = P->redctn;
+  const double o2_in = TM(k, P->io2) * 1000.;
+  const double dic_in = TM(k, P->idic);
+  const double sgb = M.sg_bathy[ij + NS * (k - 1)];
+  const double dztk = P->dzt[k - 1];
+  const double expo = AUX(MA_EXPO), expo_phos = AUX(MA_EXPOP), rn15expo = AUX(MA_RN15), rc13expo = AUX(MA_RC13);
+  const double rcalpro_k = AUX(MA_CALPRO), nfix_k = AUX(MA_NFIX);
+  const double prca = M.col[ij], prca13 = M.col[NS + ij];
+  const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
+  // benthic denitrification on the sub-grid bathymetry, mobi.F:1033-1085
+  const double tn_no3 = TNC(k, MI::no3), tn_din15 = TNC(k, MI::din15);
+  const double no3flag = flag01(tn_no3 - UV_TRCMIN);
+  const double din15flag = flag01(tn_din15 - UV_TRCMIN);
+  const double lno3 = 0.5 * tanh(tn_no3 * 10 - 5.0);
+  double sg_bdeni =
+      (0.06 + 0.19 * pow(0.99, dmax(o2_in, UV_TRCMIN) - dmax(tn_no3, UV_TRCMIN))) * dmax(expo * sgb, UV_TRCMIN) * redctn * 1.e3;
+  sg_bdeni = dmin(sg_bdeni, sgb * expo);
+  sg_bdeni = dmax(sg_bdeni, 0.);
+  sg_bdeni = sg_bdeni * (0.5 + lno3) * no3flag * din15flag;
+  const double sn_no3 = SN(MI::no3) + sgb * expo - sg_bdeni;
+  double rno3 = dmax(tn_din15, r15min) / dmax(tn_no3 - tn_din15, r15min);
+  rno3 = dmin(rno3, 2. * UV_RN15STD);
+  rno3 = dmax(rno3, UV_RN15STD / 2.);
+  const double eps_bdeni = P->eps_bdeni0 * exp(-2.5e-6 * (P->zt[k - 1]));
+  const double bbdeni = rno3 - eps_bdeni * rno3 / 1000.;
+  const double sn_din15 = SN(MI::din15) + rn15expo * sgb * expo - bbdeni / (1 + bbdeni) * sg_bdeni;
+  // sedimentary iron release, mobi.F:1086-1123
+  const double coxdepth = dmin(dmax(P->zt[k - 1], 50000.), 150000.);
+  const double oblinc = -1.26e-6 * coxdepth + 0.203;
+  const double obexpc = -6.e-7 * coxdepth + 1.14;
+  const double nburial = (oblinc * pow(expo * sgb * dztk / 100 * 86400. * 365. * redctn * 1000., obexpc)) /
+                         (86400. * 365. * dztk / 100 * redctn * 1000.);
+  const double coxsed = expo * sgb - nburial;
+  const double fesedmax = 85.;
+  const double fesed = fesedmax * tanh(coxsed * redctn * 1000 * dztk / 100 * 86400. / o2_in) / (dztk / 100 * 86400 * 1000);
+  double fe = SN(MI::dfe) + fesed;
+  // bottom remineralisation, mobi.F:1124-1134
+  SN(MI::po4) = SN(MI::po4) + sgb * expo_phos;
+  const double sn_dic = SN(MI::dic) + sgb * expo * redctn;
+  const double sn_dic13 = SN(MI::dic13) + rc13expo * sgb * redctn;
+  // DIC / alkalinity / 13C bookkeeping, mobi.F:1228-1266
+  const double dic_sms = sn_dic;
+  const double dprca = rcalpro_k * 1e-3;
+  double s_dic = sn_dic - dprca;
+  const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
+  double rtdic13 = dmax(TNC(k, MI::dic13), r13min) / dmax(dic_in, UV_TRCMIN);
+  rtdic13 = dmin(rtdic13, 2. * UV_RC13STD / (1 + UV_RC13STD));
+  rtdic13 = dmax(rtdic13, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
+  double s_dic13 = sn_dic13 - rtdic13 * dprca;
+  double a = -sn_dic * P->redntc * 1.e-3 - 2. * dprca;
+  // water-column denitrification and oxygen, the reference's second pass (mobi.F:1302-1365)
+  const double fo2 = tanh(0.22 * dmax(o2_in, 0.));
+  const double so2 = dic_sms * P->redotc + nfix_k * S.rnbio * 1.25e-3;
+  const double lno3b = 0.5 * tanh(tn_no3 - 2.5);
+  double wcdeni = 800. * no3flag * so2 * (1.0 - fo2) * (0.5 + lno3b) * din15flag;
+  wcdeni = dmax(wcdeni, 0.);
+  SRC(Q->no3) = sn_no3 - wcdeni;
+  double uno3 = wcdeni * twodt / tn_no3;
+  uno3 = dmin(uno3, 0.999);
+  uno3 = dmax(uno3, UV_TRCMIN);
+  const double bwcdeni = rayleigh(rno3, P->eps_wcdeni, uno3);
+  SRC(Q->din15) = sn_din15 - (bwcdeni / (1 + bwcdeni)) * wcdeni;
+  a = a + wcdeni * 1.e-3;
+  a = a + sg_bdeni * 1.e-3;
+  a = a - nfix_k * S.rnbio * 1.e-3;
+  SRC(Q->o2) = -so2 * fo2;
+  // calcite dissolution profile (mobi.F:1373-1436), iron inputs (tracer.F:538-545), 14C (tracer.F:853-867)
+  const double rc = (k < kmx) ? P->rcak[k - 1] : P->rcab[k - 1];
+  s_dic = s_dic + prca * rc;
+  s_dic13 = s_dic13 + prca13 * rc;
+  a = a + 2. * prca * rc;
+  SRC(Q->dic) = s_dic;
+  SRC(Q->dic13) = s_dic13;
+  SRC(Q->alk) = a;
+  if (k == 1) fe = fe + M.fe_atmdep[ij + NS * (S.month - 1)] * 1000 / (P->dzt[0] / 100.);
+  fe = fe + M.fe_hydr[ij + NS * (k - 1)];
+  SRC(Q->dfe) = fe;
+  if (Q->c14 > 0) SRC(Q->c14) = s_dic * UV_RC14STD - 3.836e-12 * TM(k, P->ic14);
+#undef SRC
+#undef SN
+}
+#undef TM
+#undef TNC
+#undef PRE
+#undef AUX
+#undef UV_MOBI_LOCALS
 
 }  // namespace uvic
 
@@ -895,7 +951,7 @@ UVIC_DEV void mobi_column_kernel(const uvic_ctx &c, const mobi_dev &M, int i, in
 struct mobi_store {
   void *params;
   double *f[8];
-  double *ac13b, *ac13b_side;   // one per stream: the side stream works one step ahead
+  double *work, *work_side;     // work planes, one set per stream: the side stream works one step ahead
 };
 static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp, const uvic_mobi_forcing *hf, mobi_dev *dev,
                             mobi_store *st, hipStream_t stream, std::string &err) {
@@ -919,10 +975,11 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
     if ((e = hipMalloc(&st->params, sizeof(uvic_mobi_params))) != hipSuccess) { err = hipGetErrorString(e); return 1; }
     for (int q = 0; q < 8; ++q)
       if ((e = hipMalloc((void **)&st->f[q], sz[q] * 8)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
-    if ((e = hipMalloc((void **)&st->ac13b, NS * km * 8)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
-    if ((e = hipMemsetAsync(st->ac13b, 0, NS * km * 8, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
-    if ((e = hipMalloc((void **)&st->ac13b_side, NS * km * 8)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
-    if ((e = hipMemsetAsync(st->ac13b_side, 0, NS * km * 8, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    const size_t wb = mobi_work_doubles(imt, jmt, km) * 8;
+    if ((e = hipMalloc((void **)&st->work, wb)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMemsetAsync(st->work, 0, wb, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMalloc((void **)&st->work_side, wb)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMemsetAsync(st->work_side, 0, wb, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
   }
   if ((e = hipMemcpyAsync(st->params, hp, sizeof(uvic_mobi_params), hipMemcpyHostToDevice, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
   for (int q = 0; q < 8; ++q) {
@@ -933,7 +990,7 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
   dev->P = (const uvic_mobi_params *)st->params;
   dev->tlat = st->f[0]; dev->dnswr = st->f[1]; dev->aice = st->f[2]; dev->hice = st->f[3]; dev->hsno = st->f[4];
   dev->sg_bathy = st->f[5]; dev->fe_atmdep = st->f[6]; dev->fe_hydr = st->f[7];
-  dev->ac13b = st->ac13b;
+  mobi_set_work(dev, st->work, imt, jmt, km);
   dev->pi = hf->pi; dev->radian = hf->radian; dev->relyr = hf->relyr; dev->co2ccn = hf->co2ccn;
   return 0;
 }

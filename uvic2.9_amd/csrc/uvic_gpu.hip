@@ -135,10 +135,15 @@ __global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c) {
   if (n > c.nt || j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
   convect_apply_cell(c, i, j, n);
 }
-__global__ void __launch_bounds__(128) k_mobi_co2(const uvic_ctx c, const mobi_dev m) {
+__global__ void __launch_bounds__(128) k_mobi_pre(const uvic_ctx c, const mobi_dev m) {
   CELL_DECODE(c);
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
-  mobi_co2_cell(c, m, i, k, j);
+  mobi_pre_cell(c, m, i, k, j);
+}
+__global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_dev m) {
+  CELL_DECODE(c);
+  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  mobi_post_cell(c, m, i, k, j);
 }
 // team form: four waves (one per SIMD of a CU) share 64 columns, see kernels_mobi.hpp
 struct GpuTeam {
@@ -418,8 +423,8 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->cv_z);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
-    (void)hipFree(h->mobi_st.ac13b);
-    (void)hipFree(h->mobi_st.ac13b_side);
+    (void)hipFree(h->mobi_st.work);
+    (void)hipFree(h->mobi_st.work_side);
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
   }
   for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -652,13 +657,15 @@ static int launch_mobi(uvic_gpu *h) {
   if (h->src_from_prefetch) return 0;  // computed one step ahead on the side stream; launch_transport waits for it
   if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.S)) return rc;
   mark(h, "begin");
-  hipLaunchKernelGGL(k_mobi_co2, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
-  mark(h, "mobi_co2");
+  hipLaunchKernelGGL(k_mobi_pre, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
+  mark(h, "mobi_pre");
   if (h->mobi_team)
     hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->stream, h->ctx, h->mobi);
   else
     hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi");
+  hipLaunchKernelGGL(k_mobi_post, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
+  mark(h, "mobi_post");
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -718,16 +725,17 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   uvic_ctx c = h->ctx;
   mobi_dev m = h->mobi;
   c.t_taum1 = h->ctx.t_tau;
-  m.ac13b = h->mobi_st.ac13b_side;
+  mobi_set_work(&m, h->mobi_st.work_side, h->d.imt, h->d.jmt, h->d.km);
   c.src = (const double *)h->src_alt;
   c.c2dtts = c2dtts_next;
   if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_step_begin, 0));
-  hipLaunchKernelGGL(k_mobi_co2, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
+  hipLaunchKernelGGL(k_mobi_pre, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
   if (h->mobi_team)
     hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->side, c, m);
   else
     hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
+  hipLaunchKernelGGL(k_mobi_post, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev_src_next, h->side));
   h->prefetch_pending = true;
