@@ -107,9 +107,11 @@ extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uv
 // ---- MOBI column kernel in TEAM form: four "waves" x 64 lanes per team, real threads and a
 // pthread barrier stand in for the workgroup (state lives in registers across barriers, so the
 // phase-loop emulation of HostEnv does not apply here)
+template <int R>
 struct HostTeam {
   static constexpr bool team = true;
-  int wave, lane;
+  static constexpr int role = R;
+  int lane;
   double *xs;
   unsigned xc;
   pthread_barrier_t *bar;
@@ -161,8 +163,12 @@ extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, con
           int i, j;
           const bool live = decode(lane, i, j);
           if (!live) { i = 2; j = c.js; }
-          HostTeam T{wave, lane, xs.data(), 0u, &bar};
-          mobi_column_body(T, c, M, i, j, live, kmax);
+          switch (wave) {
+            case 0: { HostTeam<0> T{lane, xs.data(), 0u, &bar}; mobi_column_body(T, c, M, i, j, live, kmax); break; }
+            case 1: { HostTeam<1> T{lane, xs.data(), 0u, &bar}; mobi_column_body(T, c, M, i, j, live, kmax); break; }
+            case 2: { HostTeam<2> T{lane, xs.data(), 0u, &bar}; mobi_column_body(T, c, M, i, j, live, kmax); break; }
+            default: { HostTeam<3> T{lane, xs.data(), 0u, &bar}; mobi_column_body(T, c, M, i, j, live, kmax); break; }
+          }
         });
     for (auto &t : th) t.join();
     pthread_barrier_destroy(&bar);

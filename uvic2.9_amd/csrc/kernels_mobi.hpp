@@ -30,6 +30,19 @@
 #define UV_RC14STD 1.176e-12
 #define UV_MOBI_MAXT 40
 
+// The parameter block is written once by uvic_gpu_set_mobi and never during a kernel: device code
+// reads it through the constant address space, so that the compiler may keep or re-order those
+// (scalar) loads across the workgroup barriers of the team kernel instead of re-issuing them
+// after every barrier.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) uvic_mobi_params *mobi_params_cp;
+typedef const __attribute__((address_space(4))) uvic_mobi_index *mobi_index_cp;
+#define UV_CONST_AS(p) ((mobi_params_cp)(p))
+#else
+typedef const uvic_mobi_params *mobi_params_cp;
+typedef const uvic_mobi_index *mobi_index_cp;
+#define UV_CONST_AS(p) (p)
+#endif
 // per-step scalars of tracer.F:311-343
 struct mobi_step {
   int nbio, month;
@@ -271,14 +284,18 @@ UVIC_DEV double clamp_ratio(double r, double hi, double lo) {
 #define UV_MOBI_LDS_DOUBLES ((size_t)2 * (UV_MOBI_XN + UV_MOBI_YN) * 64)
 struct NoTeam {
   static constexpr bool team = false;
-  int wave = 0, lane = 0;
+  static constexpr int role = 0;
+  int lane = 0;
   double *xs = nullptr;
   unsigned xc = 0;
+#ifdef UV_MOBI_TIMING
+  long long tq[8];
+#endif
   UVIC_DEV void sync() const {}
 };
 
 template <class Team>
-UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, double *bioin, double bct, double impo, double impo_phos,
+UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bioin, double bct, double impo, double impo_phos,
                      double wwd, double nud, double nudop, double nudon, double *bioout, double bctz,
                      double rn15impo, double rc13impo, double ac13b, double impofe, double o2flag, double aou_term,
                      double avej, double avej_D, src_out_t *out) {
@@ -330,7 +347,13 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
   const double rc13hi = 2. * UV_RC13STD / (1 + UV_RC13STD), rc13lo = 0.5 * UV_RC13STD / (1 + UV_RC13STD);
 
   for (int n = 1; n <= S.nbio; ++n) { /* mobi.F:2148-3252 */
-#define ROLE(r) (!Team::team || T.wave == (r))
+#ifdef UV_MOBI_TIMING
+    long long tq0 = clock64();
+#define TQ(q) { const long long tq1 = clock64(); T.tq[q] += tq1 - tq0; tq0 = tq1; }
+#else
+#define TQ(q)
+#endif
+#define ROLE(r) (!Team::team || Team::role == (r))
     // outputs of the four roles
     double npp = 0., npp_D = 0., no3upt_D = 0., dopupt = 0., dopupt_D = 0., fcassim = 0.;
     double graz = 0., graz_Z = 0., graz_Det = 0., graz_D = 0., morp = 0., morpt = 0., morz = 0., remi = 0., expo = 0.;
@@ -445,6 +468,7 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
       rtdoc13 = clamp_ratio(biodoc13 / (biodon * redctn), rc13hi, rc13lo);
       rtdiazc13 = clamp_ratio(biodiazc13 / (biodiaz * redctn), rc13hi, rc13lo);
     }
+    TQ(0)
     if (Team::team) {  // publish own group, one barrier, fetch the other three
       double *xb = T.xs + (size_t)(T.xc & 1u) * UV_MOBI_XN * 64 + T.lane;
       ++T.xc;
@@ -456,12 +480,14 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
   X(31, rtphytc13) X(32, rtzoopc13) X(33, rtdetrc13) X(34, rtdoc13) X(35, rtdiazc13)
 #define XPUT(sl, v) xb[(size_t)(sl) * 64] = v;
 #define XGET(sl, v) v = xb[(size_t)(sl) * 64];
-      if (T.wave == 0) { XA(XPUT) } else if (T.wave == 1) { XB(XPUT) } else if (T.wave == 2) { XC(XPUT) } else { XD(XPUT) }
+      if (Team::role == 0) { XA(XPUT) } else if (Team::role == 1) { XB(XPUT) } else if (Team::role == 2) { XC(XPUT) } else { XD(XPUT) }
+      TQ(1)
       T.sync();
-      if (T.wave != 0) { XA(XGET) }
-      if (T.wave != 1) { XB(XGET) }
-      if (T.wave != 2) { XC(XGET) }
-      if (T.wave != 3) { XD(XGET) }
+      TQ(2)
+      if (Team::role != 0) { XA(XGET) }
+      if (Team::role != 1) { XB(XGET) }
+      if (Team::role != 2) { XC(XGET) }
+      if (Team::role != 3) { XD(XGET) }
 #undef XA
 #undef XB
 #undef XC
@@ -470,6 +496,7 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
 #undef XGET
     }
 #undef ROLE
+    TQ(3)
     /* zooplankton budget, mobi.F:2446-2530 */
     const double dig_P = gamma1 * graz, dig_Z = gamma1 * graz_Z, dig_Det = gamma1 * graz_Det;
     double dig = dig_Z + dig_P + dig_Det;
@@ -499,7 +526,7 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
     /* prognostic updates, mobi.F:2738-3085; every right-hand side uses the OLD state.  In a team each
        wave advances the pools it owns (0: nutrients and producers, 1: zooplankton, detritus, iron,
        2: 15N, 3: 13C), refreshes their flags and publishes both; every wave then holds the full state. */
-#define OWN(r) (!Team::team || T.wave == (r))
+#define OWN(r) (!Team::team || Team::role == (r))
     if (OWN(0)) {
       const double n_po4 = biopo4 + dtbio * (dopupt * ptn_P - GM15ptn * npp + (1. - dfrt) * morpt * ptn_P +
                                            (1. - pfr) * remi * ptn_detr + diazptn * (morpt_D - (npp_D - dopupt_D)) +
@@ -614,6 +641,7 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
       if (doc13flag == 1) doc13flag = flag01(biodoc13 - UV_TRCMIN);
       if (diazc13flag == 1) diazc13flag = flag01(biodiazc13 - UV_TRCMIN);
     }
+    TQ(4)
     if (Team::team) {  // second exchange: new pools, their flags, the P:N ratios
       double *yb = T.xs + (size_t)2 * UV_MOBI_XN * 64 + (size_t)((T.xc - 1u) & 1u) * UV_MOBI_YN * 64 + T.lane;
 #define YA(X) X(0, biopo4) X(1, biodop) X(2, biophyt) X(3, biophyt_phos) X(4, biodic) X(5, biono3) X(6, biodon) X(7, biodiaz) \
@@ -626,21 +654,29 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
   X(45, dic13flag) X(46, phytc13flag) X(47, zoopc13flag) X(48, detrc13flag) X(49, doc13flag) X(50, diazc13flag)
 #define YPUT(sl, v) yb[(size_t)(sl) * 64] = v;
 #define YGET(sl, v) v = yb[(size_t)(sl) * 64];
-      if (T.wave == 0) { YA(YPUT) } else if (T.wave == 1) { YB(YPUT) } else if (T.wave == 2) { YC(YPUT) } else { YD(YPUT) }
+      if (Team::role == 0) { YA(YPUT) } else if (Team::role == 1) { YB(YPUT) } else if (Team::role == 2) { YC(YPUT) } else { YD(YPUT) }
+      TQ(5)
       T.sync();
-      if (T.wave != 0) { YA(YGET) }
-      if (T.wave != 1) { YB(YGET) }
-      if (T.wave != 2) { YC(YGET) }
-      if (T.wave != 3) { YD(YGET) }
+      TQ(6)
+      if (Team::role != 0) { YA(YGET) }
+      if (Team::role != 1) { YB(YGET) }
+      if (Team::role != 2) { YC(YGET) }
+      if (Team::role != 3) { YD(YGET) }   // (what a role never reads is dropped by the compiler: roles are compile-time)
+    }
+#undef OWN
+    TQ(7)
+#undef TQ
+  }
+  if (Team::team && Team::role == 0) {  // the writer needs every pool once more, after the last sub-step
+    double *yb = T.xs + (size_t)2 * UV_MOBI_XN * 64 + (size_t)((T.xc - 1u) & 1u) * UV_MOBI_YN * 64 + T.lane;
+    YB(YGET) YC(YGET) YD(YGET)
+  }
 #undef YA
 #undef YB
 #undef YC
 #undef YD
 #undef YPUT
 #undef YGET
-    }
-#undef OWN
-  }
   (void)dic13flag; (void)doc13flag; (void)phytc13flag; (void)zoopc13flag; (void)detrc13flag; (void)diazc13flag;
 #define BOUT(m, v) bioout[(m)-1] = (v)-BIN(m)
   BOUT(MI::po4, biopo4); BOUT(MI::phyt, biophyt); BOUT(MI::phyt_phos, biophyt_phos); BOUT(MI::zoop, biozoop);
@@ -672,9 +708,9 @@ UVIC_DEV void mobi_src(Team &T, const uvic_mobi_params *P, const mobi_step &S, d
 // ---------------------------------------------------------------------------
 #define UV_MOBI_LOCALS(c, M)                                   \
   UV_DIMS(c);                                                  \
-  const uvic_mobi_params *P = M.P;                             \
+  mobi_params_cp P = UV_CONST_AS(M.P);                         \
   const mobi_step &S = M.S;                                    \
-  const uvic_mobi_index *Q = &P->is;                           \
+  mobi_index_cp Q = &P->is;                                    \
   const size_t ij = X2(i, j), NS = (size_t)imt * jmt;          \
   (void)S; (void)Q; (void)ij; (void)NS
 #define TM(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
@@ -772,7 +808,7 @@ template <class Team>
 UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, int i, int j, bool live, int kmax) {
   UV_MOBI_LOCALS(c, M);
   const int kmx = live ? c.kmt[ij] : 0;
-  const bool writer = live && T.wave == 0;      // in a team only wave 0 stores
+  const bool writer = live && Team::role == 0;  // in a team only the wave of role 0 stores
   double *src = const_cast<double *>(c.src);
   double sink = 0.0;
   // every thread of a team walks the same loops (workgroup barriers inside): threads that have

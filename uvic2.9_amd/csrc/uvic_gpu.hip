@@ -145,14 +145,34 @@ __global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
   mobi_post_cell(c, m, i, k, j);
 }
-// team form: four waves (one per SIMD of a CU) share 64 columns, see kernels_mobi.hpp
+// team form: four waves (one per SIMD of a CU) share 64 columns, each with its own compile-time
+// role, see kernels_mobi.hpp
+template <int R>
 struct GpuTeam {
   static constexpr bool team = true;
-  int wave, lane;
+  static constexpr int role = R;
+  int lane;
   double *xs;
   unsigned xc;
+#ifdef UV_MOBI_TIMING
+  long long tq[8];
+#endif
   __device__ __forceinline__ void sync() const { __syncthreads(); }
 };
+template <int R>
+__device__ __forceinline__ void mobi_team_role(const uvic_ctx &c, const mobi_dev &m, double *lds, int i, int j, bool live, int kmax) {
+  GpuTeam<R> T{(int)threadIdx.x, lds, 0u};
+#ifdef UV_MOBI_TIMING
+  for (int q = 0; q < 8; ++q) T.tq[q] = 0;
+  const long long tk0 = clock64();
+#endif
+  mobi_column_body(T, c, m, i, j, live, kmax);
+#ifdef UV_MOBI_TIMING
+  if (threadIdx.x == 0 && (blockIdx.x == 60 || blockIdx.x == 100))
+    printf("blk %d role %d kmax %d total %lld | role %lld put %lld bar %lld get %lld shared+own %lld put %lld bar %lld get %lld\n", blockIdx.x, R, kmax,
+           clock64() - tk0, T.tq[0], T.tq[1], T.tq[2], T.tq[3], T.tq[4], T.tq[5], T.tq[6], T.tq[7]);
+#endif
+}
 __global__ void __launch_bounds__(256) k_mobi_team(const uvic_ctx c, const mobi_dev m) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * 64 + threadIdx.x;
@@ -163,8 +183,12 @@ __global__ void __launch_bounds__(256) k_mobi_team(const uvic_ctx c, const mobi_
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
   __builtin_amdgcn_s_setprio(3);
-  GpuTeam T{(int)threadIdx.y, (int)threadIdx.x, lds, 0u};
-  mobi_column_body(T, c, m, i, j, live, kmax);
+  switch (threadIdx.y) {   // wave-uniform: every wave runs the code specialised for its role
+    case 0: mobi_team_role<0>(c, m, lds, i, j, live, kmax); break;
+    case 1: mobi_team_role<1>(c, m, lds, i, j, live, kmax); break;
+    case 2: mobi_team_role<2>(c, m, lds, i, j, live, kmax); break;
+    default: mobi_team_role<3>(c, m, lds, i, j, live, kmax); break;
+  }
 }
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
