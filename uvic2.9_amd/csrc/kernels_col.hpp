@@ -106,6 +106,15 @@ __device__ __forceinline__ double dpp_d(double v) {
 #define DPP_WAVE_SHR1 0x138 /* lane i <- lane i-1 */
 __device__ __forceinline__ double shfl_w(double v) { return dpp_d<DPP_WAVE_SHR1>(v); }  // value of lane-1 (west)
 __device__ __forceinline__ double shfl_e(double v) { return dpp_d<DPP_WAVE_SHL1>(v); }  // value of lane+1 (east)
+// The 1-D grid metrics are written at upload time only: read them through the constant address
+// space so that a wave-uniform index becomes a scalar load (s_load, own counter) rather than a
+// vector load whose wait would also drain the level-ahead prefetch.
+__device__ __forceinline__ double kload(const double *p, int idx) {
+  return ((const __attribute__((address_space(4))) double *)p)[idx];
+}
+// v_max_f64 / v_min_f64: one instruction instead of compare + two selects (operands are never NaN here)
+__device__ __forceinline__ double fmx(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double fmn(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double upstream(double v, double a, double b) { return v * (a + b) + dabs(v) * (a - b); }
 __device__ __forceinline__ double limited(double cpos, double cneg, double f) {
   return 0.5 * ((cpos + cneg) * f + (cpos - cneg) * dabs(f));
@@ -113,11 +122,11 @@ __device__ __forceinline__ double limited(double cpos, double cneg, double f) {
 // R+ and R- of Zalesak's limiter for one cell (tracer_adv_flx.F:672-690)
 __device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, double scale, double flxlft, double flxrgt,
                                           double mask, double &rp, double &rm) {
-  const double trmax = dmax(dmax(fxa, fxb), tlo), trmin = dmin(dmin(fxa, fxb), tlo);
-  const double pplus = scale * (dmax(0.0, flxlft) - dmin(0.0, flxrgt));
-  const double pminus = scale * (dmax(0.0, flxrgt) - dmin(0.0, flxlft));
-  rp = dmin(1., mask * (trmax - tlo) / (pplus + UV_EPSLN));
-  rm = dmin(1., mask * (tlo - trmin) / (pminus + UV_EPSLN));
+  const double trmax = fmx(fmx(fxa, fxb), tlo), trmin = fmn(fmn(fxa, fxb), tlo);
+  const double pplus = scale * (fmx(0.0, flxlft) - fmn(0.0, flxrgt));
+  const double pminus = scale * (fmx(0.0, flxrgt) - fmn(0.0, flxlft));
+  rp = fmn(1., mask * (trmax - tlo) / (pplus + UV_EPSLN));
+  rm = fmn(1., mask * (tlo - trmin) / (pminus + UV_EPSLN));
 }
 
 __device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
@@ -155,125 +164,156 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   double *Sn = S + nloc * N3;
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
   const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
-  const double cstr_r = c.cstr[r - 1];
+  const double cstr_r = kload(c.cstr, r - 1);
   const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
-  const double cstdyt2r = c.cstdyt2r[r - 1], cstdytr = c.cstdytr[r - 1];
+  const double cstdyt2r = kload(c.cstdyt2r, r - 1), cstdytr = kload(c.cstdytr, r - 1);
   const double c2dtts = c.c2dtts;
   const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
   const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
+  // addresses = wave-uniform pointer (scalar registers, scalar arithmetic) + the lane's 32-bit column offset
   const size_t rowstride = (size_t)imt * km;
-  const size_t base = X3(i, 1, r);  // level k at base + (k-1)*imt
-#define LD(p, k, dj) (p)[base + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride]
-#define CF(pl, k, dj) cf[base + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride + (size_t)(pl) * N3]
-  // rolling windows: index 0 = level s-1, 1 = level s, 2 = level s+1
-  double mc[3], ms[3], mn[3], tc[3];
-  mc[0] = mc[1] = LD(tm, 1, 0); ms[0] = ms[1] = LD(tm, 1, -1); mn[0] = mn[1] = LD(tm, 1, 1);
-  tc[0] = tc[1] = LD(tt, 1, 0);
+  const size_t rbase = X3(1, 1, r);  // level k of row r starts at rbase + (k-1)*imt
+  const unsigned lb = (unsigned)(i - 1) * 8u;   // byte offset: `global_load v, v_off, s[base]` needs no per-load VALU address
+#define ATB(p) (*(decltype(p))((const char *)(p) + lb))
+#define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
+#define LD(p, k, dj) AT(p, k, dj)
+#define CF(pl, k, dj) AT(cf + (size_t)(pl) * N3, k, dj)
+  const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
+  // Everything a level reads from memory is fetched one level ahead into the other of two
+  // register sets (A/B, the loop is unrolled by two), so a wave waits for memory once per level
+  // and the latency of its ~40 loads is covered by the arithmetic of the level before.
+  struct Lvl {
+    double mc2, ms2, mn2, tc2;   // t(tau-1) centre/south/north and t(tau) centre at level s+1
+    double t_s, t_n;             // t(tau) south/north at level s
+    double ve, vn, vs, vb;       // total velocities on the east, north, south and bottom faces of level s
+    double cf[CF_COUNT], cfs[5]; // folded coefficients of row r and the north-face ones of row r-1
+  };
+  auto load_level = [&](Lvl &L, int s) {
+    const int sp = (s >= km) ? km : s + 1;
+    L.mc2 = LD(tm, sp, 0); L.ms2 = LD(tm, sp, -1); L.mn2 = LD(tm, sp, 1); L.tc2 = LD(tt, sp, 0);
+    L.t_s = LD(tt, s, -1); L.t_n = LD(tt, s, 1);
+    L.ve = AT(c.tot_e, s, 0); L.vn = AT(c.tot_n, s, 0); L.vs = AT(c.tot_n, s, -1);
+    L.vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
+    _Pragma("unroll") for (int p = 0; p < CF_COUNT; ++p) L.cf[p] = CF(p, s, 0);
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) L.cfs[p] = CF(CF_AN + p, s, -1);
+  };
+  // state carried from level to level
+  double mc0, mc1, ms0, ms1, mn0, mn1, tc0, tc1;   // levels s-1 and s of the windows
+  mc0 = mc1 = LD(tm, 1, 0); ms0 = ms1 = LD(tm, 1, -1); mn0 = mn1 = LD(tm, 1, 1);
+  tc0 = tc1 = LD(tt, 1, 0);
   // surface faces
-  const double vb0 = c.adv_vbt[XF(i, 0, r)];
-  double fblo_up = vb0 * 2.0 * mc[1];            // low-order flux through the face above level s
+  const double vb0 = ATB(c.adv_vbt + fbase);
+  double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
   double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
-  double fbfin_up2 = vb0 * (tc[1] + tc[1]);      // FINAL advective flux through the face above level s-1 ... (top: tracer.F:1063)
   double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
   double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
-  double fbfin_up = fbfin_up2;                   // final flux through the face above the level being finalised
-  for (int s = 1; s <= km; ++s) {
+  double fbfin_up = vb0 * (tc1 + tc1);           // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
+  auto level = [&](const Lvl &L, int s) {
     const bool last = (s == km);
-    const int sp = last ? km : s + 1;
-    mc[2] = LD(tm, sp, 0); ms[2] = LD(tm, sp, -1); mn[2] = LD(tm, sp, 1); tc[2] = LD(tt, sp, 0);
-    const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
-    const double mk = (s <= kz) ? 1.0 : 0.0, mk_w = (s <= kz_w) ? 1.0 : 0.0, mk_e = (s <= kz_e) ? 1.0 : 0.0;
-    const double mk_s = (s <= kz_s) ? 1.0 : 0.0, mk_n = (s <= kz_n) ? 1.0 : 0.0;
-    const double mk_up = (s - 1 >= 1 && s - 1 <= kz) ? 1.0 : 0.0, mk_dn = (s + 1 <= kz) ? 1.0 : 0.0;
-    const double m_c = mc[1], tt_c = tc[1];
+    const double mc2 = L.mc2, ms2 = L.ms2, mn2 = L.mn2, tc2 = L.tc2;
+    const double t_s = L.t_s, t_n = L.t_n;
+    const double mk = (s <= kz) ? 1.0 : 0.0;
+    // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
+    const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
+    const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
+    const double m_c = mc1, tt_c = tc1;
     const double m_e = shfl_e(m_c), tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
     // ---- advection, low order and raw antidiffusive (adv_flx:500-619) ----------
-    const double ve = c.tot_e[base + (size_t)(s - 1) * imt];
-    const double vn = c.tot_n[base + (size_t)(s - 1) * imt], vs = c.tot_n[base + (size_t)(s - 1) * imt - rowstride];
+    const double ve = L.ve, vn = L.vn, vs = L.vs;
     const double felo = upstream(ve, m_c, m_e);
     const double afe = ve * (tt_c + tt_e) - felo;
     const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
-    const double fnlo_n = upstream(vn, m_c, mn[1]), fnlo_s = upstream(vs, ms[1], m_c);
+    const double fnlo_n = upstream(vn, m_c, mn1), fnlo_s = upstream(vs, ms1, m_c);
     double fblo = 0.0, afb = 0.0;
     if (!last) {
-      const double vb = c.tot_b[XF(i, s, r)];
-      fblo = vb * (mc[2] + m_c) + dabs(vb) * (mc[2] - m_c);
-      afb = vb * (tt_c + tc[2]) - fblo * mk;
+      const double vb = L.vb;
+      fblo = vb * (mc2 + m_c) + dabs(vb) * (mc2 - m_c);
+      afb = vb * (tt_c + tc2) - fblo * mk;
     }
     const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
-    const double advz = (fblo_up - fblo) * c.dzt2r[s - 1];
-    const double tlo = m_c - (c2dtts * c.dtxcel[s - 1]) * (advx + advy + advz) * mk;
+    const double advz = (fblo_up - fblo) * kload(c.dzt2r, s - 1);
+    const double tlo = m_c - (c2dtts * kload(c.dtxcel, s - 1)) * (advx + advy + advz) * mk;
     // ---- limiter ratios ---------------------------------------------------------
     double rxp, rxm, ryp, rym, rzp, rzm;
     {
       const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
-      fct_ratio(mk_w * mw + (1.0 - mk_w) * tlo, mk_e * me + (1.0 - mk_e) * tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
+      fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
     }
     {
       const double afn_n = vn * (tt_c + t_n) - fnlo_n;
       const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
-      fct_ratio(0.5 * mk_s * (t_s + tt_c) + (1.0 - mk_s) * tlo, 0.5 * mk_n * (tt_c + t_n) + (1.0 - mk_n) * tlo, tlo,
-                c2dtts * cstdyt2r, afn_s, afn_n, mk, ryp, rym);
+      fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
+                ryp, rym);
     }
     {
-      const double fxa = (s > 1) ? 0.5 * mk_up * (tc[0] + tt_c) + (1.0 - mk_up) * tlo : tlo;
-      const double fxb = (!last) ? 0.5 * mk_dn * (tt_c + tc[2]) + (1.0 - mk_dn) * tlo : tlo;
-      fct_ratio(fxa, fxb, tlo, c2dtts * c.dzt2r[s - 1], afb, afb_up, mk, rzp, rzm);
+      const double fxa = wet_up ? 0.5 * (tc0 + tt_c) : tlo;
+      const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
+      fct_ratio(fxa, fxb, tlo, c2dtts * kload(c.dzt2r, s - 1), afb, afb_up, mk, rzp, rzm);
     }
     if (owned) {
-      RpY[base + (size_t)(s - 1) * imt] = ryp;
-      RmY[base + (size_t)(s - 1) * imt] = rym;
+      AT(RpY, s, 0) = ryp;
+      AT(RmY, s, 0) = rym;
     }
     // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
     const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
-    const double fefin = limited(dmin(rxp_e, rxm), dmin(rxp, rxm_e), afe) + felo;
+    const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
     const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
     // ---- diffusive fluxes (coefficients folded by coef_cell) ---------------------------
-    const double dz_up = (s > 1) ? mc[0] - m_c : 0.0, dz_dn = (!last) ? m_c - mc[2] : 0.0;       // own column
-    const double dze_up = shfl_e(dz_up), dze_dn = shfl_e(dz_dn);                                     // east column
-    const double dzs_up = (s > 1) ? ms[0] - ms[1] : 0.0, dzs_dn = (!last) ? ms[1] - ms[2] : 0.0;  // south row
-    const double dzn_up = (s > 1) ? mn[0] - mn[1] : 0.0, dzn_dn = (!last) ? mn[1] - mn[2] : 0.0;  // north row
-    const double dfe = CF(CF_AE, s, 0) * (m_e - m_c) + CF(CF_CE + 0, s, 0) * dz_up + CF(CF_CE + 1, s, 0) * dze_up +
-                       CF(CF_CE + 2, s, 0) * dz_dn + CF(CF_CE + 3, s, 0) * dze_dn;
+    const double dz_up = (s > 1) ? mc0 - m_c : 0.0, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column
+    const double dze_up = shfl_e(dz_up), dze_dn = shfl_e(dz_dn);                                 // east column
+    const double dzs_up = (s > 1) ? ms0 - ms1 : 0.0, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row
+    const double dzn_up = (s > 1) ? mn0 - mn1 : 0.0, dzn_dn = (!last) ? mn1 - mn2 : 0.0;      // north row
+    const double dfe = L.cf[CF_AE] * (m_e - m_c) + L.cf[CF_CE + 0] * dz_up + L.cf[CF_CE + 1] * dze_up +
+                       L.cf[CF_CE + 2] * dz_dn + L.cf[CF_CE + 3] * dze_dn;
     const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
-    const double dfn_n = CF(CF_AN, s, 0) * (mn[1] - m_c) + CF(CF_CN + 0, s, 0) * dz_up + CF(CF_CN + 1, s, 0) * dzn_up +
-                         CF(CF_CN + 2, s, 0) * dz_dn + CF(CF_CN + 3, s, 0) * dzn_dn;
-    const double dfn_s = CF(CF_AN, s, -1) * (m_c - ms[1]) + CF(CF_CN + 0, s, -1) * dzs_up + CF(CF_CN + 1, s, -1) * dz_up +
-                         CF(CF_CN + 2, s, -1) * dzs_dn + CF(CF_CN + 3, s, -1) * dz_dn;
+    const double dfn_n = L.cf[CF_AN] * (mn1 - m_c) + L.cf[CF_CN + 0] * dz_up + L.cf[CF_CN + 1] * dzn_up +
+                         L.cf[CF_CN + 2] * dz_dn + L.cf[CF_CN + 3] * dzn_dn;
+    const double dfn_s = L.cfs[0] * (m_c - ms1) + L.cfs[1] * dzs_up + L.cfs[2] * dz_up + L.cfs[3] * dzs_dn + L.cfs[4] * dz_dn;
     const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
     double dfb = 0.0, dfbi = 0.0;  // through the face below level s
     if (!last) {
-      const double dx_c = m_e - m_c, dx_d = shfl_e(mc[2]) - mc[2];  // T(i+1)-T(i) at levels s, s+1
-      const double dxw_c = shfl_w(dx_c), dxw_d = shfl_w(dx_d);      // T(i)-T(i-1)
-      dfb = CF(CF_BV, s, 0) * (m_c - mc[2]);
-      dfbi = CF(CF_CBX + 0, s, 0) * dxw_c + CF(CF_CBX + 1, s, 0) * dx_c + CF(CF_CBX + 2, s, 0) * dxw_d + CF(CF_CBX + 3, s, 0) * dx_d +
-             CF(CF_CBY + 0, s, 0) * (m_c - ms[1]) + CF(CF_CBY + 1, s, 0) * (mn[1] - m_c) + CF(CF_CBY + 2, s, 0) * (mc[2] - ms[2]) +
-             CF(CF_CBY + 3, s, 0) * (mn[2] - mc[2]);
+      const double dx_c = m_e - m_c, dx_d = shfl_e(mc2) - mc2;   // T(i+1)-T(i) at levels s, s+1
+      const double dxw_c = shfl_w(dx_c), dxw_d = shfl_w(dx_d);   // T(i)-T(i-1)
+      dfb = L.cf[CF_BV] * (m_c - mc2);
+      dfbi = L.cf[CF_CBX + 0] * dxw_c + L.cf[CF_CBX + 1] * dx_c + L.cf[CF_CBX + 2] * dxw_d + L.cf[CF_CBX + 3] * dx_d +
+             L.cf[CF_CBY + 0] * (m_c - ms1) + L.cf[CF_CBY + 1] * (mn1 - m_c) + L.cf[CF_CBY + 2] * (mc2 - ms2) +
+             L.cf[CF_CBY + 3] * (mn2 - mc2);
     }
     if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
     if (kz == 0 && s == 1) dfb_up = btf;
-    const double DIFF_Tz = (dfb_up - dfb) * c.dztr[s - 1] + (dfbi_up - dfbi) * c.dztr[s - 1];
+    const double DIFF_Tz = (dfb_up - dfb) * kload(c.dztr, s - 1) + (dfbi_up - dfbi) * kload(c.dztr, s - 1);
     const double spart = DIFF_Tx + DIFF_Ty + DIFF_Tz - ADV_Tx;
     // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
     if (s >= 2) {
-      const double fbfin = (limited(dmin(rzp_prev, rzm), dmin(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
-      const double ADV_Tz = (fbfin_up - fbfin) * c.dzt2r[s - 2];
-      if (owned) Sn[base + (size_t)(s - 2) * imt] = spart_prev - ADV_Tz;
+      const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
+      const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, s - 2);
+      if (owned) AT(Sn, s - 1, 0) = spart_prev - ADV_Tz;
       fbfin_up = fbfin;
     }
-    if (last) {  // bottom face of the column (tracer.F:1065)
-      const double fbfin = c.adv_vbt[XF(i, km, r)] * tt_c;
-      const double ADV_Tz = (fbfin_up - fbfin) * c.dzt2r[km - 1];
-      if (owned) Sn[base + (size_t)(km - 1) * imt] = spart - ADV_Tz;
+    if (last) {  // bottom face of the column (tracer.F:1065); L.vb holds adv_vbt there
+      const double fbfin = L.vb * tt_c;
+      const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, km - 1);
+      if (owned) AT(Sn, km, 0) = spart - ADV_Tz;
     }
     // ---- roll ---------------------------------------------------------------------------
     rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
     fblo_up = fblo; afb_up = afb; dfb_up = dfb; dfbi_up = dfbi;
-    mc[0] = mc[1]; mc[1] = mc[2]; ms[0] = ms[1]; ms[1] = ms[2]; mn[0] = mn[1]; mn[1] = mn[2]; tc[0] = tc[1]; tc[1] = tc[2];
+    mc0 = mc1; mc1 = mc2; ms0 = ms1; ms1 = ms2; mn0 = mn1; mn1 = mn2; tc0 = tc1; tc1 = tc2;
+  };
+  Lvl A, B;
+  load_level(A, 1);
+  for (int s = 1; s <= km; s += 2) {
+    if (s + 1 <= km) load_level(B, s + 1);
+    level(A, s);
+    if (s + 1 <= km) {
+      if (s + 2 <= km) load_level(A, s + 2);
+      level(B, s + 1);
+    }
   }
 #undef LD
 #undef CF
-  (void)fbfin_up2;
+#undef AT
+#undef ATB
 }
 
 // ===========================================================================
@@ -297,41 +337,43 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const double *source = 0;
   if (c.src && c.itrc[n1 - 1] != 0) source = c.src + (size_t)(c.itrc[n1 - 1] - 1) * N3;
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)];
-  const double cstdyt2r = c.cstdyt2r[r - 1];
+  const double cstdyt2r = kload(c.cstdyt2r, r - 1);
   const size_t rowstride = (size_t)imt * km;
-  const size_t base = X3(i, 1, r);
+  const size_t rbase = X3(1, 1, r);   // wave-uniform part of every address; the lane adds its 32-bit column offset
+  const unsigned lb = (unsigned)(i - 1) * 8u;
+#define ATB(p) (*(decltype(p))((const char *)(p) + lb))
+#define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
   const double topbc = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt], botbc = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt];
   const double aidif = c.aidif, eps = 1.e-30;
   const int kb = imax(2, kz);
   double bet = 0.0, zprev = 0.0, cprev = 0.0;
   const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
   for (int k = 1; k <= km; ++k) {
-    const size_t q = base + (size_t)(k - 1) * imt;
-    const double m_c = tm[q], m_s = tm[q - rowstride], m_n = tm[q + rowstride];
-    const double t_c = tt[q], t_s = tt[q - rowstride], t_n = tt[q + rowstride];
-    const double vn = c.tot_n[q], vs = c.tot_n[q - rowstride];
+    const double m_c = AT(tm, k, 0), m_s = AT(tm, k, -1), m_n = AT(tm, k, 1);
+    const double t_c = AT(tt, k, 0), t_s = AT(tt, k, -1), t_n = AT(tt, k, 1);
+    const double vn = AT(c.tot_n, k, 0), vs = AT(c.tot_n, k, -1);
     const double mk = (k <= kz) ? 1.0 : 0.0, mk_s = (k <= kz_s) ? 1.0 : 0.0;
     const double lo_n = upstream(vn, m_c, m_n), lo_s = upstream(vs, m_s, m_c);
     const double f_n = vn * (t_c + t_n) - lo_n;
     const double f_s = (r - 1 == 1) ? 0.0 : vs * (t_s + t_c) - lo_s;
-    const double rp0 = RpY[q], rm0 = RmY[q], rps = RpY[q - rowstride], rms = RmY[q - rowstride];
-    const double rpn = RpY[q + rowstride], rmn = RmY[q + rowstride];
-    const double fn_n = (limited(dmin(rpn, rm0), dmin(rp0, rmn), f_n) + lo_n) * mk;
-    const double fn_s = (limited(dmin(rp0, rms), dmin(rps, rm0), f_s) + lo_s) * mk_s;
+    const double rp0 = AT(RpY, k, 0), rm0 = AT(RmY, k, 0), rps = AT(RpY, k, -1), rms = AT(RmY, k, -1);
+    const double rpn = AT(RpY, k, 1), rmn = AT(RmY, k, 1);
+    const double fn_n = (limited(fmn(rpn, rm0), fmn(rp0, rmn), f_n) + lo_n) * mk;
+    const double fn_s = (limited(fmn(rp0, rms), fmn(rps, rm0), f_s) + lo_s) * mk_s;
     const double ADV_Ty = (fn_n - fn_s) * cstdyt2r;
-    const double tdt = c.c2dtts * c.dtxcel[k - 1];
-    const double z = m_c + tdt * (Sn[q] - ADV_Ty + (source ? source[q] : 0.0)) * mk;
+    const double tdt = c.c2dtts * kload(c.dtxcel, k - 1);
+    const double z = m_c + tdt * (AT(Sn, k, 0) - ADV_Ty + (source ? AT(source, k, 0) : 0.0)) * mk;
     // Thomas forward sweep, invtri.F:57-100
     const int km1 = imax(1, k - 1), kp1 = imin(k + 1, km);
-    const double factu = c.dztur[k - 1] * tdt * aidif, factl = c.dztlr[k - 1] * tdt * aidif;
-    double a = -c.diff_cbt[base + (size_t)(km1 - 1) * imt] * factu * mk;
-    double cc = -c.diff_cbt[q] * factl * ((kp1 <= kz) ? 1.0 : 0.0);
+    const double factu = kload(c.dztur, k - 1) * tdt * aidif, factl = kload(c.dztlr, k - 1) * tdt * aidif;
+    double a = -AT(c.diff_cbt, km1, 0) * factu * mk;
+    double cc = -AT(c.diff_cbt, k, 0) * factl * ((kp1 <= kz) ? 1.0 : 0.0);
     double f = z * mk;
     if (k == 1) a = 0.0;
     if (k == km) cc = 0.0;
     const double b = 1.0 - a - cc;
-    if (k == 1) f = z + topbc * tdt * c.dztr[0] * aidif * mk;
-    if (k == kb) f = z - botbc * tdt * c.dztr[k - 1] * aidif * mk;
+    if (k == 1) f = z + topbc * tdt * kload(c.dztr, 0) * aidif * mk;
+    if (k == kb) f = z - botbc * tdt * kload(c.dztr, k - 1) * aidif * mk;
     double znew;
     if (k == 1) {
       bet = mk / (b + eps);
@@ -342,7 +384,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
       bet = mk / (b - a * e + eps);
       znew = (f - a * zprev) * bet;
     }
-    tp[q] = znew;
+    AT(tp, k, 0) = znew;
     zprev = znew;
     cprev = cc;
   }
@@ -350,13 +392,14 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   double znext = zprev;
   if (ic) tp[X3(ic, km, r)] = znext;
   for (int k = km - 1; k >= 1; --k) {
-    const size_t q = base + (size_t)(k - 1) * imt;
-    const double zk = tp[q] - ework[(size_t)(k + 1) * 64 + lane] * znext;
-    tp[q] = zk;
+    const double zk = AT(tp, k, 0) - ework[(size_t)(k + 1) * 64 + lane] * znext;
+    AT(tp, k, 0) = zk;
     if (ic) tp[X3(ic, k, r)] = zk;
     znext = zk;
   }
 }
+#undef AT
+#undef ATB
 #endif  // __HIPCC__
 
 }  // namespace uvic

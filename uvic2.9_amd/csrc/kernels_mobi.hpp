@@ -678,7 +678,7 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
 #undef YPUT
 #undef YGET
   (void)dic13flag; (void)doc13flag; (void)phytc13flag; (void)zoopc13flag; (void)detrc13flag; (void)diazc13flag;
-#define BOUT(m, v) bioout[(m)-1] = (v)-BIN(m)
+#define BOUT(m, v) bioout[(m)-1] = (v) /* the new pools; the caller forms the tendency (mobi.F:3255-3313) */
   BOUT(MI::po4, biopo4); BOUT(MI::phyt, biophyt); BOUT(MI::phyt_phos, biophyt_phos); BOUT(MI::zoop, biozoop);
   BOUT(MI::detr, biodetr); BOUT(MI::detr_phos, biodetr_phos); BOUT(MI::dic, biodic); BOUT(MI::dop, biodop);
   BOUT(MI::no3, biono3); BOUT(MI::don, biodon); BOUT(MI::diaz, biodiaz); BOUT(MI::din15, biodin15);
@@ -832,7 +832,9 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     mobi_src(T, P, S, bioin, PRE(MP_BCT), impo, impo_phos, P->wd[k - 1], PRE(MP_NUD), P->nudop0, P->nudon0, snpzd, PRE(MP_BCTZ),
              rn15impo, rc13impo, PRE(MP_AC13B), impofe, PRE(MP_O2F), PRE(MP_AOUT), PRE(MP_AVEJ), PRE(MP_AVEJD), &so);
     expo = so.expo; expo_phos = so.expo_phos; rn15expo = so.rn15expo; rc13expo = so.rc13expo; expofe = so.expofe;
-    _Pragma("unroll") for (int m = 0; m < MI::count; ++m) snpzd[m] = snpzd[m] * S.rdtts;
+    // tendency = (new pool - clamped input) / twodt; the input is read again rather than kept in
+    // registers through the sub-steps
+    _Pragma("unroll") for (int m = 0; m < MI::count; ++m) snpzd[m] = (snpzd[m] - TNC(k, m + 1)) * S.rdtts;
     expofe = expofe * S.rnbio;
     expo = expo * S.rnbio;
     expo_phos = expo_phos * S.rnbio;
@@ -847,7 +849,7 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     // calcite production of the column, mobi.F:1228-1266 (bioin is clamped now)
     const double dprca = rcalpro_k * 1e-3;
     const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
-    double rtdic13 = dmax(bioin[MI::dic13 - 1], r13min) / dmax(dic_in, UV_TRCMIN);
+    double rtdic13 = dmax(TNC(k, MI::dic13), r13min) / dmax(dic_in, UV_TRCMIN);
     rtdic13 = dmin(rtdic13, 2. * UV_RC13STD / (1 + UV_RC13STD));
     rtdic13 = dmax(rtdic13, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
     if (k <= kmx) {   // levels below the sea floor are walked only for the team's barriers

@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
-  if (blk >= nblk || !col_decode(c, g, blk * 4 + threadIdx.y, r, n1, i0, i1)) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row, tracer and segment live in scalar registers
+  if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
   colfct_wave(c, cf, S, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
@@ -110,8 +111,9 @@ __global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
-  if (blk >= nblk || !col_decode(c, g, blk * 4 + threadIdx.y, r, n1, i0, i1)) return;
-  colupd_wave(c, S, lds + (size_t)threadIdx.y * (c.km + 1) * 64, r, n1, i0, i1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
+  colupd_wave(c, S, lds + (size_t)wv * (c.km + 1) * 64, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
