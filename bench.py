@@ -50,6 +50,22 @@ def kernel_alg_bytes(name, nt, nsrc):
     return None
 
 
+def pmc_traffic(kernel, workload_ok):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of tools_profile_round.sh
+    (FETCH_SIZE + WRITE_SIZE in separate passes, corrected by the 8-B-per-lane calibration of
+    tools/calib_traffic.hip as MI355X_MICROARCH.md prescribes).  The counters cannot be read from
+    inside this process: the figure comes from the committed summary of the SAME command
+    (profiles/traffic.json, or $UVIC_TRAFFIC_JSON) and is null for any other workload."""
+    path = os.environ.get("UVIC_TRAFFIC_JSON") or str(ROOT / "profiles" / "traffic.json")
+    if not workload_ok or not os.path.exists(path):
+        return None, None
+    try:
+        ent = json.load(open(path))["kernels"].get("k_" + kernel)
+        return (ent or {}).get("total"), os.path.relpath(path, ROOT)
+    except (ValueError, KeyError, OSError):
+        return None, None
+
+
 def cpu_baseline(ocean, to, so, c, src, budget_s=20.0):
     """Time the CPU path on this box's host cores, 1 core, bounded sample."""
     import oracle_c
@@ -158,8 +174,18 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
+    t_submit = time.perf_counter() - t0      # host time to enqueue the K steps
     barrier()
     el = time.perf_counter() - t0
+    # the same K steps once more with HIP events around every kernel, each on the stream it is launched
+    # on (recording ~17 events per step costs a few per cent, so it is kept out of `value`)
+    m.profile_live(True)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    barrier()
+    el_instr = time.perf_counter() - t1
+    live = m.profile_read()
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -172,15 +198,18 @@ def main():
         # restore a sane state (the timed loop may have drifted far) and profile per kernel
         m.load_ocean(ocean, to, so, c, src=src)
         shard.apply(m)
-        prof = m.profile(nrep=10)
+        iso = m.profile(nrep=10)   # the same kernels back to back on one stream, nothing overlapped
+        prof = live
         names = [k for k in prof if kernel_alg_bytes(k, nt, nsrc)]
         dom = max(names, key=lambda k: prof[k])
         local_units = imt * jmt * km * shard.nt_local
         ach = kernel_alg_bytes(dom, nt, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
         step_gbs = b_alg(nt, nsrc) * value / 1e9
+        traffic, traffic_src = pmc_traffic(dom, world == 1 and a.cfg == "c30" and a.grid == "102x102x19")
         out = {
             "metric": "tracer-cell updates/s (imt*jmt*km*nt)", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3,
+            "ms_per_step_instrumented": el_instr / a.steps * 1e3, "host_submit_ms_per_step": t_submit / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
@@ -188,8 +217,12 @@ def main():
                                    f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",
                        "grid": a.grid, "nt": nt, "parallelism": f"tracer-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "dominant HBM-side (transport) kernel; kernel_ms are HIP-event means over a second, instrumented "
+                                 "pass of the same K steps (ms_per_step_instrumented), where the MOBI kernels of the next "
+                                 "step run beside the transport kernels on the side stream",
                          "kernel_ms": {k: round(v, 5) for k, v in prof.items()},
+                         "kernel_ms_isolated": {k: round(v, 5) for k, v in iso.items()},
                          "alg_bytes_per_cell_update": kernel_alg_bytes(dom, nt, nsrc)},
             "step_hbm": {"alg_bytes_per_cell_update": b_alg(nt, nsrc), "achieved_GBs": step_gbs,
                          "frac_of_peak": step_gbs / HBM_PEAK_GBS},

@@ -203,6 +203,11 @@ int uvic_gpu_convect_async(uvic_gpu *h);
  * milliseconds of every kernel, measured with HIP events on the launch stream;
  * names[i] points to static strings.  Used by bench.py for the roofline. */
 int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const char **names, double *mean_ms, int *nkernels);
+/* the same measurement inside the caller's own time loop: between uvic_gpu_profile_live(h, 1) and
+ * uvic_gpu_profile_read every kernel launch of the handle (main and side stream) is bracketed by
+ * HIP events on its stream; _read synchronises, returns the mean per kernel and switches it off. */
+int uvic_gpu_profile_live(uvic_gpu *h, int on);
+int uvic_gpu_profile_read(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels);
 
 #ifdef __cplusplus
 }

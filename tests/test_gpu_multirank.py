@@ -1,0 +1,64 @@
+"""The N>1 schedule (tracer-index shards, exchange of t(tau+1), replicated convection, MOBI one
+step ahead) with two ranks sharing ONE GPU: gloo stands in for RCCL (which refuses two ranks on
+one device), everything else is the path bench.py --gpus N runs.  Result after several steps,
+including a mixing step, must equal the unsharded run bit for bit."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+pytestmark = pytest.mark.gpu
+NSTEP = 5
+
+
+def _run(cfg_name, imt, jmt, km, world, rank):
+    from uvic29_amd import OPTION_SETS, synthetic
+    from uvic29_amd.parallel import TracerShard
+    from uvic29_amd.tracer import TimeLoop, TracerModel
+    cfg = OPTION_SETS[cfg_name]
+    ocean = synthetic.make_ocean(cfg, imt, jmt, km)
+    to, so, c = synthetic.load_eos(km)
+    shard = TracerShard(cfg.nt, world, rank)
+    if shard.nt_model != cfg.nt:
+        ocean = synthetic.pad_tracers(ocean, shard.nt_model)
+    m = TracerModel(imt, jmt, km, shard.nt_model, cfg.nsrc, cfg.ntnpzd, device=0)
+    m.load_ocean(ocean, to, so, c)
+    if cfg.ntnpzd:
+        m.set_mobi(ocean)
+    shard.apply(m)
+    loop = TimeLoop(m, ocean.params.dtts, nmix=3, shard=shard if world > 1 else None)
+    for _ in range(NSTEP):
+        loop.step()
+    m.sync()
+    out = m.download("t_tau")[..., :cfg.nt].copy()
+    m.close()
+    return out
+
+
+def _worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    for p in (ROOT,):
+        sys.path.insert(0, str(p))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = _run("c30", 14, 14, 6, world, rank)
+    np.save(f"{out_path}.{rank}.npy", got)
+    if rank == 0:
+        np.save(f"{out_path}.single.npy", _run("c30", 14, 14, 6, 1, 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "mr")
+    mp.spawn(_worker, args=(2, 29533, out), nprocs=2, join=True)
+    ref = np.load(f"{out}.single.npy")
+    assert np.isfinite(ref).all()
+    for r in range(2):
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, 1:-1], ref[:, :, 1:-1]), f"rank {r}"

@@ -290,8 +290,9 @@ struct uvic_gpu {
   size_t fct_lds, upd_lds;
   // profiling
   bool profiling;
-  std::vector<hipEvent_t> ev;
-  std::vector<const char *> ev_names;
+  std::vector<hipEvent_t> ev[2];            // [0] main stream, [1] side stream
+  std::vector<const char *> ev_names[2];
+  std::vector<hipEvent_t> ev_pool;
 };
 
 static int64_t plane(const uvic_dims &d, Kind k) {
@@ -453,7 +454,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
     (void)hipFree(h->mobi_st.work_side);
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
   }
-  for (auto e : h->ev) (void)hipEventDestroy(e);
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
   (void)hipEventDestroy(h->ev_src_next);
@@ -564,14 +565,20 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
 }
 
 // -- launch helpers ------------------------------------------------------------
-static void mark(uvic_gpu *h, const char *name) {
+static void mark_on(uvic_gpu *h, const char *name, int sid) {
   if (!h->profiling) return;
-  hipEvent_t e;
-  (void)hipEventCreate(&e);
-  (void)hipEventRecord(e, h->stream);
-  h->ev.push_back(e);
-  h->ev_names.push_back(name);
+  const size_t used = h->ev[0].size() + h->ev[1].size();
+  if (used >= h->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    h->ev_pool.push_back(e);
+  }
+  hipEvent_t e = h->ev_pool[used];
+  (void)hipEventRecord(e, sid ? h->side : h->stream);
+  h->ev[sid].push_back(e);
+  h->ev_names[sid].push_back(name);
 }
+static void mark(uvic_gpu *h, const char *name) { mark_on(h, name, 0); }
 static unsigned cell_blocks(const uvic_gpu *h, int bs) {
   const long long n = (long long)h->d.imt * h->d.km * h->d.jmt;
   return (unsigned)((n + bs - 1) / bs);
@@ -756,12 +763,16 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   c.c2dtts = c2dtts_next;
   if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_step_begin, 0));
+  mark_on(h, "begin", 1);
   hipLaunchKernelGGL(k_mobi_pre, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
+  mark_on(h, "mobi_pre", 1);
   if (h->mobi_team)
     hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->side, c, m);
   else
     hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
+  mark_on(h, "mobi", 1);
   hipLaunchKernelGGL(k_mobi_post, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
+  mark_on(h, "mobi_post", 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev_src_next, h->side));
   h->prefetch_pending = true;
@@ -810,33 +821,26 @@ extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   return 0;
 }
 
-extern "C" int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
-  if (!h || !names || !mean_ms || !nkernels) return fail_msg("uvic_gpu_profile: null argument");
-  HIPCHK(hipSetDevice(h->device));
-  for (auto e : h->ev) (void)hipEventDestroy(e);
-  h->ev.clear();
-  h->ev_names.clear();
-  h->profiling = true;
-  int rc = 0;
-  for (int r = 0; r < nrep && !rc; ++r) {
-    rc = launch_isopyc(h);
-    if (!rc) rc = launch_tracer(h);
-  }
-  h->profiling = false;
-  if (rc) return rc;
+static void profile_reset(uvic_gpu *h) {
+  for (int q = 0; q < 2; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
+}
+// mean duration per kernel name from the recorded events (consecutive events of one stream)
+static int profile_collect(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
+  HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<KernelStat> st;
-  for (size_t e = 1; e < h->ev.size(); ++e) {
-    if (strcmp(h->ev_names[e], "begin") == 0) continue;
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev[e - 1], h->ev[e]));
-    bool found = false;
-    for (auto &s : st)
-      if (strcmp(s.name, h->ev_names[e]) == 0) {
-        s.ms += ms; s.calls++; found = true;
-      }
-    if (!found) st.push_back({h->ev_names[e], (double)ms, 1});
-  }
+  for (int q = 0; q < 2; ++q)
+    for (size_t e = 1; e < h->ev[q].size(); ++e) {
+      if (strcmp(h->ev_names[q][e], "begin") == 0) continue;
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, h->ev[q][e - 1], h->ev[q][e]));
+      bool found = false;
+      for (auto &s : st)
+        if (strcmp(s.name, h->ev_names[q][e]) == 0) {
+          s.ms += ms; s.calls++; found = true;
+        }
+      if (!found) st.push_back({h->ev_names[q][e], (double)ms, 1});
+    }
   int n = 0;
   for (auto &s : st) {
     if (n >= max_kernels) break;
@@ -845,7 +849,37 @@ extern "C" int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const ch
     ++n;
   }
   *nkernels = n;
+  profile_reset(h);
   return 0;
+}
+extern "C" int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
+  if (!h || !names || !mean_ms || !nkernels) return fail_msg("uvic_gpu_profile: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  profile_reset(h);
+  h->profiling = true;
+  int rc = 0;
+  for (int r = 0; r < nrep && !rc; ++r) {
+    rc = launch_isopyc(h);
+    if (!rc) rc = launch_tracer(h);
+  }
+  h->profiling = false;
+  if (rc) return rc;
+  return profile_collect(h, max_kernels, names, mean_ms, nkernels);
+}
+// live form: events are recorded around every kernel of the caller's own time loop (both streams)
+// from uvic_gpu_profile_live(h, 1) until uvic_gpu_profile_read, which returns the means and stops
+extern "C" int uvic_gpu_profile_live(uvic_gpu *h, int on) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  profile_reset(h);
+  h->profiling = on != 0;
+  return 0;
+}
+extern "C" int uvic_gpu_profile_read(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
+  if (!h || !names || !mean_ms || !nkernels) return fail_msg("uvic_gpu_profile_read: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  h->profiling = false;
+  return profile_collect(h, max_kernels, names, mean_ms, nkernels);
 }
 
 // -- MOBI parameters -------------------------------------------------------------

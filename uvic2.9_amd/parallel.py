@@ -76,5 +76,13 @@ class TracerShard:
         per = full.numel() // self.world
         mine = full[self.rank * per:(self.rank + 1) * per]
         with torch.cuda.stream(self._stream):
-            dist.all_gather_into_tensor(full, mine)
+            if dist.get_backend() == "nccl":       # RCCL, in place on the device buffer, on the library's stream
+                dist.all_gather_into_tensor(full, mine)
+            else:
+                # rehearsal backend (gloo has no device all-gather): staged through the host.  Used by
+                # tests/test_gpu_multirank.py to run the N>1 schedule with several ranks on ONE GPU.
+                self._stream.synchronize()
+                host = torch.empty(full.numel(), dtype=full.dtype)
+                dist.all_gather_into_tensor(host, mine.cpu())
+                full.copy_(host)
         check(model.lib.uvic_gpu_convect_async(model.h), "convect_async")

@@ -198,6 +198,18 @@ class TracerModel:
         return {names[i].decode(): ms[i] for i in range(n.value)}
 
 
+    def profile_live(self, on=True):
+        """Bracket every kernel of the following steps with HIP events (see profile_read)."""
+        check(self.lib.uvic_gpu_profile_live(self.h, 1 if on else 0), "profile_live")
+
+    def profile_read(self):
+        names = (ctypes.c_char_p * 32)()
+        ms = (ctypes.c_double * 32)()
+        n = ctypes.c_int()
+        check(self.lib.uvic_gpu_profile_read(self.h, 32, names, ms, ctypes.byref(n)), "profile_read")
+        return {names[i].decode(): ms[i] for i in range(n.value)}
+
+
 class TimeLoop:
     """The ocean time-step schedule of `mom` for a device-resident model
     (/root/reference/source/mom/mom.F:108-148): leapfrog steps with c2dtts = 2*dtts and a
