@@ -151,6 +151,7 @@ __device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..
 // ===========================================================================
 // pass A
 // ===========================================================================
+template <bool PREFETCH>
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
                                             int r, int n1, int i0, int i1) {
   UV_DIMS(c);
@@ -300,14 +301,22 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     fblo_up = fblo; afb_up = afb; dfb_up = dfb; dfbi_up = dfbi;
     mc0 = mc1; mc1 = mc2; ms0 = ms1; ms1 = ms2; mn0 = mn1; mn1 = mn2; tc0 = tc1; tc1 = tc2;
   };
-  Lvl A, B;
-  load_level(A, 1);
-  for (int s = 1; s <= km; s += 2) {
-    if (s + 1 <= km) load_level(B, s + 1);
-    level(A, s);
-    if (s + 1 <= km) {
-      if (s + 2 <= km) load_level(A, s + 2);
-      level(B, s + 1);
+  if (PREFETCH) {   // ~250 VGPRs, two waves per SIMD
+    Lvl A, B;
+    load_level(A, 1);
+    for (int s = 1; s <= km; s += 2) {
+      if (s + 1 <= km) load_level(B, s + 1);
+      level(A, s);
+      if (s + 1 <= km) {
+        if (s + 2 <= km) load_level(A, s + 2);
+        level(B, s + 1);
+      }
+    }
+  } else {          // ~150 VGPRs, three waves per SIMD (or two beside a MOBI team wave) cover the latency instead
+    for (int s = 1; s <= km; ++s) {
+      Lvl A;
+      load_level(A, s);
+      level(A, s);
     }
   }
 #undef LD

@@ -79,6 +79,10 @@ struct MI {
   enum : int { po4 = 1, phyt = 2, phyt_phos = 3, zoop = 4, detr = 5, detr_phos = 6, dic = 7, dic13 = 8, phytc13 = 9, zoopc13 = 10, detrc13 = 11, doc13 = 12, diazc13 = 13, dop = 14, no3 = 15, don = 16, diaz = 17, din15 = 18, don15 = 19, phytn15 = 20, zoopn15 = 21, detrn15 = 22, diazn15 = 23, dfe = 24, detrfe = 25, count = 25 };
 };
 
+// which wave of a team advances (and stores the tendency of) which pool: 0 nutrients and producers,
+// 1 zooplankton, detritus, iron, 2 the 15N pools, 3 the 13C pools
+static constexpr int MOBI_OWNER[MI::count] = {0, 0, 0, 1, 1, 1, 0, 3, 3, 3, 3, 3, 3, 0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 1, 1};
+
 namespace uvic {
 UVIC_DEV double flag01(double x) { return 0.5 + copysign(0.5, x); }
 UVIC_DEV double sq(double x) { return x * x; }
@@ -667,10 +671,6 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
     TQ(7)
 #undef TQ
   }
-  if (Team::team && Team::role == 0) {  // the writer needs every pool once more, after the last sub-step
-    double *yb = T.xs + (size_t)2 * UV_MOBI_XN * 64 + (size_t)((T.xc - 1u) & 1u) * UV_MOBI_YN * 64 + T.lane;
-    YB(YGET) YC(YGET) YD(YGET)
-  }
 #undef YA
 #undef YB
 #undef YC
@@ -808,16 +808,17 @@ template <class Team>
 UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, int i, int j, bool live, int kmax) {
   UV_MOBI_LOCALS(c, M);
   const int kmx = live ? c.kmt[ij] : 0;
-  const bool writer = live && Team::role == 0;  // in a team only the wave of role 0 stores
   double *src = const_cast<double *>(c.src);
   double sink = 0.0;
-  // every thread of a team walks the same loops (workgroup barriers inside): threads that have
-  // nothing to store (other waves, land, levels below the sea floor) write into `sink`
+  // every thread of a team walks the same loops (workgroup barriers inside); threads with nothing to
+  // store (land, levels below the sea floor) write into `sink`.  In a team each wave stores the
+  // tendencies of the pools it owns and a share of the hand-over planes.
+#define MINE(r) (!Team::team || Team::role == (r))
   double expo = 0.0, impo, expo_phos = 0.0, impo_phos, prca = 0.0;
   double rn15impo, rn15expo = 0.0, rc13impo, rc13expo = 0.0, prca13 = 0.0, expofe = 0.0, impofe;
   double snpzd[MI::count], bioin[MI::count];
   for (int k = 1; k <= kmax; ++k) {
-    const bool store = writer && k <= kmx;
+    const bool store = live && k <= kmx;
 #define OUT(ptr) (*(store ? (ptr) : &sink))
     rn15impo = rn15expo;
     const double dic_in = TM(k, P->idic);
@@ -834,7 +835,8 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     expo = so.expo; expo_phos = so.expo_phos; rn15expo = so.rn15expo; rc13expo = so.rc13expo; expofe = so.expofe;
     // tendency = (new pool - clamped input) / twodt; the input is read again rather than kept in
     // registers through the sub-steps
-    _Pragma("unroll") for (int m = 0; m < MI::count; ++m) snpzd[m] = (snpzd[m] - TNC(k, m + 1)) * S.rdtts;
+    _Pragma("unroll") for (int m = 0; m < MI::count; ++m)
+      if (MINE(MOBI_OWNER[m])) snpzd[m] = (snpzd[m] - TNC(k, m + 1)) * S.rdtts;
     expofe = expofe * S.rnbio;
     expo = expo * S.rnbio;
     expo_phos = expo_phos * S.rnbio;
@@ -843,9 +845,10 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     const double rcalpro_k = so.calpro * S.rnbio;
     // raw source terms into the slot of each MOBI tracer (mobi.F:1149-1205) and what the cell pass needs
     _Pragma("unroll") for (int m = 1; m <= MI::count; ++m)
-      OUT(src + X3(i, k, j) + (size_t)(P->slot_of_mobi[m - 1] - 1) * N3) = snpzd[m - 1];
-    OUT(&AUX(MA_EXPO)) = expo; OUT(&AUX(MA_EXPOP)) = expo_phos; OUT(&AUX(MA_RN15)) = rn15expo; OUT(&AUX(MA_RC13)) = rc13expo;
-    OUT(&AUX(MA_CALPRO)) = rcalpro_k; OUT(&AUX(MA_NFIX)) = so.nfix;
+      if (MINE(MOBI_OWNER[m - 1])) OUT(src + X3(i, k, j) + (size_t)(P->slot_of_mobi[m - 1] - 1) * N3) = snpzd[m - 1];
+    if (MINE(1)) { OUT(&AUX(MA_EXPO)) = expo; OUT(&AUX(MA_EXPOP)) = expo_phos; OUT(&AUX(MA_CALPRO)) = rcalpro_k; OUT(&AUX(MA_NFIX)) = so.nfix; }
+    if (MINE(2)) OUT(&AUX(MA_RN15)) = rn15expo;
+    if (MINE(3)) OUT(&AUX(MA_RC13)) = rc13expo;
     // calcite production of the column, mobi.F:1228-1266 (bioin is clamped now)
     const double dprca = rcalpro_k * 1e-3;
     const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
@@ -867,10 +870,11 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     expofe = expofe * dztk;
 #undef OUT
   }
-  if (writer) {
+  if (live && MINE(3)) {
     M.col[ij] = prca;
     M.col[NS + ij] = prca13;
   }
+#undef MINE
 }
 
 // one thread per column, all roles in the thread

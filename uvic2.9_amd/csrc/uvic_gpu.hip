@@ -98,13 +98,14 @@ __global__ void __launch_bounds__(256) k_coef(const uvic_ctx c, double *cf) {
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
   coef_cell(c, cf, i, k, j);
 }
+template <bool PREFETCH>
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row, tracer and segment live in scalar registers
   if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
-  colfct_wave(c, cf, S, r, n1, i0, i1);
+  colfct_wave<PREFETCH>(c, cf, S, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -175,7 +176,17 @@ __device__ __forceinline__ void mobi_team_role(const uvic_ctx &c, const mobi_dev
            clock64() - tk0, T.tq[0], T.tq[1], T.tq[2], T.tq[3], T.tq[4], T.tq[5], T.tq[6], T.tq[7]);
 #endif
 }
-__global__ void __launch_bounds__(256) k_mobi_team(const uvic_ctx c, const mobi_dev m) {
+#ifndef UV_TEAM_WAVES_PER_EU
+#define UV_TEAM_WAVES_PER_EU 3
+#endif
+#if UV_TEAM_WAVES_PER_EU > 0
+#define UV_TEAM_OCC __attribute__((amdgpu_waves_per_eu(UV_TEAM_WAVES_PER_EU, UV_TEAM_WAVES_PER_EU)))
+#else
+#define UV_TEAM_OCC
+#endif
+// register budget: the team's waves are resident for the whole MOBI pass on a side stream, so what
+// matters is how many transport waves still fit beside one of them on a SIMD
+__global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c, const mobi_dev m) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * 64 + threadIdx.x;
   int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -281,6 +292,7 @@ struct uvic_gpu {
   bool have_mobi;
   double mobi_dtnpzd;
   bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
+  bool col_prefetch;  // pass A of the column kernels with the level-ahead register set (UVIC_COL_PREFETCH=1)
   // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
   hipStream_t side;
   hipEvent_t ev_step_begin, ev_src_next;
@@ -371,6 +383,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->src_alt = nullptr;
   h->mobi_team = true;
   if (const char *e = getenv("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
+  h->col_prefetch = false;
+  if (const char *e = getenv("UVIC_COL_PREFETCH")) h->col_prefetch = atoi(e) != 0;
   h->prefetch_pending = h->src_from_prefetch = h->mixing = false;
   for (int f = 0; f < UVIC_F_COUNT; ++f) {
     const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
@@ -622,7 +636,10 @@ static int launch_transport(uvic_gpu *h) {
     double *S = h->work[3];
     mark(h, "begin");
     const unsigned na = (unsigned)((((a.total + 3) / 4 + 7) / 8) * 8), nb = (unsigned)((((b.total + 3) / 4 + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_colfct, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+    if (h->col_prefetch)
+      hipLaunchKernelGGL(k_colfct<true>, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+    else
+      hipLaunchKernelGGL(k_colfct<false>, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
     mark(h, "colfct");
     if (h->src_from_prefetch) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
