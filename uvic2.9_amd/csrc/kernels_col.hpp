@@ -94,9 +94,10 @@ struct ColGrid {
 // Neighbour exchange by DPP whole-wave shifts (gfx9 `wave_shr:1` / `wave_shl:1`): one
 // v_mov_b32_dpp per dword at VALU latency instead of an LDS round trip (ds_bpermute) --
 // several of these sit on the dependency chain of every level.  The lane without a
-// source (lane 0 / lane 63) keeps its own value; those lanes are halo.
+// source (lane 0 / lane 63) reads zero (bound_ctrl, so no copy of the old value is needed);
+// those lanes are halo.
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
   const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
@@ -149,9 +150,14 @@ __device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..
 }
 
 // ===========================================================================
-// pass A
+// pass A, two sweeps down the column in one wave:
+//   D  all diffusive fluxes (19 folded coefficients per level) -> S = DIFF_Tx + DIFF_Ty + DIFF_Tz
+//   F  FCT advection in x and z, the limiter ratios of all three directions -> S -= ADV_Tx + ADV_Tz, R+-Y
+// Each sweep keeps only its own operands in registers (<= 128 VGPRs instead of 250 for the fused
+// form), so four waves share a SIMD: the kernel is bound by the dependent-issue latency of fp64
+// chains, which only more resident waves hide.  S makes the round trip through the cache (each
+// lane re-reads what it wrote).
 // ===========================================================================
-template <bool PREFETCH>
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
                                             int r, int n1, int i0, int i1) {
   UV_DIMS(c);
@@ -163,14 +169,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
   double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
   double *Sn = S + nloc * N3;
-  const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
-  const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
+  const int kz = c.kmt[X2(i, r)];
   const double cstr_r = kload(c.cstr, r - 1);
-  const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
-  const double cstdyt2r = kload(c.cstdyt2r, r - 1), cstdytr = kload(c.cstdytr, r - 1);
-  const double c2dtts = c.c2dtts;
-  const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
-  const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
   // addresses = wave-uniform pointer (scalar registers, scalar arithmetic) + the lane's 32-bit column offset
   const size_t rowstride = (size_t)imt * km;
   const size_t rbase = X3(1, 1, r);  // level k of row r starts at rbase + (k-1)*imt
@@ -179,144 +179,144 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 #define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
 #define LD(p, k, dj) AT(p, k, dj)
 #define CF(pl, k, dj) AT(cf + (size_t)(pl) * N3, k, dj)
-  const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
-  // Everything a level reads from memory is fetched one level ahead into the other of two
-  // register sets (A/B, the loop is unrolled by two), so a wave waits for memory once per level
-  // and the latency of its ~40 loads is covered by the arithmetic of the level before.
-  struct Lvl {
-    double mc2, ms2, mn2, tc2;   // t(tau-1) centre/south/north and t(tau) centre at level s+1
-    double t_s, t_n;             // t(tau) south/north at level s
-    double ve, vn, vs, vb;       // total velocities on the east, north, south and bottom faces of level s
-    double cf[CF_COUNT], cfs[5]; // folded coefficients of row r and the north-face ones of row r-1
-  };
-  auto load_level = [&](Lvl &L, int s) {
-    const int sp = (s >= km) ? km : s + 1;
-    L.mc2 = LD(tm, sp, 0); L.ms2 = LD(tm, sp, -1); L.mn2 = LD(tm, sp, 1); L.tc2 = LD(tt, sp, 0);
-    L.t_s = LD(tt, s, -1); L.t_n = LD(tt, s, 1);
-    L.ve = AT(c.tot_e, s, 0); L.vn = AT(c.tot_n, s, 0); L.vs = AT(c.tot_n, s, -1);
-    L.vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
-    _Pragma("unroll") for (int p = 0; p < CF_COUNT; ++p) L.cf[p] = CF(p, s, 0);
-    _Pragma("unroll") for (int p = 0; p < 5; ++p) L.cfs[p] = CF(CF_AN + p, s, -1);
-  };
-  // state carried from level to level
-  double mc0, mc1, ms0, ms1, mn0, mn1, tc0, tc1;   // levels s-1 and s of the windows
-  mc0 = mc1 = LD(tm, 1, 0); ms0 = ms1 = LD(tm, 1, -1); mn0 = mn1 = LD(tm, 1, 1);
-  tc0 = tc1 = LD(tt, 1, 0);
-  // surface faces
-  const double vb0 = ATB(c.adv_vbt + fbase);
-  double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
-  double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
-  double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
-  double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
-  double fbfin_up = vb0 * (tc1 + tc1);           // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
-  auto level = [&](const Lvl &L, int s) {
-    const bool last = (s == km);
-    const double mc2 = L.mc2, ms2 = L.ms2, mn2 = L.mn2, tc2 = L.tc2;
-    const double t_s = L.t_s, t_n = L.t_n;
-    const double mk = (s <= kz) ? 1.0 : 0.0;
-    // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
-    const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
-    const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
-    const double m_c = mc1, tt_c = tc1;
-    const double m_e = shfl_e(m_c), tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
-    // ---- advection, low order and raw antidiffusive (adv_flx:500-619) ----------
-    const double ve = L.ve, vn = L.vn, vs = L.vs;
-    const double felo = upstream(ve, m_c, m_e);
-    const double afe = ve * (tt_c + tt_e) - felo;
-    const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
-    const double fnlo_n = upstream(vn, m_c, mn1), fnlo_s = upstream(vs, ms1, m_c);
-    double fblo = 0.0, afb = 0.0;
-    if (!last) {
-      const double vb = L.vb;
-      fblo = vb * (mc2 + m_c) + dabs(vb) * (mc2 - m_c);
-      afb = vb * (tt_c + tc2) - fblo * mk;
-    }
-    const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
-    const double advz = (fblo_up - fblo) * kload(c.dzt2r, s - 1);
-    const double tlo = m_c - (c2dtts * kload(c.dtxcel, s - 1)) * (advx + advy + advz) * mk;
-    // ---- limiter ratios ---------------------------------------------------------
-    double rxp, rxm, ryp, rym, rzp, rzm;
-    {
-      const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
-      fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
-    }
-    {
-      const double afn_n = vn * (tt_c + t_n) - fnlo_n;
-      const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
-      fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
-                ryp, rym);
-    }
-    {
-      const double fxa = wet_up ? 0.5 * (tc0 + tt_c) : tlo;
-      const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
-      fct_ratio(fxa, fxb, tlo, c2dtts * kload(c.dzt2r, s - 1), afb, afb_up, mk, rzp, rzm);
-    }
-    if (owned) {
-      AT(RpY, s, 0) = ryp;
-      AT(RmY, s, 0) = rym;
-    }
-    // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
-    const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
-    const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
-    const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
-    // ---- diffusive fluxes (coefficients folded by coef_cell) ---------------------------
-    const double dz_up = (s > 1) ? mc0 - m_c : 0.0, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column
-    const double dze_up = shfl_e(dz_up), dze_dn = shfl_e(dz_dn);                                 // east column
-    const double dzs_up = (s > 1) ? ms0 - ms1 : 0.0, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row
-    const double dzn_up = (s > 1) ? mn0 - mn1 : 0.0, dzn_dn = (!last) ? mn1 - mn2 : 0.0;      // north row
-    const double dfe = L.cf[CF_AE] * (m_e - m_c) + L.cf[CF_CE + 0] * dz_up + L.cf[CF_CE + 1] * dze_up +
-                       L.cf[CF_CE + 2] * dz_dn + L.cf[CF_CE + 3] * dze_dn;
-    const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
-    const double dfn_n = L.cf[CF_AN] * (mn1 - m_c) + L.cf[CF_CN + 0] * dz_up + L.cf[CF_CN + 1] * dzn_up +
-                         L.cf[CF_CN + 2] * dz_dn + L.cf[CF_CN + 3] * dzn_dn;
-    const double dfn_s = L.cfs[0] * (m_c - ms1) + L.cfs[1] * dzs_up + L.cfs[2] * dz_up + L.cfs[3] * dzs_dn + L.cfs[4] * dz_dn;
-    const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
-    double dfb = 0.0, dfbi = 0.0;  // through the face below level s
-    if (!last) {
-      const double dx_c = m_e - m_c, dx_d = shfl_e(mc2) - mc2;   // T(i+1)-T(i) at levels s, s+1
-      const double dxw_c = shfl_w(dx_c), dxw_d = shfl_w(dx_d);   // T(i)-T(i-1)
-      dfb = L.cf[CF_BV] * (m_c - mc2);
-      dfbi = L.cf[CF_CBX + 0] * dxw_c + L.cf[CF_CBX + 1] * dx_c + L.cf[CF_CBX + 2] * dxw_d + L.cf[CF_CBX + 3] * dx_d +
-             L.cf[CF_CBY + 0] * (m_c - ms1) + L.cf[CF_CBY + 1] * (mn1 - m_c) + L.cf[CF_CBY + 2] * (mc2 - ms2) +
-             L.cf[CF_CBY + 3] * (mn2 - mc2);
-    }
-    if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
-    if (kz == 0 && s == 1) dfb_up = btf;
-    const double DIFF_Tz = (dfb_up - dfb) * kload(c.dztr, s - 1) + (dfbi_up - dfbi) * kload(c.dztr, s - 1);
-    const double spart = DIFF_Tx + DIFF_Ty + DIFF_Tz - ADV_Tx;
-    // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
-    if (s >= 2) {
-      const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
-      const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, s - 2);
-      if (owned) AT(Sn, s - 1, 0) = spart_prev - ADV_Tz;
-      fbfin_up = fbfin;
-    }
-    if (last) {  // bottom face of the column (tracer.F:1065); L.vb holds adv_vbt there
-      const double fbfin = L.vb * tt_c;
-      const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, km - 1);
-      if (owned) AT(Sn, km, 0) = spart - ADV_Tz;
-    }
-    // ---- roll ---------------------------------------------------------------------------
-    rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
-    fblo_up = fblo; afb_up = afb; dfb_up = dfb; dfbi_up = dfbi;
-    mc0 = mc1; mc1 = mc2; ms0 = ms1; ms1 = ms2; mn0 = mn1; mn1 = mn2; tc0 = tc1; tc1 = tc2;
-  };
-  if (PREFETCH) {   // ~250 VGPRs, two waves per SIMD
-    Lvl A, B;
-    load_level(A, 1);
-    for (int s = 1; s <= km; s += 2) {
-      if (s + 1 <= km) load_level(B, s + 1);
-      level(A, s);
-      if (s + 1 <= km) {
-        if (s + 2 <= km) load_level(A, s + 2);
-        level(B, s + 1);
-      }
-    }
-  } else {          // ~150 VGPRs, three waves per SIMD (or two beside a MOBI team wave) cover the latency instead
+  // ---- sweep D: diffusive fluxes (coefficients folded by coef_cell) -----------------------------
+  {
+    const double cstdxtr = cstr_r * c.dxtr[i - 1], cstdytr = kload(c.cstdytr, r - 1);
+    const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
+    const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
+    double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
+    double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
+    // differences that level s+1 needs again are handed down instead of being formed (and shuffled) twice:
+    // T(s)-T(s+1) of the own, east, south and north columns; T(i+1)-T(i) and T(i)-T(i-1) at level s+1
+    double dz_c = 0.0, dz_e = 0.0, dz_s = 0.0, dz_n = 0.0;
+    double dx_next = shfl_e(mc1) - mc1, dxw_next = shfl_w(dx_next);
     for (int s = 1; s <= km; ++s) {
-      Lvl A;
-      load_level(A, s);
-      level(A, s);
+      const bool last = (s == km);
+      const int sp = last ? km : s + 1;
+      const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1);
+      double cfc[CF_COUNT], cfs[5];
+      _Pragma("unroll") for (int p = 0; p < CF_COUNT; ++p) cfc[p] = CF(p, s, 0);
+      _Pragma("unroll") for (int p = 0; p < 5; ++p) cfs[p] = CF(CF_AN + p, s, -1);
+      const double m_c = mc1;
+      const double dz_up = dz_c, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column (dz_up = dz_dn of the level above, 0 at the top)
+      const double dze_up = dz_e, dze_dn = shfl_e(dz_dn);                   // east column
+      const double dzs_up = dz_s, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row
+      const double dzn_up = dz_n, dzn_dn = (!last) ? mn1 - mn2 : 0.0;      // north row
+      const double dx_c = dx_next, dx_d = shfl_e(mc2) - mc2;               // T(i+1)-T(i) at levels s, s+1
+      const double dxw_c = dxw_next, dxw_d = shfl_w(dx_d);                 // T(i)-T(i-1)
+      const double dfe = cfc[CF_AE] * dx_c + cfc[CF_CE + 0] * dz_up + cfc[CF_CE + 1] * dze_up + cfc[CF_CE + 2] * dz_dn +
+                         cfc[CF_CE + 3] * dze_dn;
+      const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
+      const double dfn_n = cfc[CF_AN] * (mn1 - m_c) + cfc[CF_CN + 0] * dz_up + cfc[CF_CN + 1] * dzn_up + cfc[CF_CN + 2] * dz_dn +
+                           cfc[CF_CN + 3] * dzn_dn;
+      const double dfn_s = cfs[0] * (m_c - ms1) + cfs[1] * dzs_up + cfs[2] * dz_up + cfs[3] * dzs_dn + cfs[4] * dz_dn;
+      const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
+      double dfb = 0.0, dfbi = 0.0;  // through the face below level s
+      if (!last) {
+        dfb = cfc[CF_BV] * (m_c - mc2);
+        dfbi = cfc[CF_CBX + 0] * dxw_c + cfc[CF_CBX + 1] * dx_c + cfc[CF_CBX + 2] * dxw_d + cfc[CF_CBX + 3] * dx_d +
+               cfc[CF_CBY + 0] * (m_c - ms1) + cfc[CF_CBY + 1] * (mn1 - m_c) + cfc[CF_CBY + 2] * (mc2 - ms2) +
+               cfc[CF_CBY + 3] * (mn2 - mc2);
+      }
+      if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
+      if (kz == 0 && s == 1) dfb_up = btf;
+      const double ddztr = kload(c.dztr, s - 1);
+      const double DIFF_Tz = (dfb_up - dfb) * ddztr + (dfbi_up - dfbi) * ddztr;
+      if (owned) AT(Sn, s, 0) = DIFF_Tx + DIFF_Ty + DIFF_Tz;
+      dfb_up = dfb; dfbi_up = dfbi;
+      dx_next = dx_d; dxw_next = dxw_d; dz_c = dz_dn; dz_e = dze_dn; dz_s = dzs_dn; dz_n = dzn_dn;
+      mc1 = mc2; ms1 = ms2; mn1 = mn2;
+    }
+  }
+  // ---- sweep F: flux-corrected advection -------------------------------------------------------
+  {
+    const int kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
+    const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
+    const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5;
+    const double cstdyt2r = kload(c.cstdyt2r, r - 1);
+    const double c2dtts = c.c2dtts;
+    const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
+    double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);
+    double tc0, tc1;                   // levels s-1 and s of t(tau)
+    tc0 = tc1 = LD(tt, 1, 0);
+    double me_next = shfl_e(mc1);
+    // surface faces
+    const double vb0 = ATB(c.adv_vbt + fbase);
+    double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
+    double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
+    double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
+    double fbfin_up = vb0 * (tc1 + tc1);           // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
+    for (int s = 1; s <= km; ++s) {
+      const bool last = (s == km);
+      const int sp = last ? km : s + 1;
+      const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1), tc2 = LD(tt, sp, 0);
+      const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
+      const double ve = AT(c.tot_e, s, 0), vn = AT(c.tot_n, s, 0), vs = AT(c.tot_n, s, -1);
+      const double vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
+      const double sdiff = AT(Sn, s, 0);             // written by sweep D (this lane)
+      const double mk = (s <= kz) ? 1.0 : 0.0;
+      // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
+      const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
+      const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
+      const double m_c = mc1, tt_c = tc1;
+      const double m_e = me_next, tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
+      // ---- low order and raw antidiffusive (adv_flx:500-619) ----------
+      const double felo = upstream(ve, m_c, m_e);
+      const double afe = ve * (tt_c + tt_e) - felo;
+      const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
+      const double fnlo_n = upstream(vn, m_c, mn1), fnlo_s = upstream(vs, ms1, m_c);
+      double fblo = 0.0, afb = 0.0;
+      if (!last) {
+        fblo = vb * (mc2 + m_c) + dabs(vb) * (mc2 - m_c);
+        afb = vb * (tt_c + tc2) - fblo * mk;
+      }
+      const double dzt2r_s = kload(c.dzt2r, s - 1);
+      const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
+      const double advz = (fblo_up - fblo) * dzt2r_s;
+      const double tlo = m_c - (c2dtts * kload(c.dtxcel, s - 1)) * (advx + advy + advz) * mk;
+      // ---- limiter ratios ---------------------------------------------------------
+      double rxp, rxm, ryp, rym, rzp, rzm;
+      {
+        const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
+        fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
+      }
+      {
+        const double afn_n = vn * (tt_c + t_n) - fnlo_n;
+        const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
+        fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
+                  ryp, rym);
+      }
+      {
+        const double fxa = wet_up ? 0.5 * (tc0 + tt_c) : tlo;
+        const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
+        fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up, mk, rzp, rzm);
+      }
+      if (owned) {
+        AT(RpY, s, 0) = ryp;
+        AT(RmY, s, 0) = rym;
+      }
+      // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
+      const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
+      const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
+      const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
+      const double spart = sdiff - ADV_Tx;
+      // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
+      if (s >= 2) {
+        const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
+        const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, s - 2);
+        if (owned) AT(Sn, s - 1, 0) = spart_prev - ADV_Tz;
+        fbfin_up = fbfin;
+      }
+      if (last) {  // bottom face of the column (tracer.F:1065); vb holds adv_vbt there
+        const double fbfin = vb * tt_c;
+        const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, km - 1);
+        if (owned) AT(Sn, km, 0) = spart - ADV_Tz;
+      }
+      // ---- roll ---------------------------------------------------------------------------
+      rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
+      fblo_up = fblo; afb_up = afb;
+      me_next = shfl_e(mc2);
+      mc1 = mc2; ms1 = ms2; mn1 = mn2; tc0 = tc1; tc1 = tc2;
     }
   }
 #undef LD

@@ -98,14 +98,13 @@ __global__ void __launch_bounds__(256) k_coef(const uvic_ctx c, double *cf) {
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
   coef_cell(c, cf, i, k, j);
 }
-template <bool PREFETCH>
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row, tracer and segment live in scalar registers
   if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
-  colfct_wave<PREFETCH>(c, cf, S, r, n1, i0, i1);
+  colfct_wave(c, cf, S, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -292,7 +291,6 @@ struct uvic_gpu {
   bool have_mobi;
   double mobi_dtnpzd;
   bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
-  bool col_prefetch;  // pass A of the column kernels with the level-ahead register set (UVIC_COL_PREFETCH=1)
   // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
   hipStream_t side;
   hipEvent_t ev_step_begin, ev_src_next;
@@ -383,8 +381,6 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->src_alt = nullptr;
   h->mobi_team = true;
   if (const char *e = getenv("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
-  h->col_prefetch = false;
-  if (const char *e = getenv("UVIC_COL_PREFETCH")) h->col_prefetch = atoi(e) != 0;
   h->prefetch_pending = h->src_from_prefetch = h->mixing = false;
   for (int f = 0; f < UVIC_F_COUNT; ++f) {
     const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
@@ -636,10 +632,7 @@ static int launch_transport(uvic_gpu *h) {
     double *S = h->work[3];
     mark(h, "begin");
     const unsigned na = (unsigned)((((a.total + 3) / 4 + 7) / 8) * 8), nb = (unsigned)((((b.total + 3) / 4 + 7) / 8) * 8);
-    if (h->col_prefetch)
-      hipLaunchKernelGGL(k_colfct<true>, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
-    else
-      hipLaunchKernelGGL(k_colfct<false>, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+    hipLaunchKernelGGL(k_colfct, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
     mark(h, "colfct");
     if (h->src_from_prefetch) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
