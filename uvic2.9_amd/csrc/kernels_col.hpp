@@ -113,6 +113,20 @@ __device__ __forceinline__ double shfl_e(double v) { return dpp_d<DPP_WAVE_SHL1>
 __device__ __forceinline__ double kload(const double *p, int idx) {
   return ((const __attribute__((address_space(4))) double *)p)[idx];
 }
+// A per-level metric table (km <= 64 entries) held one entry per lane and broadcast with v_readlane:
+// no memory latency on the level-to-level dependency chain (a scalar load there costs ~200 cycles,
+// twice that when its pointer has to be re-read from the kernel arguments first).
+struct LaneTable {
+  int lo, hi;
+  __device__ __forceinline__ void load(const double *p, int n) {
+    const int l = threadIdx.x & 63;
+    const double v = (l < n) ? kload(p, l) : 0.0;
+    lo = __double2loint(v); hi = __double2hiint(v);
+  }
+  __device__ __forceinline__ double at(int idx) const {   // idx wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(hi, idx), __builtin_amdgcn_readlane(lo, idx));
+  }
+};
 // v_max_f64 / v_min_f64: one instruction instead of compare + two selects (operands are never NaN here)
 __device__ __forceinline__ double fmx(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double fmn(double a, double b) { return __builtin_fmin(a, b); }
@@ -142,6 +156,19 @@ __device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, 
   i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
   return true;
 }
+// pass B order: latitude row fastest, so the four waves of a workgroup (and the workgroups next to it)
+// work on adjacent rows of ONE tracer: rows r-1, r, r+1 of t, R+-Y that a wave reads are the centre
+// rows of its neighbours and come from L1/L2 instead of being fetched three times
+__device__ __forceinline__ bool col_decode_rows(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
+  if (item >= g.total) return false;
+  r = g.r0 + item % g.nrows;
+  const int rest = item / g.nrows;
+  const int seg = rest % g.nseg;
+  n1 = c.n0 + rest / g.nseg + 1;
+  i0 = 2 + seg * COL_OWN;
+  i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
+  return true;
+}
 __device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..imt-1, cyclic
   const int p = imt - 2;
   int y = (x - 2) % p;
@@ -150,13 +177,7 @@ __device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..
 }
 
 // ===========================================================================
-// pass A, two sweeps down the column in one wave:
-//   D  all diffusive fluxes (19 folded coefficients per level) -> S = DIFF_Tx + DIFF_Ty + DIFF_Tz
-//   F  FCT advection in x and z, the limiter ratios of all three directions -> S -= ADV_Tx + ADV_Tz, R+-Y
-// Each sweep keeps only its own operands in registers (<= 128 VGPRs instead of 250 for the fused
-// form), so four waves share a SIMD: the kernel is bound by the dependent-issue latency of fp64
-// chains, which only more resident waves hide.  S makes the round trip through the cache (each
-// lane re-reads what it wrote).
+// pass A: one sweep down the column
 // ===========================================================================
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
                                             int r, int n1, int i0, int i1) {
@@ -169,8 +190,17 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
   double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
   double *Sn = S + nloc * N3;
-  const int kz = c.kmt[X2(i, r)];
+  // per-level metrics, one entry per lane, broadcast by v_readlane (no memory latency in the march)
+  LaneTable t_dzt2r, t_dtxcel, t_dztr;
+  t_dzt2r.load(c.dzt2r, km); t_dtxcel.load(c.dtxcel, km); t_dztr.load(c.dztr, km);
+  const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
+  const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
   const double cstr_r = kload(c.cstr, r - 1);
+  const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
+  const double cstdyt2r = kload(c.cstdyt2r, r - 1), cstdytr = kload(c.cstdytr, r - 1);
+  const double c2dtts = c.c2dtts;
+  const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
+  const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
   // addresses = wave-uniform pointer (scalar registers, scalar arithmetic) + the lane's 32-bit column offset
   const size_t rowstride = (size_t)imt * km;
   const size_t rbase = X3(1, 1, r);  // level k of row r starts at rbase + (k-1)*imt
@@ -179,145 +209,120 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 #define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
 #define LD(p, k, dj) AT(p, k, dj)
 #define CF(pl, k, dj) AT(cf + (size_t)(pl) * N3, k, dj)
-  // ---- sweep D: diffusive fluxes (coefficients folded by coef_cell) -----------------------------
-  {
-    const double cstdxtr = cstr_r * c.dxtr[i - 1], cstdytr = kload(c.cstdytr, r - 1);
-    const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
-    const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
-    double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
-    double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
-    // differences that level s+1 needs again are handed down instead of being formed (and shuffled) twice:
-    // T(s)-T(s+1) of the own, east, south and north columns; T(i+1)-T(i) and T(i)-T(i-1) at level s+1
-    double dz_c = 0.0, dz_e = 0.0, dz_s = 0.0, dz_n = 0.0;
-    double dx_next = shfl_e(mc1) - mc1, dxw_next = shfl_w(dx_next);
-    for (int s = 1; s <= km; ++s) {
-      const bool last = (s == km);
-      const int sp = last ? km : s + 1;
-      const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1);
-      double cfc[CF_COUNT], cfs[5];
-      _Pragma("unroll") for (int p = 0; p < CF_COUNT; ++p) cfc[p] = CF(p, s, 0);
-      _Pragma("unroll") for (int p = 0; p < 5; ++p) cfs[p] = CF(CF_AN + p, s, -1);
-      const double m_c = mc1;
-      const double dz_up = dz_c, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column (dz_up = dz_dn of the level above, 0 at the top)
-      const double dze_up = dz_e, dze_dn = shfl_e(dz_dn);                   // east column
-      const double dzs_up = dz_s, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row
-      const double dzn_up = dz_n, dzn_dn = (!last) ? mn1 - mn2 : 0.0;      // north row
-      const double dx_c = dx_next, dx_d = shfl_e(mc2) - mc2;               // T(i+1)-T(i) at levels s, s+1
-      const double dxw_c = dxw_next, dxw_d = shfl_w(dx_d);                 // T(i)-T(i-1)
-      const double dfe = cfc[CF_AE] * dx_c + cfc[CF_CE + 0] * dz_up + cfc[CF_CE + 1] * dze_up + cfc[CF_CE + 2] * dz_dn +
-                         cfc[CF_CE + 3] * dze_dn;
-      const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
-      const double dfn_n = cfc[CF_AN] * (mn1 - m_c) + cfc[CF_CN + 0] * dz_up + cfc[CF_CN + 1] * dzn_up + cfc[CF_CN + 2] * dz_dn +
-                           cfc[CF_CN + 3] * dzn_dn;
-      const double dfn_s = cfs[0] * (m_c - ms1) + cfs[1] * dzs_up + cfs[2] * dz_up + cfs[3] * dzs_dn + cfs[4] * dz_dn;
-      const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
-      double dfb = 0.0, dfbi = 0.0;  // through the face below level s
-      if (!last) {
-        dfb = cfc[CF_BV] * (m_c - mc2);
-        dfbi = cfc[CF_CBX + 0] * dxw_c + cfc[CF_CBX + 1] * dx_c + cfc[CF_CBX + 2] * dxw_d + cfc[CF_CBX + 3] * dx_d +
-               cfc[CF_CBY + 0] * (m_c - ms1) + cfc[CF_CBY + 1] * (mn1 - m_c) + cfc[CF_CBY + 2] * (mc2 - ms2) +
-               cfc[CF_CBY + 3] * (mn2 - mc2);
-      }
-      if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
-      if (kz == 0 && s == 1) dfb_up = btf;
-      const double ddztr = kload(c.dztr, s - 1);
-      const double DIFF_Tz = (dfb_up - dfb) * ddztr + (dfbi_up - dfbi) * ddztr;
-      if (owned) AT(Sn, s, 0) = DIFF_Tx + DIFF_Ty + DIFF_Tz;
-      dfb_up = dfb; dfbi_up = dfbi;
-      dx_next = dx_d; dxw_next = dxw_d; dz_c = dz_dn; dz_e = dze_dn; dz_s = dzs_dn; dz_n = dzn_dn;
-      mc1 = mc2; ms1 = ms2; mn1 = mn2;
+  const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
+  double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
+  double tc0, tc1;                                                        // levels s-1 and s of t(tau)
+  tc0 = tc1 = LD(tt, 1, 0);
+  // surface faces
+  const double vb0 = ATB(c.adv_vbt + fbase);
+  double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
+  double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
+  double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
+  double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
+  // differences that level s+1 needs again are handed down instead of being formed (and shuffled) twice:
+  // T(s)-T(s+1) of the own, east, south and north columns; T(i+1)-T(i) and T(i)-T(i-1) at level s+1
+  double me_next = shfl_e(mc1);
+  double dz_c = 0.0, dz_e = 0.0, dz_s = 0.0, dz_n = 0.0;
+  double dx_next = me_next - mc1, dxw_next = shfl_w(dx_next);
+  double fbfin_up = vb0 * (tc1 + tc1);           // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
+  for (int s = 1; s <= km; ++s) {
+    const bool last = (s == km);
+    const int sp = last ? km : s + 1;
+    const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1), tc2 = LD(tt, sp, 0);
+    const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
+    const double ve = AT(c.tot_e, s, 0), vn = AT(c.tot_n, s, 0), vs = AT(c.tot_n, s, -1);
+    const double vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
+    double cfc[CF_COUNT], cfs[5];   // folded coefficients of row r and the north-face ones of row r-1
+    _Pragma("unroll") for (int p = 0; p < CF_COUNT; ++p) cfc[p] = CF(p, s, 0);
+    _Pragma("unroll") for (int p = 0; p < 5; ++p) cfs[p] = CF(CF_AN + p, s, -1);
+    const double dzt2r_s = t_dzt2r.at(s - 1), ddztr = t_dztr.at(s - 1);
+    const double mk = (s <= kz) ? 1.0 : 0.0;
+    // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
+    const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
+    const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
+    const double m_c = mc1, tt_c = tc1;
+    const double m_e = me_next, tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
+    // ---- advection, low order and raw antidiffusive (adv_flx:500-619) ----------
+    const double felo = upstream(ve, m_c, m_e);
+    const double afe = ve * (tt_c + tt_e) - felo;
+    const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
+    const double fnlo_n = upstream(vn, m_c, mn1), fnlo_s = upstream(vs, ms1, m_c);
+    double fblo = 0.0, afb = 0.0;
+    if (!last) {
+      fblo = vb * (mc2 + m_c) + dabs(vb) * (mc2 - m_c);
+      afb = vb * (tt_c + tc2) - fblo * mk;
     }
-  }
-  // ---- sweep F: flux-corrected advection -------------------------------------------------------
-  {
-    const int kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
-    const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
-    const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5;
-    const double cstdyt2r = kload(c.cstdyt2r, r - 1);
-    const double c2dtts = c.c2dtts;
-    const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
-    double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);
-    double tc0, tc1;                   // levels s-1 and s of t(tau)
-    tc0 = tc1 = LD(tt, 1, 0);
-    double me_next = shfl_e(mc1);
-    // surface faces
-    const double vb0 = ATB(c.adv_vbt + fbase);
-    double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
-    double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
-    double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
-    double fbfin_up = vb0 * (tc1 + tc1);           // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
-    for (int s = 1; s <= km; ++s) {
-      const bool last = (s == km);
-      const int sp = last ? km : s + 1;
-      const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1), tc2 = LD(tt, sp, 0);
-      const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
-      const double ve = AT(c.tot_e, s, 0), vn = AT(c.tot_n, s, 0), vs = AT(c.tot_n, s, -1);
-      const double vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
-      const double sdiff = AT(Sn, s, 0);             // written by sweep D (this lane)
-      const double mk = (s <= kz) ? 1.0 : 0.0;
-      // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
-      const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
-      const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
-      const double m_c = mc1, tt_c = tc1;
-      const double m_e = me_next, tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
-      // ---- low order and raw antidiffusive (adv_flx:500-619) ----------
-      const double felo = upstream(ve, m_c, m_e);
-      const double afe = ve * (tt_c + tt_e) - felo;
-      const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
-      const double fnlo_n = upstream(vn, m_c, mn1), fnlo_s = upstream(vs, ms1, m_c);
-      double fblo = 0.0, afb = 0.0;
-      if (!last) {
-        fblo = vb * (mc2 + m_c) + dabs(vb) * (mc2 - m_c);
-        afb = vb * (tt_c + tc2) - fblo * mk;
-      }
-      const double dzt2r_s = kload(c.dzt2r, s - 1);
-      const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
-      const double advz = (fblo_up - fblo) * dzt2r_s;
-      const double tlo = m_c - (c2dtts * kload(c.dtxcel, s - 1)) * (advx + advy + advz) * mk;
-      // ---- limiter ratios ---------------------------------------------------------
-      double rxp, rxm, ryp, rym, rzp, rzm;
-      {
-        const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
-        fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
-      }
-      {
-        const double afn_n = vn * (tt_c + t_n) - fnlo_n;
-        const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
-        fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
-                  ryp, rym);
-      }
-      {
-        const double fxa = wet_up ? 0.5 * (tc0 + tt_c) : tlo;
-        const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
-        fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up, mk, rzp, rzm);
-      }
-      if (owned) {
-        AT(RpY, s, 0) = ryp;
-        AT(RmY, s, 0) = rym;
-      }
-      // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
-      const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
-      const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
-      const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
-      const double spart = sdiff - ADV_Tx;
-      // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
-      if (s >= 2) {
-        const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
-        const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, s - 2);
-        if (owned) AT(Sn, s - 1, 0) = spart_prev - ADV_Tz;
-        fbfin_up = fbfin;
-      }
-      if (last) {  // bottom face of the column (tracer.F:1065); vb holds adv_vbt there
-        const double fbfin = vb * tt_c;
-        const double ADV_Tz = (fbfin_up - fbfin) * kload(c.dzt2r, km - 1);
-        if (owned) AT(Sn, km, 0) = spart - ADV_Tz;
-      }
-      // ---- roll ---------------------------------------------------------------------------
-      rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
-      fblo_up = fblo; afb_up = afb;
-      me_next = shfl_e(mc2);
-      mc1 = mc2; ms1 = ms2; mn1 = mn2; tc0 = tc1; tc1 = tc2;
+    const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
+    const double advz = (fblo_up - fblo) * dzt2r_s;
+    const double tlo = m_c - (c2dtts * t_dtxcel.at(s - 1)) * (advx + advy + advz) * mk;
+    // ---- limiter ratios ---------------------------------------------------------
+    double rxp, rxm, ryp, rym, rzp, rzm;
+    {
+      const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
+      fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
     }
+    {
+      const double afn_n = vn * (tt_c + t_n) - fnlo_n;
+      const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
+      fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
+                ryp, rym);
+    }
+    {
+      const double fxa = wet_up ? 0.5 * (tc0 + tt_c) : tlo;
+      const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
+      fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up, mk, rzp, rzm);
+    }
+    if (owned) {
+      AT(RpY, s, 0) = ryp;
+      AT(RmY, s, 0) = rym;
+    }
+    // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
+    const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
+    const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
+    const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
+    // ---- diffusive fluxes (coefficients folded by coef_cell) ---------------------------
+    const double dz_up = dz_c, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column (dz_up = dz_dn of the level above, 0 at the top)
+    const double dze_up = dz_e, dze_dn = shfl_e(dz_dn);                   // east column
+    const double dzs_up = dz_s, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row
+    const double dzn_up = dz_n, dzn_dn = (!last) ? mn1 - mn2 : 0.0;      // north row
+    const double mc2_e = shfl_e(mc2);
+    const double dx_c = dx_next, dx_d = mc2_e - mc2;                      // T(i+1)-T(i) at levels s, s+1
+    const double dxw_c = dxw_next, dxw_d = shfl_w(dx_d);                  // T(i)-T(i-1)
+    const double dfe = cfc[CF_AE] * dx_c + cfc[CF_CE + 0] * dz_up + cfc[CF_CE + 1] * dze_up + cfc[CF_CE + 2] * dz_dn +
+                       cfc[CF_CE + 3] * dze_dn;
+    const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
+    const double dfn_n = cfc[CF_AN] * (mn1 - m_c) + cfc[CF_CN + 0] * dz_up + cfc[CF_CN + 1] * dzn_up + cfc[CF_CN + 2] * dz_dn +
+                         cfc[CF_CN + 3] * dzn_dn;
+    const double dfn_s = cfs[0] * (m_c - ms1) + cfs[1] * dzs_up + cfs[2] * dz_up + cfs[3] * dzs_dn + cfs[4] * dz_dn;
+    const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
+    double dfb = 0.0, dfbi = 0.0;  // through the face below level s
+    if (!last) {
+      dfb = cfc[CF_BV] * (m_c - mc2);
+      dfbi = cfc[CF_CBX + 0] * dxw_c + cfc[CF_CBX + 1] * dx_c + cfc[CF_CBX + 2] * dxw_d + cfc[CF_CBX + 3] * dx_d +
+             cfc[CF_CBY + 0] * (m_c - ms1) + cfc[CF_CBY + 1] * (mn1 - m_c) + cfc[CF_CBY + 2] * (mc2 - ms2) +
+             cfc[CF_CBY + 3] * (mn2 - mc2);
+    }
+    if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
+    if (kz == 0 && s == 1) dfb_up = btf;
+    const double DIFF_Tz = (dfb_up - dfb) * ddztr + (dfbi_up - dfbi) * ddztr;
+    const double spart = DIFF_Tx + DIFF_Ty + DIFF_Tz - ADV_Tx;
+    // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
+    if (s >= 2) {
+      const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
+      const double ADV_Tz = (fbfin_up - fbfin) * t_dzt2r.at(s - 2);
+      if (owned) AT(Sn, s - 1, 0) = spart_prev - ADV_Tz;
+      fbfin_up = fbfin;
+    }
+    if (last) {  // bottom face of the column (tracer.F:1065); vb holds adv_vbt there
+      const double fbfin = vb * tt_c;
+      const double ADV_Tz = (fbfin_up - fbfin) * dzt2r_s;
+      if (owned) AT(Sn, km, 0) = spart - ADV_Tz;
+    }
+    // ---- roll ---------------------------------------------------------------------------
+    rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
+    fblo_up = fblo; afb_up = afb; dfb_up = dfb; dfbi_up = dfbi;
+    me_next = mc2_e; dx_next = dx_d; dxw_next = dxw_d; dz_c = dz_dn; dz_e = dze_dn; dz_s = dzs_dn; dz_n = dzn_dn;
+    mc1 = mc2; ms1 = ms2; mn1 = mn2; tc0 = tc1; tc1 = tc2;
   }
 #undef LD
 #undef CF
@@ -334,6 +339,8 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   UV_DIMS(c);
   const int lane = threadIdx.x;
   const int i = i0 + lane;
+  LaneTable t_dtxcel, t_dztur, t_dztlr, t_dztr;   // filled while every lane is still active
+  t_dtxcel.load(c.dtxcel, c.km); t_dztur.load(c.dztur, c.km); t_dztlr.load(c.dztlr, c.km); t_dztr.load(c.dztr, c.km);
   if (i > i1) return;
   const size_t nloc = (size_t)(n1 - 1 - c.n0);
   const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
@@ -357,32 +364,48 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const int kb = imax(2, kz);
   double bet = 0.0, zprev = 0.0, cprev = 0.0;
   const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
-  for (int k = 1; k <= km; ++k) {
-    const double m_c = AT(tm, k, 0), m_s = AT(tm, k, -1), m_n = AT(tm, k, 1);
-    const double t_c = AT(tt, k, 0), t_s = AT(tt, k, -1), t_n = AT(tt, k, 1);
-    const double vn = AT(c.tot_n, k, 0), vs = AT(c.tot_n, k, -1);
+  // source term: always loaded (from S when the tracer has none) and selected afterwards, so that the
+  // number of loads in flight is the same on every path and the waits stay exact
+  const bool has_src = source != 0;
+  const double *srcp = has_src ? source : Sn;
+  // The sweep is one dependent chain per column (Thomas recurrence): what a level reads is fetched one
+  // level ahead into the other of two register sets so that the chain never waits for memory.
+  struct Lvl {
+    double m_c, m_s, m_n, t_c, t_s, t_n, vn, vs, rp0, rm0, rps, rms, rpn, rmn, sn, src, dcb;
+  };
+  auto load_level = [&](Lvl &L, int k) {
+    L.m_c = AT(tm, k, 0); L.m_s = AT(tm, k, -1); L.m_n = AT(tm, k, 1);
+    L.t_c = AT(tt, k, 0); L.t_s = AT(tt, k, -1); L.t_n = AT(tt, k, 1);
+    L.vn = AT(c.tot_n, k, 0); L.vs = AT(c.tot_n, k, -1);
+    L.rp0 = AT(RpY, k, 0); L.rm0 = AT(RmY, k, 0); L.rps = AT(RpY, k, -1); L.rms = AT(RmY, k, -1);
+    L.rpn = AT(RpY, k, 1); L.rmn = AT(RmY, k, 1);
+    L.sn = AT(Sn, k, 0);
+    L.src = AT(srcp, k, 0);
+    L.dcb = AT(c.diff_cbt, k, 0);
+  };
+  double dcb_up = 0.0;   // diff_cbt of the level above (the reference reads level max(1,k-1); at k=1 its factor is zeroed)
+  auto level = [&](const Lvl &L, int k) {
+    const double m_c = L.m_c, t_c = L.t_c;
     const double mk = (k <= kz) ? 1.0 : 0.0, mk_s = (k <= kz_s) ? 1.0 : 0.0;
-    const double lo_n = upstream(vn, m_c, m_n), lo_s = upstream(vs, m_s, m_c);
-    const double f_n = vn * (t_c + t_n) - lo_n;
-    const double f_s = (r - 1 == 1) ? 0.0 : vs * (t_s + t_c) - lo_s;
-    const double rp0 = AT(RpY, k, 0), rm0 = AT(RmY, k, 0), rps = AT(RpY, k, -1), rms = AT(RmY, k, -1);
-    const double rpn = AT(RpY, k, 1), rmn = AT(RmY, k, 1);
-    const double fn_n = (limited(fmn(rpn, rm0), fmn(rp0, rmn), f_n) + lo_n) * mk;
-    const double fn_s = (limited(fmn(rp0, rms), fmn(rps, rm0), f_s) + lo_s) * mk_s;
+    const double lo_n = upstream(L.vn, m_c, L.m_n), lo_s = upstream(L.vs, L.m_s, m_c);
+    const double f_n = L.vn * (t_c + L.t_n) - lo_n;
+    const double f_s = (r - 1 == 1) ? 0.0 : L.vs * (L.t_s + t_c) - lo_s;
+    const double fn_n = (limited(fmn(L.rpn, L.rm0), fmn(L.rp0, L.rmn), f_n) + lo_n) * mk;
+    const double fn_s = (limited(fmn(L.rp0, L.rms), fmn(L.rps, L.rm0), f_s) + lo_s) * mk_s;
     const double ADV_Ty = (fn_n - fn_s) * cstdyt2r;
-    const double tdt = c.c2dtts * kload(c.dtxcel, k - 1);
-    const double z = m_c + tdt * (AT(Sn, k, 0) - ADV_Ty + (source ? AT(source, k, 0) : 0.0)) * mk;
+    const double tdt = c.c2dtts * t_dtxcel.at(k - 1);
+    const double z = m_c + tdt * (L.sn - ADV_Ty + (has_src ? L.src : 0.0)) * mk;
     // Thomas forward sweep, invtri.F:57-100
-    const int km1 = imax(1, k - 1), kp1 = imin(k + 1, km);
-    const double factu = kload(c.dztur, k - 1) * tdt * aidif, factl = kload(c.dztlr, k - 1) * tdt * aidif;
-    double a = -AT(c.diff_cbt, km1, 0) * factu * mk;
-    double cc = -AT(c.diff_cbt, k, 0) * factl * ((kp1 <= kz) ? 1.0 : 0.0);
+    const int kp1 = imin(k + 1, km);
+    const double factu = t_dztur.at(k - 1) * tdt * aidif, factl = t_dztlr.at(k - 1) * tdt * aidif;
+    double a = -((k == 1) ? L.dcb : dcb_up) * factu * mk;
+    double cc = -L.dcb * factl * ((kp1 <= kz) ? 1.0 : 0.0);
     double f = z * mk;
     if (k == 1) a = 0.0;
     if (k == km) cc = 0.0;
     const double b = 1.0 - a - cc;
-    if (k == 1) f = z + topbc * tdt * kload(c.dztr, 0) * aidif * mk;
-    if (k == kb) f = z - botbc * tdt * kload(c.dztr, k - 1) * aidif * mk;
+    if (k == 1) f = z + topbc * tdt * t_dztr.at(0) * aidif * mk;
+    if (k == kb) f = z - botbc * tdt * t_dztr.at(k - 1) * aidif * mk;
     double znew;
     if (k == 1) {
       bet = mk / (b + eps);
@@ -396,16 +419,54 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
     AT(tp, k, 0) = znew;
     zprev = znew;
     cprev = cc;
+    dcb_up = L.dcb;
+  };
+#ifdef UV_COL_TIMING
+  const long long tq0 = clock64();
+#endif
+  {
+    Lvl A, B;
+    load_level(A, 1);
+    for (int k = 1; k <= km; k += 2) {
+      if (k + 1 <= km) load_level(B, k + 1);
+      level(A, k);
+      if (k + 1 <= km) {
+        if (k + 2 <= km) load_level(A, k + 2);
+        level(B, k + 1);
+      }
+    }
   }
-  // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155)
+#ifdef UV_COL_TIMING
+  const long long tq1 = clock64();
+#endif
+  // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155); the operands of
+  // four levels are fetched before their four dependent updates
   double znext = zprev;
   if (ic) tp[X3(ic, km, r)] = znext;
-  for (int k = km - 1; k >= 1; --k) {
+  int k = km - 1;
+  for (; k >= 4; k -= 4) {
+    double zz[4], ee[4];
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {
+      zz[u] = AT(tp, k - u, 0);
+      ee[u] = ework[(size_t)(k - u + 1) * 64 + lane];
+    }
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {
+      const double zk = zz[u] - ee[u] * znext;
+      AT(tp, k - u, 0) = zk;
+      if (ic) tp[X3(ic, k - u, r)] = zk;
+      znext = zk;
+    }
+  }
+  for (; k >= 1; --k) {
     const double zk = AT(tp, k, 0) - ework[(size_t)(k + 1) * 64 + lane] * znext;
     AT(tp, k, 0) = zk;
     if (ic) tp[X3(ic, k, r)] = zk;
     znext = zk;
   }
+#ifdef UV_COL_TIMING
+  if (lane == 0 && (blockIdx.x % 301) == 0 && threadIdx.y == 0)
+    printf("colupd blk %d r %d n %d: start %lld forward %lld backsub %lld\n", blockIdx.x, r, n1, tq0, tq1 - tq0, clock64() - tq1);
+#endif
 }
 #undef AT
 #undef ATB

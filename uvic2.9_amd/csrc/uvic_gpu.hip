@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
+  if (blk >= nblk || !col_decode_rows(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
   colupd_wave(c, S, lds + (size_t)wv * (c.km + 1) * 64, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
@@ -366,6 +366,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   if (!out || !dims) return fail_msg("uvic_gpu_create: null argument");
   if (dims->imt < 6 || dims->jmt < 6 || dims->km < 2 || dims->nt < 2)
     return fail_msg("uvic_gpu_create: dimensions too small (need imt,jmt >= 6, km >= 2, nt >= 2)");
+  if (dims->km > 64) return fail_msg("uvic_gpu_create: km > 64 not supported (per-level metrics are held one per lane of a wave)");
   HIPCHK(hipSetDevice(device));
   uvic_gpu *h = new uvic_gpu();
   h->d = *dims;
