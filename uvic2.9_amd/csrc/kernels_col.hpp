@@ -90,6 +90,7 @@ struct ColGrid {
   int r0, nrows, nseg, total;  // total = nrows * nt_local * nseg work items (one wave each)
 };
 #define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
+#define COLUPD_WAVES 2  // waves per workgroup of pass B: 2 x 2 x (km+1) x 512 B of LDS each, three workgroups per CU at km = 19
 
 // Neighbour exchange by DPP whole-wave shifts (gfx9 `wave_shr:1` / `wave_shl:1`): one
 // v_mov_b32_dpp per dword at VALU latency instead of an LDS round trip (ds_bpermute) --
@@ -332,7 +333,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 
 // ===========================================================================
 // pass B: y advection, explicit update, implicit vertical diffusion (invtri.F)
-// `ework` is a per-lane scratch of km doubles in LDS laid out [k][lane]
+// `ework` is the wave's LDS scratch: e(k) and z(k) of the Thomas recurrence, each (km+1) x 64 doubles laid out
+// [k][lane], so that the forward sweep writes t(tau+1) nowhere and the back substitution stores it once
 // ===========================================================================
 __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int r, int n1,
                                             int i0, int i1) {
@@ -364,6 +366,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const int kb = imax(2, kz);
   double bet = 0.0, zprev = 0.0, cprev = 0.0;
   const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
+  double *zwork = ework + (size_t)(km + 1) * 64;
   // source term: always loaded (from S when the tracer has none) and selected afterwards, so that the
   // number of loads in flight is the same on every path and the waits stay exact
   const bool has_src = source != 0;
@@ -416,7 +419,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
       bet = mk / (b - a * e + eps);
       znew = (f - a * zprev) * bet;
     }
-    AT(tp, k, 0) = znew;
+    zwork[(size_t)k * 64 + lane] = znew;
     zprev = znew;
     cprev = cc;
     dcb_up = L.dcb;
@@ -439,26 +442,12 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
 #ifdef UV_COL_TIMING
   const long long tq1 = clock64();
 #endif
-  // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155); the operands of
-  // four levels are fetched before their four dependent updates
+  // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155)
   double znext = zprev;
+  AT(tp, km, 0) = znext;
   if (ic) tp[X3(ic, km, r)] = znext;
-  int k = km - 1;
-  for (; k >= 4; k -= 4) {
-    double zz[4], ee[4];
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {
-      zz[u] = AT(tp, k - u, 0);
-      ee[u] = ework[(size_t)(k - u + 1) * 64 + lane];
-    }
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {
-      const double zk = zz[u] - ee[u] * znext;
-      AT(tp, k - u, 0) = zk;
-      if (ic) tp[X3(ic, k - u, r)] = zk;
-      znext = zk;
-    }
-  }
-  for (; k >= 1; --k) {
-    const double zk = AT(tp, k, 0) - ework[(size_t)(k + 1) * 64 + lane] * znext;
+  for (int k = km - 1; k >= 1; --k) {
+    const double zk = zwork[(size_t)k * 64 + lane] - ework[(size_t)(k + 1) * 64 + lane] * znext;
     AT(tp, k, 0) = zk;
     if (ic) tp[X3(ic, k, r)] = zk;
     znext = zk;

@@ -106,14 +106,14 @@ __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *
   if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
   colfct_wave(c, cf, S, r, n1, i0, i1);
 }
-__global__ void __launch_bounds__(256) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
+__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int nblk = (g.total + 3) / 4;
+  const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (blk >= nblk || !col_decode_rows(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
-  colupd_wave(c, S, lds + (size_t)wv * (c.km + 1) * 64, r, n1, i0, i1);
+  if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, r, n1, i0, i1)) return;
+  colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,6 +444,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   }
   HIPCHK(hipFuncSetAttribute((const void *)k_fct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fct_lds));
   HIPCHK(hipFuncSetAttribute((const void *)k_update_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->upd_lds));
+  {
+    const size_t colupd_lds = (size_t)COLUPD_WAVES * 2 * (h->d.km + 1) * 64 * 8;
+    if (colupd_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_colupd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
+  }
   HIPCHK(hipDeviceSynchronize());
   *out = h;
   return 0;
@@ -632,14 +636,16 @@ static int launch_transport(uvic_gpu *h) {
     b.r0 = c.js; b.nrows = c.je - c.js + 1; b.total = b.nrows * c.nt_local * b.nseg;
     double *S = h->work[3];
     mark(h, "begin");
-    const unsigned na = (unsigned)((((a.total + 3) / 4 + 7) / 8) * 8), nb = (unsigned)((((b.total + 3) / 4 + 7) / 8) * 8);
+    const unsigned na = (unsigned)((((a.total + 3) / 4 + 7) / 8) * 8);
+    const unsigned nb = (unsigned)((((b.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
     hipLaunchKernelGGL(k_colfct, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
     mark(h, "colfct");
     if (h->src_from_prefetch) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
       h->src_from_prefetch = false;
     }
-    hipLaunchKernelGGL(k_colupd, dim3(nb), dim3(64, 4), (size_t)4 * (c.km + 1) * 64 * 8, h->stream, c, (const double *)S, b);
+    hipLaunchKernelGGL(k_colupd, dim3(nb), dim3(64, COLUPD_WAVES), (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8, h->stream, c,
+                       (const double *)S, b);
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
     return 0;
