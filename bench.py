@@ -199,6 +199,21 @@ def main():
         m.load_ocean(ocean, to, so, c, src=src)
         shard.apply(m)
         iso = m.profile(nrep=10)   # the same kernels back to back on one stream, nothing overlapped
+        # §8(f) rank-1 rows (producers of the shared inputs), timed on their own: not part of `value`
+        nxt = {}
+        try:
+            tid = synthetic.make_tidal(ocean.grid, ocean.topo, ocean.params.kappa_h)
+            m.load_velocity(ocean)
+            m.load_tidal(ocean, tid)
+            m.set_params(diff_cbt_has_k33=1)
+            m.profile_live(True)
+            for _ in range(10):
+                m.adv_vel(); m.isopyc(); m.vmixc()
+            pr = m.profile_read()
+            nxt = {k: round(pr[k], 5) for k in ("adv_vel_hor", "adv_vel_vert", "vmixc") if k in pr}
+            m.set_params(diff_cbt_has_k33=0)
+        except Exception as e:   # never let the side measurement break the bench line
+            nxt = {"error": str(e)}
         prof = live
         names = [k for k in prof if kernel_alg_bytes(k, nt, nsrc)]
         dom = max(names, key=lambda k: prof[k])
@@ -223,6 +238,7 @@ def main():
                                  "step run beside the transport kernels on the side stream",
                          "kernel_ms": {k: round(v, 5) for k, v in prof.items()},
                          "kernel_ms_isolated": {k: round(v, 5) for k, v in iso.items()},
+                         "next_rows_kernel_ms": nxt,
                          "alg_bytes_per_cell_update": kernel_alg_bytes(dom, nt, nsrc)},
             "step_hbm": {"alg_bytes_per_cell_update": b_alg(nt, nsrc), "achieved_GBs": step_gbs,
                          "frac_of_peak": step_gbs / HBM_PEAK_GBS},

@@ -61,6 +61,12 @@ enum uvic_field {
   UVIC_F_AI_EZ, UVIC_F_AI_NZ, UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33,
   UVIC_F_ADV_VETISO, UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO,
   UVIC_F_DIFF_CBT,                            /* C, background + K33 */
+  /* inputs of uvic_gpu_adv_vel / uvic_gpu_vmixc */
+  UVIC_F_U1, UVIC_F_U2,                       /* C, mw.h u(imt,km,jmw,1:2,tau): zonal, meridional velocity on U cells */
+  UVIC_F_DXT2R, UVIC_F_DYT2R,                 /* (imt), (jmt) grdvar.h */
+  UVIC_F_ZW,                                  /* (km) coord.h: depth of T-cell bottoms */
+  UVIC_F_TLAT,                                /* S, grdvar.h tlat(imt,jmt) */
+  UVIC_F_EDRM2, UVIC_F_EDRS2, UVIC_F_EDRK1, UVIC_F_EDRO1, /* C, u09/mom/tidal_kv.h edr*(imt,km,jmt) */
   UVIC_F_COUNT
 };
 
@@ -78,6 +84,12 @@ typedef struct uvic_params {
   int32_t diff_cbt_has_k33;
   int32_t pad_;
 } uvic_params;
+
+/* constants of the tidal-mixing scheme (u09/mom/tidal_kv.h, set in u09/mom/setmom.F:80-82) and the
+ * background diffusivity (vmixc.h) */
+typedef struct uvic_vmix_params {
+  double kappa_h, zetar, ogamma, gravrho0r;
+} uvic_vmix_params;
 
 /* ---- MOBI biogeochemistry (option set C) --------------------- */
 /* 1-based positions, 0 = absent.  `im`: position in the MOBI column vector
@@ -198,6 +210,17 @@ int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
 int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);
+
+/* ---- producers of the step's shared inputs ------------------------------
+ * replaces `call adv_vel (joff, js, je, is, ie)` (source/mom/mom.F:332; source/mom/adv_vel.F:63-131, the
+ * T-cell part, rigid lid): UVIC_F_ADV_VET/VNT/VBT from UVIC_F_U1/U2 */
+int uvic_gpu_adv_vel(uvic_gpu *h);
+int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p);
+/* replaces the tracer part of `call vmixc (joff, js, je, is, ie)` (mom.F:347; u09/mom/vmixc.F:62-190 with
+ * O_constvmix O_tidal_kv O_isopycmix): UVIC_F_DIFF_CBT = max(kappa_h, min(100, tidal + kappa_h)) above the
+ * bottom level, the previous value elsewhere, plus K33.  Call after uvic_gpu_isopyc of the same step with
+ * uvic_params.diff_cbt_has_k33 = 1 (isopyc then leaves diff_cbt to this call). */
+int uvic_gpu_vmixc(uvic_gpu *h);
 
 /* run `nrep` x [isopyc, tracer] back to back and return the mean duration in
  * milliseconds of every kernel, measured with HIP events on the launch stream;

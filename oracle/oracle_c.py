@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "liboracle.so"
-SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c"]
+SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c", HERE / "prep_oracle.c"]
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)
@@ -143,3 +143,36 @@ class Oracle:
     def transport(self):
         self.lib.orc_tracer_transport(ctypes.byref(self.ctx))
         return self.a["t_taup1"]
+
+
+# ---- producers of the shared inputs (prep_oracle.c) ---------------------------------------------
+def _p(a):
+    return a.ctypes.data_as(_D)
+
+
+def adv_vel(g, u):
+    """adv_vet, adv_vnt (imt,km,jmt), adv_vbt (imt,km+1,jmt) from u(imt,km,jmt,2) as adv_vel.F."""
+    imt, jmt, km = g.imt, g.jmt, g.km
+    u1 = np.asfortranarray(u[..., 0]); u2 = np.asfortranarray(u[..., 1])
+    vet, vnt, vbt = _f((imt, km, jmt)), _f((imt, km, jmt)), _f((imt, km + 1, jmt))
+    c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    arrs = [c(g.dxu), c(g.dyu), c(g.dxt2r), c(g.dyt2r), c(g.dxtr), c(g.dytr), c(g.cstr), c(g.csu), c(g.dzt)]
+    lib().orc_adv_vel(ctypes.c_int(imt), ctypes.c_int(jmt), ctypes.c_int(km), _p(u1), _p(u2), *[_p(a) for a in arrs],
+                      _p(vet), _p(vnt), _p(vbt))
+    return vet, vnt, vbt
+
+
+def vmixc(g, topo, tidal, alphai, betai, ddzt, K33, diff_cbt_prev):
+    """diff_cbt (imt,km,jmt) as vmixc.F leaves it (tidal mixing + K33) from the isopyc products."""
+    imt, jmt, km = g.imt, g.jmt, g.km
+    out = np.array(diff_cbt_prev, order="F", dtype=np.float64)
+    kmt = np.asfortranarray(topo.kmt, dtype=np.int32)
+    c = lambda a: np.asfortranarray(a, dtype=np.float64)
+    tl, zw = c(tidal.tlat), np.ascontiguousarray(g.zw, dtype=np.float64)
+    e = [c(tidal.edrm2), c(tidal.edrs2), c(tidal.edrk1), c(tidal.edro1)]
+    al, be, dz, k33 = c(alphai), c(betai), c(ddzt), c(K33)
+    D = ctypes.c_double
+    lib().orc_vmixc(ctypes.c_int(imt), ctypes.c_int(jmt), ctypes.c_int(km), kmt.ctypes.data_as(_I), _p(tl), _p(zw), _p(al),
+                    _p(be), _p(dz), _p(k33), *[_p(a) for a in e], D(tidal.kappa_h), D(tidal.zetar), D(tidal.ogamma),
+                    D(tidal.gravrho0r), _p(out))
+    return out

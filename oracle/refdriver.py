@@ -171,6 +171,32 @@ class RefOcean:
         g = self.ocean.grid
         self.ref.call("tracer", 0, 2, g.jmt - 1, 2, g.imt - 1)
 
+    # -- producers of the shared inputs -------------------
+    def adv_vel(self):
+        """source/mom/adv_vel.F with the arguments of mom.F:332 for one memory window; returns
+        adv_vet, adv_vnt, adv_vbt over all jmt rows (row 1 of vet/vbt is not computed: zero)."""
+        g = self.ocean.grid
+        for n in ("adv_vet", "adv_vnt", "adv_vbt"):
+            self.v[n][...] = 0.0
+        self.ref.call("adv_vel", 0, 1, g.jmt, 2, g.imt - 1)
+        vet = np.zeros((g.imt, g.km, g.jmt), order="F"); vet[:, :, 1:] = self.v["adv_vet"]
+        vbt = np.zeros((g.imt, g.km + 1, g.jmt), order="F"); vbt[:, :, 1:] = self.v["adv_vbt"]
+        return vet, np.array(self.v["adv_vnt"], order="F"), vbt
+
+    def vmixc(self, tidal, diff_cbt_prev):
+        """updates/09/source/mom/vmixc.F (mom.F:347) after `isopyc`: tidal mixing + K33.  Returns
+        diff_cbt over all jmt rows (rows 1 and jmt are not part of the reference array: zero)."""
+        g = self.ocean.grid
+        S = self.ref.set
+        for n in ("edrm2", "edrs2", "edrk1", "edro1"):
+            self.v[n][...] = getattr(tidal, n)
+        S("zetar", tidal.zetar); S("ogamma", tidal.ogamma); S("gravrho0r", tidal.gravrho0r); S("kappa_h", tidal.kappa_h)
+        self.v["diff_cbt"][...] = diff_cbt_prev[:, :, 1:g.jmt - 1]
+        self.ref.call("vmixc", 0, 1, g.jmt, 2, g.imt - 1)
+        out = np.zeros((g.imt, g.km, g.jmt), order="F")
+        out[:, :, 1:g.jmt - 1] = self.v["diff_cbt"]
+        return out
+
     def step(self, c2dtts=None):
         if c2dtts is not None:
             self.ref.set("c2dtts", c2dtts)

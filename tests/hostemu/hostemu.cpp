@@ -16,6 +16,7 @@
 #include "../../uvic2.9_amd/csrc/kernels_fct.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_isopyc.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_mobi.hpp"
+#include "../../uvic2.9_amd/csrc/kernels_prep.hpp"
 
 using namespace uvic;
 
@@ -71,6 +72,22 @@ extern "C" void emu_convect_twopass(const uvic_ctx *cp) {
   for (int n = 3; n <= c.nt; ++n)
     for (int j = c.js; j <= c.je; ++j)
       for (int i = 2; i <= c.imt - 1; ++i) convect_apply_cell(c, i, j, n);
+}
+
+// producers of the shared inputs (kernels_prep.hpp)
+extern "C" void emu_adv_vel(const uvic_ctx *cp) {
+  const uvic_ctx &c = *cp;
+  for (int j = 1; j <= c.jmt; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 1; i <= c.imt; ++i) adv_vel_hor_cell(c, i, k, j);
+  for (int j = 2; j <= c.jmt; ++j)
+    for (int i = 2; i <= c.imt - 1; ++i) adv_vel_vert_column(c, i, j);
+}
+extern "C" void emu_vmixc(const uvic_ctx *cp) {
+  const uvic_ctx &c = *cp;
+  for (int j = 2; j <= c.jmt - 1; ++j)
+    for (int k = 1; k <= c.km; ++k)
+      for (int i = 2; i <= c.imt - 1; ++i) vmixc_cell(c, i, k, j);
 }
 
 // MOBI column kernel on the host: same source as the GPU kernel, libm instead of ocml

@@ -43,7 +43,7 @@ EXPORTS = [
     "uvic_gpu_field_devptr", "uvic_gpu_stream", "uvic_gpu_set_params", "uvic_gpu_set_shard", "uvic_gpu_isopyc",
     "uvic_gpu_transport", "uvic_gpu_convect", "uvic_gpu_tracer", "uvic_gpu_rotate", "uvic_gpu_sync",
     "uvic_gpu_profile", "uvic_gpu_profile_live", "uvic_gpu_profile_read", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_set_mobi_flat", "uvic_gpu_mobi", "uvic_gpu_prefetch_sources",
-    "uvic_gpu_set_mixing", "uvic_gpu_set_exact",
+    "uvic_gpu_set_mixing", "uvic_gpu_set_exact", "uvic_gpu_adv_vel", "uvic_gpu_set_vmix_params", "uvic_gpu_vmixc",
 ]
 
 
@@ -54,6 +54,10 @@ class Dims(ctypes.Structure):
 class Params(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_double) for n in ("c2dtts", "aidif", "diff_cet", "diff_cnt", "slmxr", "ahisop", "athkdf")]
                 + [("diff_cbt_has_k33", ctypes.c_int32), ("pad_", ctypes.c_int32)])
+
+
+class VmixParams(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("kappa_h", "zetar", "ogamma", "gravrho0r")]
 
 
 _lib = None
@@ -94,6 +98,7 @@ def load():
     lib.uvic_gpu_set_mobi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    lib.uvic_gpu_set_vmix_params.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_profile_live.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]

@@ -60,6 +60,12 @@ typedef struct uvic_ctx {
   int js, je;
   /* 1: diff_cbt was uploaded with K33 already added (host vmixc); isopyc leaves it alone */
   int diff_cbt_given;
+  /* inputs of adv_vel and vmixc (kernels_prep.hpp) */
+  const double *u1, *u2;                                          /* (imt,km,jmt) u(:,:,:,1:2,tau) */
+  const double *dxt2r, *dyt2r, *zw;                               /* (imt), (jmt), (km) */
+  const double *tlat;                                             /* (imt,jmt) */
+  const double *edrm2, *edrs2, *edrk1, *edro1;                    /* (imt,km,jmt) */
+  double kappa_h, zetar, ogamma, gravrho0r;
 } uvic_ctx;
 
 #endif

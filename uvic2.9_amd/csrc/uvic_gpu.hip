@@ -16,6 +16,7 @@
 
 #include "../../include/uvic_gpu.h"
 #include "kernels_col.hpp"
+#include "kernels_prep.hpp"
 #include "kernels_fct.hpp"
 #include "kernels_isopyc.hpp"
 #include "kernels_mobi.hpp"
@@ -93,6 +94,22 @@ __global__ void __launch_bounds__(1024) k_update_rows(const uvic_ctx c, const Ti
   update_rows_block(env, c, n1, row, chunk, g.nchunk, lds);
 }
 // ---- lane-per-column production path (kernels_col.hpp) ------------------------------
+__global__ void __launch_bounds__(256) k_adv_vel_hor(const uvic_ctx c) {
+  CELL_DECODE(c);
+  if (j > c.jmt) return;
+  adv_vel_hor_cell(c, i, k, j);
+}
+__global__ void __launch_bounds__(64) k_adv_vel_vert(const uvic_ctx c) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
+  if (j < 2 || j > c.jmt || i < 2 || i > c.imt - 1) return;
+  adv_vel_vert_column(c, i, j);
+}
+__global__ void __launch_bounds__(256) k_vmixc(const uvic_ctx c) {
+  CELL_DECODE(c);
+  if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  vmixc_cell(c, i, k, j);
+}
 __global__ void __launch_bounds__(256) k_coef(const uvic_ctx c, double *cf) {
   CELL_DECODE(c);
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
@@ -266,6 +283,9 @@ static const FieldDesc FIELDS[UVIC_F_COUNT] = {
     {"K11", K_C, 1, false}, {"K22", K_C, 1, false}, {"K33", K_C, 1, false},
     {"adv_vetiso", K_C, 1, false}, {"adv_vntiso", K_C, 1, false}, {"adv_vbtiso", K_F, 1, false},
     {"diff_cbt", K_C, 1, false},
+    {"u1", K_C, 1, false}, {"u2", K_C, 1, false}, {"dxt2r", K_IMT, 1, false}, {"dyt2r", K_JMT, 1, false},
+    {"zw", K_KM, 1, false}, {"tlat", K_S, 1, false},
+    {"edrm2", K_C, 1, false}, {"edrs2", K_C, 1, false}, {"edrk1", K_C, 1, false}, {"edro1", K_C, 1, false},
 };
 
 struct KernelStat {
@@ -289,6 +309,7 @@ struct uvic_gpu {
   mobi_dev mobi;
   mobi_store mobi_st;
   bool have_mobi;
+  bool have_vmix;   // uvic_gpu_set_vmix_params was called
   double mobi_dtnpzd;
   bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
   // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
@@ -329,7 +350,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 1; }
+extern "C" int uvic_gpu_abi_version(void) { return 2; }
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -353,6 +374,8 @@ static void bind_ctx(uvic_gpu *h) {
   B(Ai_ez, UVIC_F_AI_EZ); B(Ai_nz, UVIC_F_AI_NZ); B(Ai_bx, UVIC_F_AI_BX); B(Ai_by, UVIC_F_AI_BY);
   B(K11, UVIC_F_K11); B(K22, UVIC_F_K22); B(K33, UVIC_F_K33);
   B(adv_vetiso, UVIC_F_ADV_VETISO); B(adv_vntiso, UVIC_F_ADV_VNTISO); B(adv_vbtiso, UVIC_F_ADV_VBTISO);
+  B(u1, UVIC_F_U1); B(u2, UVIC_F_U2); B(dxt2r, UVIC_F_DXT2R); B(dyt2r, UVIC_F_DYT2R); B(zw, UVIC_F_ZW); B(tlat, UVIC_F_TLAT);
+  B(edrm2, UVIC_F_EDRM2); B(edrs2, UVIC_F_EDRS2); B(edrk1, UVIC_F_EDRK1); B(edro1, UVIC_F_EDRO1);
 #undef B
   if (h->mixing) c.t_taum1 = c.t_tau;  // forward step: both slots hold tau (updates/09/source/mom/loadmw.F:107-111)
   c.tot_e = h->work[0]; c.tot_n = h->work[1]; c.tot_b = h->work[2];
@@ -373,6 +396,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->device = device;
   h->profiling = false;
   h->have_mobi = false;
+  h->have_vmix = false;
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -717,6 +741,46 @@ static int launch_mobi(uvic_gpu *h) {
   hipLaunchKernelGGL(k_mobi_post, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
   mark(h, "mobi_post");
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// -- producers of the shared inputs (kernels_prep.hpp) ---------------------------------
+static int launch_adv_vel(uvic_gpu *h) {
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_adv_vel_hor, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
+  mark(h, "adv_vel_hor");
+  hipLaunchKernelGGL(k_adv_vel_vert, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx);
+  mark(h, "adv_vel_vert");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_vmixc(uvic_gpu *h) {
+  if (!h->have_vmix) return fail_msg("uvic_gpu_vmixc: call uvic_gpu_set_vmix_params first");
+  if (!h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_vmixc: set uvic_params.diff_cbt_has_k33 = 1 (isopyc must leave diff_cbt to vmixc)");
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_vmixc, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
+  mark(h, "vmixc");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+extern "C" int uvic_gpu_adv_vel(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_adv_vel(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p) {
+  if (!h || !p) return fail_msg("uvic_gpu_set_vmix_params: null argument");
+  h->ctx.kappa_h = p->kappa_h; h->ctx.zetar = p->zetar; h->ctx.ogamma = p->ogamma; h->ctx.gravrho0r = p->gravrho0r;
+  h->have_vmix = true;
+  return 0;
+}
+extern "C" int uvic_gpu_vmixc(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_vmixc(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

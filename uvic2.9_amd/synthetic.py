@@ -270,6 +270,25 @@ def advective_velocities(g, u):
     return vet, vnt, vbt
 
 
+def make_tidal(g, topo, kappa_h=0.35):
+    """Synthetic inputs of the tidal-mixing part of `vmixc` (updates/09/source/mom/tidal_kv.h,
+    vmixc.F:84-122): smooth positive energy dissipation rates of the four constituents on the
+    sub-grid bathymetry, the constants of setmom.F:80-82 and the T-cell latitude."""
+    imt, jmt, km = g.imt, g.jmt, g.km
+    lam = 2.0 * np.pi * (np.arange(1, imt + 1) - 1.5) / (imt - 2)
+    shape = (1.0 + 0.6 * np.sin(3.0 * lam))[:, None, None] * (1.0 + 0.5 * np.cos(2.0 * g.phi))[None, None, :]
+    prof = (0.2 + (g.zt / g.zt[-1]) ** 2)[None, :, None]       # more dissipation near the bottom
+    base = 2.0e-2 * shape * prof * topo.tmask
+    rho0r, grav = 1.0 / 1.035, 980.6
+    zetar = 1.0 / 500.0e2
+    return SimpleNamespace(tlat=g.tlat, edrm2=F_(base), edrs2=F_(0.45 * base), edrk1=F_(0.3 * base), edro1=F_(0.2 * base),
+                           kappa_h=float(kappa_h), zetar=zetar, ogamma=0.2 * rho0r * zetar, gravrho0r=grav * rho0r)
+
+
+def F_(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
 @dataclass
 class Ocean:
     cfg: OptionSet

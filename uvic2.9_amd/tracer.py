@@ -59,6 +59,7 @@ class TracerModel:
             "ddxt": C + (2,), "ddyt": C + (2,), "ddzt": Fc + (2,), "ai_ez": C + (2, 2), "ai_nz": C + (2, 2),
             "ai_bx": C + (2, 2), "ai_by": C + (2, 2), "k11": C, "k22": C, "k33": C, "adv_vetiso": C,
             "adv_vntiso": C, "adv_vbtiso": Fc, "diff_cbt": C, "to": (km,), "so": (km,), "c": (km, 9),
+            "u1": C, "u2": C, "tlat": S, "edrm2": C, "edrs2": C, "edrk1": C, "edro1": C, "dxt2r": (imt,), "zw": (km,),
         }
         if name in table:
             return table[name]
@@ -111,6 +112,35 @@ class TracerModel:
 
     def mobi(self):
         check(self.lib.uvic_gpu_mobi(self.h), "mobi")
+
+    # producers of the shared inputs ---------------------------------
+    def load_velocity(self, ocean):
+        """Upload u(tau) and the metrics `adv_vel` needs."""
+        g = ocean.grid
+        self.upload("u1", np.asfortranarray(ocean.u[..., 0]))
+        self.upload("u2", np.asfortranarray(ocean.u[..., 1]))
+        self.upload("dxt2r", g.dxt2r)
+        self.upload("dyt2r", g.dyt2r)
+
+    def adv_vel(self):
+        """adv_vet, adv_vnt, adv_vbt from u(tau) on the device (source/mom/adv_vel.F:63-131)."""
+        check(self.lib.uvic_gpu_adv_vel(self.h), "adv_vel")
+
+    def load_tidal(self, ocean, tidal):
+        """Upload the inputs of the tidal-mixing scheme (updates/09/source/mom/tidal_kv.h)."""
+        from .capi import VmixParams
+        g = ocean.grid
+        self.upload("zw", g.zw)
+        self.upload("tlat", np.asfortranarray(tidal.tlat))
+        for n in ("edrm2", "edrs2", "edrk1", "edro1"):
+            self.upload(n, np.asfortranarray(getattr(tidal, n)))
+        p = VmixParams(tidal.kappa_h, tidal.zetar, tidal.ogamma, tidal.gravrho0r)
+        check(self.lib.uvic_gpu_set_vmix_params(self.h, ctypes.byref(p)), "set_vmix_params")
+
+    def vmixc(self):
+        """diff_cbt = tidal mixing + K33 on the device (updates/09/source/mom/vmixc.F:62-190); call after
+        isopyc() with set_params(diff_cbt_has_k33=1)."""
+        check(self.lib.uvic_gpu_vmixc(self.h), "vmixc")
 
     def set_shard(self, n0=0, nt_local=None, js=2, je=None):
         nt_local = self.nt - n0 if nt_local is None else nt_local
