@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--cfg", default="c30")
     ap.add_argument("--grid", default="102x102x19")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decomp", default="auto", choices=["auto", "tracer", "slab"],
+                    help="N>1: tracer-index shards + all-gather, or latitude slabs + 2-row halo exchange "
+                         "(auto: slabs when every rank gets at least 12 rows, SURVEY.md §8e)")
     a = ap.parse_args()
 
     import torch
@@ -130,10 +133,17 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tracer step has no CPU path")
+    # rehearsal of the N>1 path on a box with one GPU (tests only): every rank on device 0, gloo instead of RCCL
+    rehearse = os.environ.get("UVIC_BENCH_REHEARSAL") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     imt, jmt, km = (int(x) for x in a.grid.split("x"))
     cfg = OPTION_SETS[a.cfg] if a.cfg in OPTION_SETS else performance_set(int(a.cfg.replace("perf", "")))
@@ -145,8 +155,16 @@ def main():
         rng = np.random.default_rng(2029)
         src = np.asfortranarray(rng.standard_normal((imt, km, jmt, nsrc)) * 1e-10 * ocean.topo.tmask[..., None])
 
-    from uvic29_amd.parallel import TracerShard
-    shard = TracerShard(nt, world, rank)
+    from uvic29_amd.parallel import SlabShard, TracerShard
+    decomp = a.decomp
+    if decomp == "auto":
+        decomp = "slab" if world > 1 and (jmt - 2) // world >= 12 else "tracer"
+    if decomp == "slab" and world > 1:
+        shard = SlabShard(jmt, world, rank)
+        shard.nt_model, shard.nt_local = nt, nt
+    else:
+        decomp = "tracer"
+        shard = TracerShard(nt, world, rank)
     if shard.nt_model != nt:          # pad the tracer dimension with inert tracers (see parallel.py)
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, nsrc, cfg.ntnpzd, device=local_rank)
@@ -218,6 +236,8 @@ def main():
         names = [k for k in prof if kernel_alg_bytes(k, nt, nsrc)]
         dom = max(names, key=lambda k: prof[k])
         local_units = imt * jmt * km * shard.nt_local
+        if decomp == "slab":
+            local_units = imt * (shard.je - shard.js + 1 + 2) * km * nt     # pass A also does one row beyond each side
         ach = kernel_alg_bytes(dom, nt, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
         step_gbs = b_alg(nt, nsrc) * value / 1e9
         traffic, traffic_src = pmc_traffic(dom, world == 1 and a.cfg == "c30" and a.grid == "102x102x19")
@@ -230,7 +250,7 @@ def main():
             "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
                                    f"(FCT adv_flux, isoflux, explicit update, invtri, convct2"
                                    f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",
-                       "grid": a.grid, "nt": nt, "parallelism": f"tracer-shard x{world}"},
+                       "grid": a.grid, "nt": nt, "parallelism": (f"latitude-slab x{world}, 2-row halo exchange" if decomp == "slab" else f"tracer-shard x{world}")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "dominant HBM-side (transport) kernel; kernel_ms are HIP-event means over a second, instrumented "

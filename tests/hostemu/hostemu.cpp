@@ -24,17 +24,21 @@ extern "C" int emu_ctx_size(void) { return (int)sizeof(uvic_ctx); }
 
 extern "C" void emu_isopyc(const uvic_ctx *cp) {
   const uvic_ctx &c = *cp;
+  // latitude-slab runs: the same row window as the GPU kernels (two rows beyond the slab)
+  const int lo = c.js - 2, hi = c.je + 2;
+#define IN(j) ((j) >= lo && (j) <= hi)
   for (int j = 1; j <= c.jmt; ++j)
     for (int k = 1; k <= c.km; ++k)
-      for (int i = 2; i <= c.imt - 1; ++i) isopyc_elements_cell(c, i, k, j);
+      for (int i = 2; i <= c.imt - 1; ++i) if (IN(j)) isopyc_elements_cell(c, i, k, j);
   for (int j = 1; j <= c.jmt - 1; ++j)
     for (int k = 1; k <= c.km; ++k)
-      for (int i = 2; i <= c.imt - 1; ++i) isopyc_ai_cell(c, i, k, j);
+      for (int i = 2; i <= c.imt - 1; ++i) if (IN(j)) isopyc_ai_cell(c, i, k, j);
   for (int j = 1; j <= c.jmt - 1; ++j)
     for (int k = 1; k <= c.km; ++k)
-      for (int i = 1; i <= c.imt; ++i) isopyc_adv_cell(c, i, k, j);
+      for (int i = 1; i <= c.imt; ++i) if (IN(j)) isopyc_adv_cell(c, i, k, j);
   for (int j = 2; j <= c.jmt - 1; ++j)
-    for (int i = 2; i <= c.imt - 1; ++i) isopyc_column(c, i, j);
+    for (int i = 2; i <= c.imt - 1; ++i) if (IN(j)) isopyc_column(c, i, j);
+#undef IN
 }
 
 extern "C" void emu_transport(const uvic_ctx *cp, int nchunk, int nthreads) {

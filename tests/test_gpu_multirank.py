@@ -14,14 +14,18 @@ pytestmark = pytest.mark.gpu
 NSTEP = 5
 
 
-def _run(cfg_name, imt, jmt, km, world, rank):
+def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
     from uvic29_amd import OPTION_SETS, synthetic
-    from uvic29_amd.parallel import TracerShard
+    from uvic29_amd.parallel import SlabShard, TracerShard
     from uvic29_amd.tracer import TimeLoop, TracerModel
     cfg = OPTION_SETS[cfg_name]
     ocean = synthetic.make_ocean(cfg, imt, jmt, km)
     to, so, c = synthetic.load_eos(km)
-    shard = TracerShard(cfg.nt, world, rank)
+    if decomp == "slab":
+        shard = SlabShard(jmt, world, rank)
+        shard.nt_model = cfg.nt
+    else:
+        shard = TracerShard(cfg.nt, world, rank)
     if shard.nt_model != cfg.nt:
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, cfg.nsrc, cfg.ntnpzd, device=0)
@@ -38,17 +42,17 @@ def _run(cfg_name, imt, jmt, km, world, rank):
     return out
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, decomp="tracer", grid=(14, 14, 6)):
     import torch.distributed as dist
     for p in (ROOT,):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    got = _run("c30", 14, 14, 6, world, rank)
+    got = _run("c30", *grid, world, rank, decomp)
     np.save(f"{out_path}.{rank}.npy", got)
     if rank == 0:
-        np.save(f"{out_path}.single.npy", _run("c30", 14, 14, 6, 1, 0))
+        np.save(f"{out_path}.single.npy", _run("c30", *grid, 1, 0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,3 +66,30 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     for r in range(2):
         got = np.load(f"{out}.{r}.npy")
         assert np.array_equal(got[:, :, 1:-1], ref[:, :, 1:-1]), f"rank {r}"
+
+
+def test_two_latitude_slabs_on_one_gpu_equal_single_rank(tmp_path):
+    """j-slab decomposition (BASELINE config 5): each rank computes its rows, exchanges a 2-row halo of
+    t(tau+1) per step; the owned rows equal the single-rank run bit for bit."""
+    import torch.multiprocessing as mp
+    from uvic29_amd.parallel import slab_rows
+    out = str(tmp_path / "slab")
+    mp.spawn(_worker, args=(2, 29537, out, "slab"), nprocs=2, join=True)
+    ref = np.load(f"{out}.single.npy")
+    for r in range(2):
+        js, je = slab_rows(14, 2, r)
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
+
+
+def test_four_latitude_slabs_full_grid(tmp_path):
+    """The same on the 102x102x19 grid with four slabs of 25 rows (interior ranks exchange both ways)."""
+    import torch.multiprocessing as mp
+    from uvic29_amd.parallel import slab_rows
+    out = str(tmp_path / "slab4")
+    mp.spawn(_worker, args=(4, 29541, out, "slab", (102, 102, 19)), nprocs=4, join=True)
+    ref = np.load(f"{out}.single.npy")
+    for r in range(4):
+        js, je = slab_rows(102, 4, r)
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"

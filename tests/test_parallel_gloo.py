@@ -76,3 +76,72 @@ def test_two_rank_tracer_shard_equals_single_rank(tmp_path):
     for r in range(world):
         got = np.load(f"{out}.{r}.npy")
         assert np.array_equal(got[:, :, 1:13], em.a["t_taup1"][:, :, 1:13]), r
+
+
+# ---- latitude slabs (BASELINE config 5): 2-row halo exchange of t(tau+1) ----------------------
+NSTEP_SLAB = 3
+
+
+def _slab_steps(em, js, je, exchange):
+    """NSTEP_SLAB leapfrog steps of rows js..je with the host-emulated kernels."""
+    em.ctx.js, em.ctx.je = js, je
+    for _ in range(NSTEP_SLAB):
+        em.isopyc(); em.transport(nchunk=2, nthreads=32); em.convect()
+        exchange(em.a["t_taup1"])
+        a = em.a
+        a["t_taum1"], a["t_tau"], a["t_taup1"] = a["t_tau"], a["t_taup1"], a["t_taum1"]
+        em.rebind()
+    return em.a["t_tau"]
+
+
+def _slab_worker(rank, world, port, out_path):
+    for p in (ROOT, ROOT / "oracle", ROOT / "tests" / "hostemu"):
+        sys.path.insert(0, str(p))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uvic29_amd import performance_set, synthetic
+    from uvic29_amd.parallel import HALO, slab_rows
+    import emu
+    oc = synthetic.make_ocean(performance_set(3), 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    em = emu.EmuOcean(oc, to, so, c)
+    js, je = slab_rows(14, world, rank)
+
+    def exchange(tp):                      # tp (imt,km,jmt,nt), F order; rows are axis 2
+        ws, bufs = [], []
+        for peer, send, recv in ((rank - 1, slice(js - 1, js - 1 + HALO), slice(js - 1 - HALO, js - 1)),
+                                 (rank + 1, slice(je - HALO, je), slice(je, je + HALO))):
+            if 0 <= peer < world:
+                sb = torch.from_numpy(np.ascontiguousarray(tp[:, :, send, :]))
+                rb = torch.empty_like(sb)
+                ws += [dist.isend(sb, peer), dist.irecv(rb, peer)]
+                bufs.append((recv, rb))
+        for w in ws:
+            w.wait()
+        for recv, rb in bufs:
+            tp[:, :, recv, :] = rb.numpy()
+
+    got = _slab_steps(em, js, je, exchange)
+    np.save(f"{out_path}.{rank}.npy", got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_latitude_slabs_equal_single_rank(tmp_path):
+    sys.path.insert(0, str(ROOT / "tests" / "hostemu"))
+    from uvic29_amd import performance_set, synthetic
+    from uvic29_amd.parallel import slab_rows
+    import emu
+    world = 2
+    out = str(tmp_path / "slab")
+    mp.spawn(_slab_worker, args=(world, 29517, out), nprocs=world, join=True)
+    oc = synthetic.make_ocean(performance_set(3), 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    ref = _slab_steps(emu.EmuOcean(oc, to, so, c), 2, 13, lambda tp: None)
+    assert np.isfinite(ref).all()
+    for r in range(world):
+        js, je = slab_rows(14, world, r)
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), r
+    assert slab_rows(102, 8, 0) == (2, 14) and slab_rows(102, 8, 7)[1] == 101

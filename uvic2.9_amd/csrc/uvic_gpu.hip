@@ -44,25 +44,28 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
   const int k = (int)((gid / (c).imt) % (c).km) + 1;          \
   const int j = (int)(gid / ((long long)(c).imt * (c).km)) + 1
 
+// latitude-slab runs (uvic_gpu_set_shard js..je): the T,S-derived fields are needed two rows beyond the slab
+// (SURVEY.md §8e); rows further out are left alone
+#define SLAB_OUT(c, j) ((j) < (c).js - 2 || (j) > (c).je + 2)
 __global__ void __launch_bounds__(256) k_isopyc_elements(const uvic_ctx c) {
   CELL_DECODE(c);
-  if (j > c.jmt || i < 2 || i > c.imt - 1) return;
+  if (j > c.jmt || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   isopyc_elements_cell(c, i, k, j);
 }
 __global__ void __launch_bounds__(256) k_isopyc_ai(const uvic_ctx c) {
   CELL_DECODE(c);
-  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   isopyc_ai_cell(c, i, k, j);
 }
 __global__ void __launch_bounds__(256) k_isopyc_adv(const uvic_ctx c) {
   CELL_DECODE(c);
-  if (j > c.jmt - 1) return;
+  if (j > c.jmt - 1 || SLAB_OUT(c, j)) return;
   isopyc_adv_cell(c, i, k, j);
 }
 __global__ void __launch_bounds__(128) k_isopyc_column(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
-  if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   isopyc_column(c, i, j);
 }
 
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(256) k_vmixc(const uvic_ctx c) {
 }
 __global__ void __launch_bounds__(256) k_coef(const uvic_ctx c, double *cf) {
   CELL_DECODE(c);
-  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
+  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   coef_cell(c, cf, i, k, j);
 }
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {

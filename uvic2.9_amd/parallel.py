@@ -13,6 +13,14 @@ Hence the schedule per step:
     all ranks  : all-gather of t(:,:,:,slice,tau+1)      -- the one real exchange
     every rank : convct2 on all tracers                  -- replicated, ~0.2 % of the step
 
+Latitude-slab decomposition (BASELINE config 5, `SlabShard`): rank r owns the contiguous rows
+js..je of every field and every tracer; isopyc, MOBI, transport and convection all run on the slab
+(the T,S-derived fields two rows beyond it, redundantly), and after the step the two outermost
+owned rows of t(tau+1) on each side go to the neighbour's halo: 2 x imt x km x nt x 8 B per
+neighbour and direction, point to point (RCCL send/recv over xGMI).  Longitude is cyclic and stays
+on the rank.  Every rank keeps the full-size arrays (global row indices, no re-indexing); only its
+slab and halo are ever touched.
+
 The tracer dimension is padded to a multiple of the world size so that every
 rank contributes an equal, contiguous chunk and the all-gather runs in place on
 the device buffer of t(tau+1) (torch.distributed.all_gather_into_tensor, RCCL).
@@ -86,3 +94,91 @@ class TracerShard:
                 dist.all_gather_into_tensor(host, mine.cpu())
                 full.copy_(host)
         check(model.lib.uvic_gpu_convect_async(model.h), "convect_async")
+
+
+HALO = 2   # rows: FCT needs R+-Y of rows r+-1, each of which needs t of its own r+-1
+
+
+def slab_rows(jmt: int, world: int, rank: int):
+    """Owned rows (1-based, inclusive) of `rank`: the computed rows 2..jmt-1 split into contiguous slabs."""
+    n = jmt - 2
+    base, rem = divmod(n, world)
+    lo = 2 + rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0) - 1
+    return lo, hi
+
+
+class SlabShard:
+    """Latitude-slab decomposition with a 2-row halo exchange of t(tau+1) per step."""
+
+    def __init__(self, jmt: int, world: int = 1, rank: int = 0):
+        self.jmt, self.world, self.rank = jmt, world, rank
+        self.js, self.je = slab_rows(jmt, world, rank)
+        if world > 1 and self.je - self.js + 1 < HALO:
+            raise ValueError(f"slab of {self.je - self.js + 1} rows is thinner than the halo ({HALO}): use fewer ranks")
+        self.nt_model = None
+        self._views = {}
+        self._stream = None
+
+    def apply(self, model):
+        model.set_shard(js=self.js, je=self.je)
+
+    def _rows(self, model, name):
+        """t field as a (nt, jmt, imt*km) strided view of the device buffer."""
+        import torch
+        ptr = model.devptr(name)
+        if ptr not in self._views:
+            n = model.imt * model.km * model.jmt * model.nt
+            flat = torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{model.device}")
+            self._views[ptr] = flat.view(model.nt, model.jmt, model.imt * model.km)
+        return self._views[ptr]
+
+    def exchange(self, model, name="t_taup1"):
+        """Send the outermost HALO owned rows to the neighbours, receive theirs into the halo rows."""
+        import torch
+        import torch.distributed as dist
+        t = self._rows(model, name)
+        js, je = self.js - 1, self.je - 1          # 0-based
+        south, north = self.rank - 1, self.rank + 1
+        jobs = []                                   # (peer, send rows slice, recv rows slice)
+        if south >= 0:
+            jobs.append((south, slice(js, js + HALO), slice(js - HALO, js)))
+        if north < self.world:
+            jobs.append((north, slice(je - HALO + 1, je + 1), slice(je + 1, je + 1 + HALO)))
+        if not jobs:
+            return
+        nccl = dist.get_backend() == "nccl"
+        sends = [t[:, s, :].contiguous() for _, s, _ in jobs]
+        recvs = [torch.empty_like(b) for b in sends]
+        if nccl:
+            ops = []
+            for (peer, _, _), sb, rb in zip(jobs, sends, recvs):
+                ops.append(dist.P2POp(dist.isend, sb, peer))
+                ops.append(dist.P2POp(dist.irecv, rb, peer))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        else:                                       # rehearsal backend: staged through the host
+            torch.cuda.current_stream().synchronize()
+            hs = [b.cpu() for b in sends]
+            hr = [torch.empty_like(b) for b in hs]
+            ws = []
+            for (peer, _, _), sb, rb in zip(jobs, hs, hr):
+                ws.append(dist.isend(sb, peer))
+                ws.append(dist.irecv(rb, peer))
+            for w in ws:
+                w.wait()
+            for rb, hb in zip(recvs, hr):
+                rb.copy_(hb)
+        for (_, _, r), rb in zip(jobs, recvs):
+            t[:, r, :].copy_(rb)
+
+    def step(self, model):
+        """One device-resident step of the slab and the halo exchange (no host sync with RCCL)."""
+        model.step_async()
+        if self.world == 1:
+            return
+        import torch
+        if self._stream is None:
+            self._stream = torch.cuda.ExternalStream(model.lib.uvic_gpu_stream(model.h), device=f"cuda:{model.device}")
+        with torch.cuda.stream(self._stream):
+            self.exchange(model, "t_taup1")
