@@ -297,23 +297,45 @@ UVIC_DEV void isopyc_column(const uvic_ctx &c, int i, int j) {
   UV_DIMS(c);
   double run = 0.0;
   const int kz = c.kmt[X2(i, j)];
+  // The running sum is the only level-to-level dependency.  The operands of eight levels are read
+  // before their eight sums are stored: stores may alias the next loads as far as the compiler knows,
+  // so a level-by-level loop would pay one memory round trip per level.
 #define IDXF(ii) XF(ii, k, j)
-  for (int k = 0; k <= km; ++k) {
-    double v = 0.0;
-    if (k >= 1 && k <= km - 1) {
-      const double d = c.dzt[k - 1] * c.cstr[j - 1] *
-                       ((c.adv_vetiso[X3(i, k, j)] - c.adv_vetiso[X3(i - 1, k, j)]) * c.dxtr[i - 1] +
-                        (c.adv_vntiso[X3(i, k, j)] - c.adv_vntiso[X3(i, k, j - 1)]) * c.dytr[j - 1]);
-      run = d + run;
-      v = run;
+  for (int k0 = 0; k0 <= km; k0 += 8) {
+    double d[8], vb[8];
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      d[u] = 0.0; vb[u] = 0.0;
+      if (k <= km) {
+        vb[u] = c.adv_vbt[XF(i, k, j)];
+        if (k >= 1 && k <= km - 1)
+          d[u] = c.dzt[k - 1] * c.cstr[j - 1] *
+                 ((c.adv_vetiso[X3(i, k, j)] - c.adv_vetiso[X3(i - 1, k, j)]) * c.dxtr[i - 1] +
+                  (c.adv_vntiso[X3(i, k, j)] - c.adv_vntiso[X3(i, k, j - 1)]) * c.dytr[j - 1]);
+      }
     }
-    if (k == kz) v = 0.0;
-    UV_CYC_STORE(c.adv_vbtiso, IDXF, i, v);
-    UV_CYC_STORE(c.tot_b, IDXF, i, c.adv_vbt[XF(i, k, j)] + v);
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      if (k > km) break;
+      double v = 0.0;
+      if (k >= 1 && k <= km - 1) {
+        run = d[u] + run;
+        v = run;
+      }
+      if (k == kz) v = 0.0;
+      UV_CYC_STORE(c.adv_vbtiso, IDXF, i, v);
+      UV_CYC_STORE(c.tot_b, IDXF, i, vb[u] + v);
+    }
   }
 #undef IDXF
   if (!c.diff_cbt_given)
-    for (int k = 1; k <= km; ++k) c.diff_cbt[X3(i, k, j)] = c.diff_cbt_bg[X3(i, k, j)] + c.K33[X3(i, k, j)];
+    for (int k0 = 1; k0 <= km; k0 += 8) {
+      double s[8];
+      _Pragma("unroll") for (int u = 0; u < 8; ++u)
+        s[u] = (k0 + u <= km) ? c.diff_cbt_bg[X3(i, k0 + u, j)] + c.K33[X3(i, k0 + u, j)] : 0.0;
+      _Pragma("unroll") for (int u = 0; u < 8; ++u)
+        if (k0 + u <= km) c.diff_cbt[X3(i, k0 + u, j)] = s[u];
+    }
 }
 
 }  // namespace uvic
