@@ -230,6 +230,11 @@ def main():
             pr = m.profile_read()
             nxt = {k: round(pr[k], 5) for k in ("adv_vel_hor", "adv_vel_vert", "vmixc") if k in pr}
             m.set_params(diff_cbt_has_k33=0)
+            m.set_filter(ocean, synthetic.make_filter(ocean.grid, km))     # §8(f) rank 3: polar Fourier filter
+            pf = m.profile(nrep=3)
+            if "filt" in pf:
+                nxt["filt"] = round(pf["filt"], 5)
+            m.set_filter(ocean, None)
         except Exception as e:   # never let the side measurement break the bench line
             nxt = {"error": str(e)}
         prof = live

@@ -222,6 +222,15 @@ int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p);
  * uvic_params.diff_cbt_has_k33 = 1 (isopyc then leaves diff_cbt to this call). */
 int uvic_gpu_vmixc(uvic_gpu *h);
 
+/* ---- polar Fourier filter of the tracers ---------------------------------
+ * replaces `call filt (joff, js, je)` inside tracer (u09/mom/tracer.F:1245; source/common/filt.F,
+ * filtr.F, findex.F with O_fourfil O_cyclic).  Called once after kmt and the grid metrics are uploaded:
+ * the ocean strips of the rows jfrst..jft1 and jft2..jmt-1 (index.h, set in u09/common/setcom.F:75-85)
+ * and their filter operators are built on the host and kept on the device; from then on every
+ * uvic_gpu_tracer / uvic_gpu_convect filters t(tau+1) after convection.  jfrst > jmt switches it off.
+ * `pi` is the reference's constant (scalar.h), `lsegf` the strip limit of index.h:34. */
+int uvic_gpu_set_filter(uvic_gpu *h, double pi, int jfrst, int jft0, int jft1, int jft2, int lsegf);
+
 /* run `nrep` x [isopyc, tracer] back to back and return the mean duration in
  * milliseconds of every kernel, measured with HIP events on the launch stream;
  * names[i] points to static strings.  Used by bench.py for the roofline. */

@@ -69,7 +69,7 @@ SOURCES = [
     "updates/09/source/mom/isopyc.F", "source/mom/invtri.F",
     "updates/09/source/mom/mobi.F", "updates/09/source/common/co2calc.F",
     "source/mom/convect.F", "updates/09/source/mom/set_sbc.F",
-    "source/common/util.F", "source/common/filt.F", "source/common/filtr.F",
+    "source/common/util.F", "source/common/filt.F", "source/common/filtr.F", "source/common/findex.F",
     "updates/09/source/common/iomngr.F", "updates/09/source/common/file_names.F",
     "updates/09/source/common/UVic_ESCM.F",
     "source/mom/state.F", "source/mom/denscoef.F", "source/mom/adv_vel.F",

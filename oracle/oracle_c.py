@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "liboracle.so"
-SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c", HERE / "prep_oracle.c"]
+SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c", HERE / "prep_oracle.c", HERE / "filter_oracle.c"]
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)
@@ -176,3 +176,43 @@ def vmixc(g, topo, tidal, alphai, betai, ddzt, K33, diff_cbt_prev):
                     _p(be), _p(dz), _p(k33), *[_p(a) for a in e], D(tidal.kappa_h), D(tidal.zetar), D(tidal.ogamma),
                     D(tidal.gravrho0r), _p(out))
     return out
+
+
+# ---- polar Fourier filter (filter_oracle.c) ------------------------------------------------------
+def findex(kmt, flt):
+    """istf, ietf (jmtfil, lsegf, km) for the filtered rows as findex.F (O_cyclic)."""
+    imt, jmt = kmt.shape
+    km = flt.km
+    kx = np.asfortranarray(kmt, dtype=np.int32)
+    isf = np.zeros((flt.jmtfil, flt.lsegf, km), dtype=np.int32, order="F")
+    ief = np.zeros_like(isf)
+    rc = lib().orc_findex(kx.ctypes.data_as(_I), ctypes.c_int(imt), ctypes.c_int(jmt), ctypes.c_int(km), ctypes.c_int(flt.jfrst),
+                          ctypes.c_int(flt.jft1), ctypes.c_int(flt.jft2), ctypes.c_int(flt.lsegf), ctypes.c_int(flt.jmtfil),
+                          isf.ctypes.data_as(_I), ief.ctypes.data_as(_I))
+    if rc:
+        raise RuntimeError(f"orc_findex: more strips than lsegf or rows than jmtfil (rc={rc})")
+    return isf, ief
+
+
+def filt(t_taup1, g, topo, flt, istf, ietf, js=2, je=None):
+    """Fourier-filter rows js..je of t(imt,km,jmt,nt) in place as filt.F does inside `tracer`."""
+    imt, km, jmt, nt = t_taup1.shape
+    je = jmt - 1 if je is None else je
+    assert t_taup1.flags.f_contiguous
+    kx = np.asfortranarray(topo.kmt, dtype=np.int32)
+    cst, cstr = np.ascontiguousarray(g.cst), np.ascontiguousarray(g.cstr)
+    rc = lib().orc_filt(_p(t_taup1), ctypes.c_int(imt), ctypes.c_int(km), ctypes.c_int(jmt), ctypes.c_int(nt),
+                        kx.ctypes.data_as(_I), _p(cst), _p(cstr), ctypes.c_double(g.pi), ctypes.c_int(flt.jfrst),
+                        ctypes.c_int(flt.jft0), ctypes.c_int(flt.jft1), ctypes.c_int(flt.jft2), ctypes.c_int(flt.lsegf),
+                        ctypes.c_int(flt.jmtfil), istf.ctypes.data_as(_I), ietf.ctypes.data_as(_I), ctypes.c_int(js),
+                        ctypes.c_int(je))
+    if rc:
+        raise RuntimeError("orc_filt: filtr hit one of the reference's stop conditions")
+    return t_taup1
+
+
+def setbcx(a):
+    """Cyclic images of columns 2 and imt-1 (source/common/util.F:789-814), in place on the first axis."""
+    a[0] = a[-2]
+    a[-1] = a[1]
+    return a

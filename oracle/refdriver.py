@@ -171,6 +171,31 @@ class RefOcean:
         g = self.ocean.grid
         self.ref.call("tracer", 0, 2, g.jmt - 1, 2, g.imt - 1)
 
+    # -- polar Fourier filter -------------------------------
+    def set_filter(self, flt):
+        """Switch the polar filter of `tracer` on: filter rows as setcom.F computes them, strips by the
+        reference's own findex (setmom.F:729)."""
+        S, v = self.ref.set, self.v
+        if flt.jmtfil != v["istf"].shape[0] or flt.lsegf != v["istf"].shape[1]:
+            raise ValueError("filter dimensions differ from the reference build (index.h: jmtfil=50, lsegf=20)")
+        S("jfrst", flt.jfrst); S("jft0", flt.jft0); S("jft1", flt.jft1); S("jft2", flt.jft2); S("jskpt", flt.jskpt)
+        S("njtbft", flt.njtbft)
+        v["istf"][...] = 0
+        v["ietf"][...] = 0
+        g = self.ocean.grid
+        self.ref.call("findex", v["kmt"], flt.jmtfil, g.km, flt.jft1, flt.jft2, g.imt, v["istf"], v["ietf"])
+        return np.array(v["istf"], order="F"), np.array(v["ietf"], order="F")
+
+    def filt(self):
+        """source/common/filt.F on t(taup1) as called at tracer.F:1245."""
+        g = self.ocean.grid
+        saved = self._silence()
+        try:
+            self.ref.call("filt", 0, 2, g.jmt - 1)
+        finally:
+            self._restore(saved)
+        return self.v["t"][..., 2]
+
     # -- producers of the shared inputs (SURVEY.md §8f rank 1) -------------------
     def adv_vel(self):
         """source/mom/adv_vel.F with the arguments of mom.F:332 for one memory window; returns

@@ -17,6 +17,8 @@
 #include "../../uvic2.9_amd/csrc/kernels_isopyc.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_mobi.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_prep.hpp"
+#include "../../uvic2.9_amd/csrc/kernels_filter.hpp"
+#include "../../uvic2.9_amd/csrc/filter_host.hpp"
 
 using namespace uvic;
 
@@ -92,6 +94,24 @@ extern "C" void emu_vmixc(const uvic_ctx *cp) {
   for (int j = 2; j <= c.jmt - 1; ++j)
     for (int k = 1; k <= c.km; ++k)
       for (int i = 2; i <= c.imt - 1; ++i) vmixc_cell(c, i, k, j);
+}
+
+// polar filter: the library's host set-up + the workgroup routine under HostEnv
+extern "C" int emu_filt(const uvic_ctx *cp, double pi, int jfrst, int jft0, int jft1, int jft2, int lsegf, int nthreads) {
+  const uvic_ctx &c = *cp;
+  FilterSetup fs;
+  std::string err;
+  if (filter_build(c.imt, c.jmt, c.km, c.kmt, c.cst, c.cstr, pi, jfrst, jft0, jft1, jft2, lsegf, fs, err)) return -1;
+  std::vector<double> lds((size_t)2 * nthreads + 4);
+  HostEnv env{nthreads};
+  for (int n = c.n0 + 1; n <= c.n0 + c.nt_local; ++n)
+    for (const FilterItem &it : fs.items) {
+      if (it.j < c.js || it.j > c.je) continue;
+      if (it.im > nthreads) return -2;
+      std::fill(lds.begin(), lds.end(), -7.0e33);
+      filt_block(env, c, it, n, fs.mats.data(), lds.data());
+    }
+  return (int)fs.items.size();
 }
 
 // MOBI column kernel on the host: same source as the GPU kernel, libm instead of ocml

@@ -30,3 +30,28 @@ def test_overlay_tracer_matches_reference_tracer(cfg, dims, monkeypatch):
     for n, name in enumerate(oc.cfg.tracers):
         a, b = got[:, :, 1:jmt - 1, n], want[:, :, 1:jmt - 1, n]
         assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (name, np.abs(a - b).max())
+
+
+def test_overlay_tracer_with_polar_filter_matches_reference(monkeypatch):
+    """The same with the polar Fourier filter of `tracer` switched on (O_fourfil; filter rows from setcom.F's
+    latitudes): the overlay hands jfrst, jft0-2 of index.h to uvic_gpu_set_filter once, the device then
+    filters t(taup1) after convection as tracer.F:1245 does."""
+    monkeypatch.setenv("UVIC_EXACT", "1")
+    cfg, dims = "p2", (14, 14, 6)
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    flt = synthetic.make_filter(oc.grid, dims[2])
+    ref = refdriver.RefOcean(oc)
+    if not hasattr(ref.ref.lib, "findex_"):
+        pytest.skip("oracle/_ref predates findex")
+    plain = ref.step().copy()
+    ref = refdriver.RefOcean(oc)                 # (one library = one set of COMMON blocks: start over)
+    ref.set_filter(flt)
+    want = ref.step().copy()
+    assert (want != plain).any()                 # the filter did something
+    shim = refdriver.RefOcean(oc, shim=True)
+    shim.set_filter(flt)
+    got = shim.step().copy()
+    assert np.array_equal(got[:, :, 1:-1], want[:, :, 1:-1])

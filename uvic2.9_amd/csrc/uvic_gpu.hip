@@ -17,6 +17,8 @@
 #include "../../include/uvic_gpu.h"
 #include "kernels_col.hpp"
 #include "kernels_prep.hpp"
+#include "kernels_filter.hpp"
+#include "filter_host.hpp"
 #include "kernels_fct.hpp"
 #include "kernels_isopyc.hpp"
 #include "kernels_mobi.hpp"
@@ -167,6 +169,15 @@ __global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_
   if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
   mobi_post_cell(c, m, i, k, j);
 }
+// polar Fourier filter: one workgroup per (strip of a level of a row, local tracer)
+__global__ void __launch_bounds__(1024) k_filt(const uvic_ctx c, const FilterItem *items, const double *mats, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int item = blockIdx.x % nitems, n1 = c.n0 + blockIdx.x / nitems + 1;
+  const FilterItem it = items[item];
+  if (it.j < c.js || it.j > c.je) return;     // latitude-slab runs filter their own rows only
+  GpuEnv env;
+  filt_block(env, c, it, n1, mats, lds);
+}
 // team form: four waves (one per SIMD of a CU) share 64 columns, each with its own compile-time
 // role, see kernels_mobi.hpp
 template <int R>
@@ -313,6 +324,10 @@ struct uvic_gpu {
   mobi_store mobi_st;
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
+  // polar filter (uvic_gpu_set_filter): strips and operators, built once
+  FilterItem *flt_items;
+  double *flt_mats;
+  int flt_nitems, flt_threads;
   double mobi_dtnpzd;
   bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
   // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
@@ -400,6 +415,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->profiling = false;
   h->have_mobi = false;
   h->have_vmix = false;
+  h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -488,6 +504,8 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
   (void)hipFree(h->coef);
+  (void)hipFree(h->flt_items);
+  (void)hipFree(h->flt_mats);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
   (void)hipFree(h->cv_z);
   if (h->mobi_st.params) {
@@ -711,6 +729,12 @@ static int launch_convect(uvic_gpu *h) {
       mark(h, "convect_apply");
     }
   }
+  if (h->flt_nitems > 0 && h->ctx.nt_local > 0) {   // filt follows convection inside `tracer` (tracer.F:1245)
+    hipLaunchKernelGGL(k_filt, dim3((unsigned)h->flt_nitems * (unsigned)h->ctx.nt_local), dim3(h->flt_threads),
+                       (size_t)(2 * h->flt_threads + 4) * 8, h->stream, h->ctx, (const FilterItem *)h->flt_items,
+                       (const double *)h->flt_mats, h->flt_nitems);
+    mark(h, "filt");
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -766,6 +790,42 @@ static int launch_vmixc(uvic_gpu *h) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+// polar Fourier filter of t(tau+1): strips and operators from kmt and the grid already uploaded
+extern "C" int uvic_gpu_set_filter(uvic_gpu *h, double pi, int jfrst, int jft0, int jft1, int jft2, int lsegf) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  (void)hipFree(h->flt_items); h->flt_items = nullptr;
+  (void)hipFree(h->flt_mats); h->flt_mats = nullptr;
+  h->flt_nitems = 0;
+  if (jfrst > h->d.jmt) return 0;          // `jrow .lt. jfrst` for every row: filter off
+  if (lsegf < 1) return fail_msg("uvic_gpu_set_filter: lsegf < 1");
+  const uvic_dims &d = h->d;
+  std::vector<int> kmt((size_t)d.imt * d.jmt);
+  std::vector<double> cst(d.jmt), cstr(d.jmt);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(kmt.data(), h->buf[UVIC_F_KMT], kmt.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cst.data(), h->buf[UVIC_F_CST], cst.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cstr.data(), h->buf[UVIC_F_CSTR], cstr.size() * 8, hipMemcpyDeviceToHost));
+  FilterSetup fs;
+  std::string err;
+  if (int rc = filter_build(d.imt, d.jmt, d.km, kmt.data(), cst.data(), cstr.data(), pi, jfrst, jft0, jft1, jft2, lsegf, fs, err)) {
+    g_err = err;
+    return rc;
+  }
+  if (fs.items.empty()) return 0;
+  int maxim = 0;
+  for (auto &it : fs.items) maxim = it.im > maxim ? it.im : maxim;
+  if (maxim > 1024) return fail_msg("uvic_gpu_set_filter: strips longer than 1024 columns are not supported");
+  h->flt_threads = ((maxim + 63) / 64) * 64;
+  HIPCHK(hipMalloc((void **)&h->flt_items, fs.items.size() * sizeof(FilterItem)));
+  HIPCHK(hipMemcpy(h->flt_items, fs.items.data(), fs.items.size() * sizeof(FilterItem), hipMemcpyHostToDevice));
+  const size_t nm = fs.mats.empty() ? 1 : fs.mats.size();
+  HIPCHK(hipMalloc((void **)&h->flt_mats, nm * 8));
+  if (!fs.mats.empty()) HIPCHK(hipMemcpy(h->flt_mats, fs.mats.data(), fs.mats.size() * 8, hipMemcpyHostToDevice));
+  h->flt_nitems = (int)fs.items.size();
+  return 0;
+}
+
 extern "C" int uvic_gpu_adv_vel(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));

@@ -97,6 +97,13 @@
           real(c_double) :: sgb(*), fe_atmdep(*), fe_hydr(*)
           integer(c_int) :: rc
         end function
+        function uvic_gpu_set_filter(h, pi, jfrst, jft0, jft1, jft2, lsegf) bind(C,name='uvic_gpu_set_filter') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double), value :: pi
+          integer(c_int), value :: jfrst, jft0, jft1, jft2, lsegf
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_isopyc(h) bind(C,name='uvic_gpu_isopyc') result(rc)
           import
           type(c_ptr), value :: h

@@ -285,6 +285,34 @@ def make_tidal(g, topo, kappa_h=0.35):
                            kappa_h=float(kappa_h), zetar=zetar, ogamma=0.2 * rho0r * zetar, gravrho0r=grav * rho0r)
 
 
+def indp(value, array):
+    """1-based index of the element of the increasing `array` nearest to `value`
+    (/root/reference/source/common/util.F `indp`)."""
+    a = np.asarray(array)
+    if value < a[0]:
+        return 1
+    if value > a[-1]:
+        return len(a)
+    for i in range(1, len(a)):
+        if value <= a[i]:
+            return i if a[i] - value > value - a[i - 1] else i + 1
+    return len(a)
+
+
+def make_filter(g, km, lsegf=20, jmtfil=50):
+    """Rows of the polar Fourier filter of the tracers from the latitudes of
+    /root/reference/updates/09/source/common/setcom.F:36-40, 75-85 (rjfrst=-87.3, rjft0=-67.5,
+    rjft1=-69.3, rjft2=69.3); lsegf, jmtfil as source/common/index.h:34."""
+    yt = g.yt
+    f = SimpleNamespace(jfrst=indp(-87.3, yt), jft0=indp(-67.5, yt), jft1=indp(-69.3, yt), jft2=indp(69.3, yt),
+                        lsegf=lsegf, jmtfil=jmtfil, km=km)
+    f.jskpt = f.jft2 - f.jft1
+    f.njtbft = (f.jft1 - f.jfrst + 1) + (g.jmt - 1 - f.jft2 + 1)
+    if f.njtbft > jmtfil:
+        f.jmtfil = f.njtbft
+    return f
+
+
 def F_(a):
     return np.asfortranarray(a, dtype=np.float64)
 

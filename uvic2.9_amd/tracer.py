@@ -142,6 +142,15 @@ class TracerModel:
         isopyc() with set_params(diff_cbt_has_k33=1)."""
         check(self.lib.uvic_gpu_vmixc(self.h), "vmixc")
 
+    def set_filter(self, ocean, flt):
+        """Polar Fourier filter of t(tau+1) after convection (source/common/filt.F); `flt` as
+        synthetic.make_filter.  Call after load_ocean.  flt=None switches it off."""
+        if flt is None:
+            check(self.lib.uvic_gpu_set_filter(self.h, float(ocean.grid.pi), self.jmt + 1, 1, 1, 2, 1), "set_filter")
+        else:
+            check(self.lib.uvic_gpu_set_filter(self.h, float(ocean.grid.pi), flt.jfrst, flt.jft0, flt.jft1, flt.jft2, flt.lsegf),
+                  "set_filter")
+
     def set_shard(self, n0=0, nt_local=None, js=2, je=None):
         nt_local = self.nt - n0 if nt_local is None else nt_local
         je = self.jmt - 1 if je is None else je
