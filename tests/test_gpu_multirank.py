@@ -32,6 +32,7 @@ def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
     m.load_ocean(ocean, to, so, c)
     if cfg.ntnpzd:
         m.set_mobi(ocean)
+    m.set_filter(ocean, synthetic.make_filter(ocean.grid, km))      # polar filter on: it must commute with both decompositions
     shard.apply(m)
     loop = TimeLoop(m, ocean.params.dtts, nmix=3, shard=shard if world > 1 else None)
     for _ in range(NSTEP):

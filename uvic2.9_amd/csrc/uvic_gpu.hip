@@ -729,9 +729,11 @@ static int launch_convect(uvic_gpu *h) {
       mark(h, "convect_apply");
     }
   }
-  if (h->flt_nitems > 0 && h->ctx.nt_local > 0) {   // filt follows convection inside `tracer` (tracer.F:1245)
-    hipLaunchKernelGGL(k_filt, dim3((unsigned)h->flt_nitems * (unsigned)h->ctx.nt_local), dim3(h->flt_threads),
-                       (size_t)(2 * h->flt_threads + 4) * 8, h->stream, h->ctx, (const FilterItem *)h->flt_items,
+  if (h->flt_nitems > 0) {   // filt follows convection inside `tracer` (tracer.F:1245); like convection it
+    uvic_ctx cf = h->ctx;    // runs on every tracer (under tracer sharding: replicated, after the exchange)
+    cf.n0 = 0; cf.nt_local = h->d.nt;
+    hipLaunchKernelGGL(k_filt, dim3((unsigned)h->flt_nitems * (unsigned)h->d.nt), dim3(h->flt_threads),
+                       (size_t)(2 * h->flt_threads + 4) * 8, h->stream, cf, (const FilterItem *)h->flt_items,
                        (const double *)h->flt_mats, h->flt_nitems);
     mark(h, "filt");
   }
