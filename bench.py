@@ -268,7 +268,7 @@ def main():
             "step_hbm": {"alg_bytes_per_cell_update": b_alg(nt, nsrc), "achieved_GBs": step_gbs,
                          "frac_of_peak": step_gbs / HBM_PEAK_GBS},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU baseline is reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(ocean, to, so, c, src)
         print(json.dumps(out), flush=True)
     m.close()
