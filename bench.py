@@ -51,7 +51,7 @@ def kernel_alg_bytes(name, nt, nsrc):
 
 
 def pmc_traffic(kernel, workload_ok):
-    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of tools_profile_round.sh
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of tools/profile_round.sh
     (FETCH_SIZE + WRITE_SIZE in separate passes, corrected by the 8-B-per-lane calibration of
     tools/calib_traffic.hip as MI355X_MICROARCH.md prescribes).  The counters cannot be read from
     inside this process: the figure comes from the committed summary of the SAME command

@@ -2,7 +2,7 @@
 // (8 bytes per lane, coalesced along i): MI355X_MICROARCH.md calibrates only 16 B/lane and says
 // other widths must be calibrated on a known byte count.  k_calib_read8 reads N doubles and writes
 // N/64 doubles; k_calib_copy8 reads N and writes N.  Run under `rocprofv3 --pmc FETCH_SIZE` and
-// `--pmc WRITE_SIZE` (separate passes); tools_pmc_summary.py divides the known bytes by the counters.
+// `--pmc WRITE_SIZE` (separate passes); tools/pmc_summary.py divides the known bytes by the counters.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Run the MOBI pass once with the -DUV_MOBI_TIMING build (per-phase cycle counters printed by the team kernel)."""
+"""One isopyc + tracer step with the -DUV_COL_TIMING build (per-wave cycle counters printed by colupd)."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from uvic29_amd import OPTION_SETS, synthetic  # noqa: E402
 from uvic29_amd.tracer import TracerModel  # noqa: E402
@@ -13,5 +13,4 @@ to, so, c = synthetic.load_eos(km)
 m = TracerModel(imt, jmt, km, cfg.nt, cfg.nsrc, cfg.ntnpzd, device=0)
 m.load_ocean(ocean, to, so, c)
 m.set_mobi(ocean)
-m.mobi(); m.sync()
-m.mobi(); m.sync()
+m.isopyc(); m.tracer(); m.sync()

@@ -3,7 +3,7 @@
 per-sub-step cost from the per-level prologue/epilogue.  GPU only; diagnostic, not a test."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent
+ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from uvic29_amd import OPTION_SETS, synthetic, mobi as pm  # noqa: E402
 from uvic29_amd.tracer import TracerModel  # noqa: E402

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 --pmc passes of tools_profile_round.sh: mean per launch of every counter per kernel,
+"""Summarise the rocprofv3 --pmc passes of tools/profile_round.sh: mean per launch of every counter per kernel,
 and HBM traffic per launch corrected as MI355X_MICROARCH.md (HBM / rocprofv3 PMC slots) prescribes:
 FETCH_SIZE and WRITE_SIZE are in KB; their relation to real bytes depends on the access width, so both are
 calibrated on tools/calib_traffic.hip (8 B per lane coalesced reads/writes of a known size, the width the
-transport kernels use).    usage: tools_pmc_summary.py <pmc dir> [traffic.json]"""
+transport kernels use).    usage: tools/pmc_summary.py <pmc dir> [traffic.json]"""
 import collections
 import csv
 import glob
@@ -26,7 +26,7 @@ def mean(v):
     return sum(v) / len(v)
 
 
-print("rocprofv3 --pmc passes (tools_profile_round.sh), bench.py c30 102x102x19 nt=30; mean per launch")
+print("rocprofv3 --pmc passes (tools/profile_round.sh), bench.py c30 102x102x19 nt=30; mean per launch")
 for d in ["sq1", "sq2", "fetch", "write", "tcc"]:
     agg = load(d)
     for k in sorted(agg):

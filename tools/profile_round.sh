@@ -3,7 +3,7 @@
 #   bench.json            the bench line (with cpu_baseline)
 #   kernel_stats.csv      rocprofv3 --kernel-trace --stats summary of the same command
 #   pmc_*                 separate --pmc passes (SQ, FETCH_SIZE, WRITE_SIZE, TCC) + calibration passes
-#   traffic.json, pmc_summary.txt   from tools_pmc_summary.py
+#   traffic.json, pmc_summary.txt   from tools/pmc_summary.py
 # Copy what is to be judged into profiles/ (gpurun_out/ is scratch).
 R=$PWD; O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
 BENCH="python3 $R/bench.py --steps 64 --warmup 4"
@@ -19,7 +19,7 @@ run tcc TCC_HIT_sum TCC_MISS_sum
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc/calib_fetch -- $R/tools/calib_traffic.bin 64 > $O/pmc_calib_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc/calib_write -- $R/tools/calib_traffic.bin 64 > $O/pmc_calib_write.log 2>&1 || exit 1
 cd $R
-python3 tools_pmc_summary.py $O/pmc $O/traffic.json > $O/pmc_summary.txt 2>&1 || exit 1
+python3 tools/pmc_summary.py $O/pmc $O/traffic.json > $O/pmc_summary.txt 2>&1 || exit 1
 cp $O/traffic.json $R/gpurun_out/traffic_latest.json
 UVIC_TRAFFIC_JSON=$O/traffic.json python3 bench.py --steps 64 --warmup 4 > $O/bench.json 2> $O/bench.err || exit 1
 tail -1 $O/bench.json; tail -25 $O/pmc_summary.txt
