@@ -428,16 +428,18 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const long long tq0 = clock64();
 #endif
   {
+    // no branch around a load: the compiler's wait counts stay exact only on straight-line code, so the
+    // level index is clamped instead (the last pair re-reads level km) and an odd last level is peeled
     Lvl A, B;
     load_level(A, 1);
-    for (int k = 1; k <= km; k += 2) {
-      if (k + 1 <= km) load_level(B, k + 1);
+    int k = 1;
+    for (; k + 1 <= km; k += 2) {
+      load_level(B, k + 1);
       level(A, k);
-      if (k + 1 <= km) {
-        if (k + 2 <= km) load_level(A, k + 2);
-        level(B, k + 1);
-      }
+      load_level(A, imin(k + 2, km));
+      level(B, k + 1);
     }
+    if (k == km) level(A, km);
   }
 #ifdef UV_COL_TIMING
   const long long tq1 = clock64();
