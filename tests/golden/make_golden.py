@@ -15,6 +15,9 @@ Fixtures
                                        K33 and the GM velocities
   tests/golden/run_<cfg>_<grid>.npz    t after N leapfrog steps (mixing step every
                                        nmix-th) and the tbar/travar integrals
+  tests/golden/prep_<cfg>_<grid>.npz   outputs of the reference's adv_vel, vmixc (tidal
+                                       mixing + K33 after isopyc), findex and of one
+                                       isopyc+tracer step with the polar filter on
 """
 from __future__ import annotations
 
@@ -105,7 +108,24 @@ def run_fixture(cfg, imt, jmt, km, nsteps):
     print("wrote run", cfg, imt, jmt, km, nsteps)
 
 
+def prep_fixture(cfg, imt, jmt, km):
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    flt = synthetic.make_filter(oc.grid, km)
+    ro = refdriver.RefOcean(oc)
+    vet, vnt, vbt = ro.adv_vel()
+    ro.isopyc()
+    dcb = ro.vmixc(tid, np.asfortranarray(oc.diff_cbt_bg))
+    ro = refdriver.RefOcean(oc)
+    istf, ietf = ro.set_filter(flt)
+    tp = ro.step().copy()
+    np.savez_compressed(HERE / f"prep_{cfg}_{imt}x{jmt}x{km}.npz", adv_vet=vet, adv_vnt=vnt, adv_vbt=vbt, diff_cbt=dcb,
+                        istf=istf, ietf=ietf, t_taup1_filtered=tp)
+    print("wrote prep", cfg, imt, jmt, km)
+
+
 if __name__ == "__main__":
+    prep_fixture("p2", 14, 14, 6)
     eos_fixture()
     mobi_fixture()
     step_fixture("p2", 14, 14, 6)

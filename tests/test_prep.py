@@ -94,3 +94,25 @@ def test_gpu_adv_vel_and_vmixc(cfg, imt, jmt, km):
     assert rel.max() <= 1e-13, rel.max()
     # a whole step with the device-made inputs equals the step with the uploaded ones
     m.close()
+
+
+def test_oracle_matches_golden_fixture():
+    """The same pinning without the compiled reference at hand: tests/golden/prep_p2_14x14x6.npz holds the
+    reference's own outputs (tests/golden/make_golden.py)."""
+    import oracle_c
+    from uvic29_amd import synthetic
+    gold = np.load(ROOT / "tests" / "golden" / "prep_p2_14x14x6.npz")
+    oc, tid, eos = _setup("p2", 14, 14, 6)
+    vet, vnt, vbt = oracle_c.adv_vel(oc.grid, oc.u)
+    assert np.array_equal(vet[:, :, 1:], gold["adv_vet"][:, :, 1:]) and np.array_equal(vnt, gold["adv_vnt"])
+    assert np.array_equal(vbt[:, :, 1:], gold["adv_vbt"][:, :, 1:])
+    want, _ = _oracle_vmixc(oc, tid, eos)
+    assert np.array_equal(want[1:-1, :, 1:-1], gold["diff_cbt"][1:-1, :, 1:-1])
+    flt = synthetic.make_filter(oc.grid, 6)
+    istf, ietf = oracle_c.findex(oc.topo.kmt, flt)
+    assert np.array_equal(istf, gold["istf"]) and np.array_equal(ietf, gold["ietf"])
+    to, so, c = eos
+    orc = oracle_c.Oracle(oc, to=to, so=so, c=c)
+    orc.isopyc(); orc.add_k33()
+    got = oracle_c.setbcx(oracle_c.filt(np.array(orc.transport(), order="F"), oc.grid, oc.topo, flt, istf, ietf))
+    assert np.array_equal(got[:, :, 1:-1], gold["t_taup1_filtered"][:, :, 1:-1])
