@@ -33,12 +33,16 @@
 
 namespace uvic {
 
-enum {  // planes of the coefficient buffer, each (imt,km,jmt)
-  CF_AE = 0, CF_CE = 1,   // east face:   A, C[ip + 2*kr]
-  CF_AN = 5, CF_CN = 6,   // north face
+// slots of the coefficient buffer.  Two slots share one 16-byte element per cell (a lane fetches both with
+// one global_load_dwordx4): the buffer is (2, imt, km, jmt, CF_PAIRS).  The north-face slots come first
+// because pass A also reads them for row r-1.
+enum {
+  CF_AN = 0, CF_CN = 1,   // north face:  A, C[jq + 2*kr]
+  CF_AE = 5, CF_CE = 6,   // east face:   A, C[ip + 2*kr]
   CF_BV = 10, CF_CBX = 11, CF_CBY = 15,  // bottom face
-  CF_COUNT = 19
+  CF_COUNT = 19, CF_PAIRS = 10
 };
+#define CF_IDX(slot, q, N3) ((((size_t)((slot) / 2) * (N3)) + (q)) * 2 + ((slot) % 2))
 
 // ---------------------------------------------------------------------------
 // per-step coefficient folding; one thread per cell, i = 2..imt-1
@@ -50,37 +54,37 @@ UVIC_DEV void coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
   if (j >= 2 && j <= jmt - 1) {  // east face: tracer.F:930-942, isopyc.F:953-1002, fdift.h:61-62
     const double m = TMASK(i, k, j) * TMASK(i + 1, k, j);
     const double cstdxur = c.cstr[j - 1] * c.dxur[i - 1];
-    cf[q + (size_t)CF_AE * N3] = (c.diff_cet * cstdxur + c.K11[q] * cstdxur) * m;
+    cf[CF_IDX(CF_AE, q, N3)] = (c.diff_cet * cstdxur + c.K11[q] * cstdxur) * m;
     for (int kr = 0; kr <= 1; ++kr)
       for (int ip = 0; ip <= 1; ++ip)
-        cf[q + (size_t)(CF_CE + ip + 2 * kr) * N3] =
+        cf[CF_IDX(CF_CE + ip + 2 * kr, q, N3)] =
             -dzt4r * (c.Ai_ez[q + (size_t)(ip + 2 * kr) * N3] * drodxe(i, k, j, ip) / (drodze(i, k, j, ip, kr) + UV_EPSLN));
   }
   if (j <= jmt - 1) {  // north face: tracer.F:948-961, isopyc.F:1008-1053, fdift.h:77-78
     const double m = TMASK(i, k, j) * TMASK(i, k, j + 1);
-    cf[q + (size_t)CF_AN * N3] = (c.diff_cnt * c.csu_dyur[j - 1] + c.K22[q] * c.csu_dyur[j - 1]) * m;
+    cf[CF_IDX(CF_AN, q, N3)] = (c.diff_cnt * c.csu_dyur[j - 1] + c.K22[q] * c.csu_dyur[j - 1]) * m;
     const double csu_dzt4r = c.csu[j - 1] * dzt4r;
     for (int kr = 0; kr <= 1; ++kr)
       for (int jq = 0; jq <= 1; ++jq)
-        cf[q + (size_t)(CF_CN + jq + 2 * kr) * N3] =
+        cf[CF_IDX(CF_CN + jq + 2 * kr, q, N3)] =
             -csu_dzt4r * (c.Ai_nz[q + (size_t)(jq + 2 * kr) * N3] * drodyn(i, k, j, jq) / (drodzn(i, k, j, jq, kr) + UV_EPSLN));
   }
   if (j >= 2 && j <= jmt - 1) {  // bottom face: tracer.F:1025-1032, isopyc.F:1062-1107, fdift.h:83-88
     if (k <= km - 1) {
-      cf[q + (size_t)CF_BV * N3] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
+      cf[CF_IDX(CF_BV, q, N3)] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
       for (int ip = 0; ip <= 1; ++ip)
         for (int kr = 0; kr <= 1; ++kr)
-          cf[q + (size_t)(CF_CBX + ip + 2 * kr) * N3] =
+          cf[CF_IDX(CF_CBX + ip + 2 * kr, q, N3)] =
               -c.dxt4r[i - 1] * (c.Ai_bx[q + (size_t)(ip + 2 * kr) * N3] * c.cstr[j - 1] * drodxb(i, k, j, ip, kr) /
                                  (drodzb(i, k, j, kr) + UV_EPSLN));
       for (int jq = 0; jq <= 1; ++jq)
         for (int kr = 0; kr <= 1; ++kr)
-          cf[q + (size_t)(CF_CBY + jq + 2 * kr) * N3] =
+          cf[CF_IDX(CF_CBY + jq + 2 * kr, q, N3)] =
               -c.dyt4r[j - 1] * c.cstr[j - 1] *
               (c.Ai_by[q + (size_t)(jq + 2 * kr) * N3] * c.csu[j - 1 + jq - 1] * drodyb(i, k, j, jq, kr) /
                (drodzb(i, k, j, kr) + UV_EPSLN));
     } else {
-      for (int p = CF_BV; p < CF_COUNT; ++p) cf[q + (size_t)p * N3] = 0.0;
+      for (int p = CF_BV; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
     }
   }
 }
@@ -209,7 +213,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 #define ATB(p) (*(decltype(p))((const char *)(p) + lb))
 #define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
 #define LD(p, k, dj) AT(p, k, dj)
-#define CF(pl, k, dj) AT(cf + (size_t)(pl) * N3, k, dj)
+  const unsigned lb2 = (unsigned)(i - 1) * 16u;
+#define CFP(pair, k, dj) (*(const double2 *)((const char *)(cf + ((size_t)(pair) * N3 + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride) * 2) + lb2))
   const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
   double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
   double tc0, tc1;                                                        // levels s-1 and s of t(tau)
@@ -233,9 +238,15 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
     const double ve = AT(c.tot_e, s, 0), vn = AT(c.tot_n, s, 0), vs = AT(c.tot_n, s, -1);
     const double vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
-    double cfc[CF_COUNT], cfs[5];   // folded coefficients of row r and the north-face ones of row r-1
-    _Pragma("unroll") for (int p = 0; p < CF_COUNT; ++p) cfc[p] = CF(p, s, 0);
-    _Pragma("unroll") for (int p = 0; p < 5; ++p) cfs[p] = CF(CF_AN + p, s, -1);
+    double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
+    _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
+      const double2 v = CFP(p, s, 0);
+      cfc[2 * p] = v.x; cfc[2 * p + 1] = v.y;
+    }
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+      const double2 v = CFP(p, s, -1);
+      cfs[2 * p] = v.x; cfs[2 * p + 1] = v.y;
+    }
     const double dzt2r_s = t_dzt2r.at(s - 1), ddztr = t_dztr.at(s - 1);
     const double mk = (s <= kz) ? 1.0 : 0.0;
     // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
@@ -326,7 +337,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     mc1 = mc2; ms1 = ms2; mn1 = mn2; tc0 = tc1; tc1 = tc2;
   }
 #undef LD
-#undef CF
+#undef CFP
 #undef AT
 #undef ATB
 }

@@ -449,8 +449,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
     h->exact_convect = false;
     if (const char *e = getenv("UVIC_CONVECT_ONEPASS")) h->exact_convect = atoi(e) != 0;
   }
-  HIPCHK(hipMalloc((void **)&h->coef, N3 * 8 * CF_COUNT));
-  HIPCHK(hipMemset(h->coef, 0, N3 * 8 * CF_COUNT));
+  HIPCHK(hipMalloc((void **)&h->coef, N3 * 16 * CF_PAIRS));
+  HIPCHK(hipMemset(h->coef, 0, N3 * 16 * CF_PAIRS));
   h->exact = false;
   if (const char *e = getenv("UVIC_EXACT")) h->exact = atoi(e) != 0;
   // tmask lives in its own buffer (derived data)
