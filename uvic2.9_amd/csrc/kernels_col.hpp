@@ -193,7 +193,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const size_t nloc = (size_t)(n1 - 1 - c.n0);
   const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
-  double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
+  double *Rpm = c.Rpm + nloc * N3 * 2;   // (R+, R-) of the y limiter, one 16-byte element per cell
   double *Sn = S + nloc * N3;
   // per-level metrics, one entry per lane, broadcast by v_readlane (no memory latency in the march)
   LaneTable t_dzt2r, t_dtxcel, t_dztr;
@@ -284,10 +284,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
       fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up, mk, rzp, rzm);
     }
-    if (owned) {
-      AT(RpY, s, 0) = ryp;
-      AT(RmY, s, 0) = rym;
-    }
+    if (owned) *(double2 *)((char *)(Rpm + (rbase + (size_t)(s - 1) * imt) * 2) + lb2) = make_double2(ryp, rym);
     // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
     const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
     const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
@@ -359,7 +356,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
   double *tp = c.t_taup1 + (size_t)(n1 - 1) * N3;
-  const double *RpY = c.RpY + nloc * N3, *RmY = c.RmY + nloc * N3;
+  const double *Rpm = c.Rpm + nloc * N3 * 2;
   const double *Sn = S + nloc * N3;
   // the source term is read here, not in pass A: with MOBI computed one step ahead on the side
   // stream only this pass has to wait for it
@@ -372,6 +369,8 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const unsigned lb = (unsigned)(i - 1) * 8u;
 #define ATB(p) (*(decltype(p))((const char *)(p) + lb))
 #define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
+  const unsigned lb2 = (unsigned)(i - 1) * 16u;
+#define RPM(k, dj) (*(const double2 *)((const char *)(Rpm + (rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride) * 2) + lb2))
   const double topbc = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt], botbc = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt];
   const double aidif = c.aidif, eps = 1.e-30;
   const int kb = imax(2, kz);
@@ -391,8 +390,10 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
     L.m_c = AT(tm, k, 0); L.m_s = AT(tm, k, -1); L.m_n = AT(tm, k, 1);
     L.t_c = AT(tt, k, 0); L.t_s = AT(tt, k, -1); L.t_n = AT(tt, k, 1);
     L.vn = AT(c.tot_n, k, 0); L.vs = AT(c.tot_n, k, -1);
-    L.rp0 = AT(RpY, k, 0); L.rm0 = AT(RmY, k, 0); L.rps = AT(RpY, k, -1); L.rms = AT(RmY, k, -1);
-    L.rpn = AT(RpY, k, 1); L.rmn = AT(RmY, k, 1);
+    {
+      const double2 r0 = RPM(k, 0), rs = RPM(k, -1), rn = RPM(k, 1);
+      L.rp0 = r0.x; L.rm0 = r0.y; L.rps = rs.x; L.rms = rs.y; L.rpn = rn.x; L.rmn = rn.y;
+    }
     L.sn = AT(Sn, k, 0);
     L.src = AT(srcp, k, 0);
     L.dcb = AT(c.diff_cbt, k, 0);
@@ -472,6 +473,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
 }
 #undef AT
 #undef ATB
+#undef RPM
 #endif  // __HIPCC__
 
 }  // namespace uvic

@@ -317,7 +317,8 @@ struct uvic_gpu {
   int *cv_int[3];   // convection segments: nseg, kt, kb
   double *cv_z;
   bool exact_convect;  // single-kernel convct2 (debug: UVIC_CONVECT_ONEPASS=1)
-  double *coef;     // folded isopycnal coefficients, CF_COUNT planes (kernels_col.hpp)
+  double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
+  double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
   uvic_ctx ctx;
   mobi_dev mobi;
@@ -398,6 +399,7 @@ static void bind_ctx(uvic_gpu *h) {
   if (h->mixing) c.t_taum1 = c.t_tau;  // forward step: both slots hold tau (updates/09/source/mom/loadmw.F:107-111)
   c.tot_e = h->work[0]; c.tot_n = h->work[1]; c.tot_b = h->work[2];
   c.adv_x = h->work[3]; c.adv_z = h->work[4]; c.RpY = h->work[5]; c.RmY = h->work[6];
+  c.Rpm = h->rpm;
 }
 
 // the t(:,:,:,:,-1:1) slots rotate by pointer; tmask is derived from kmt on upload
@@ -449,6 +451,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
     h->exact_convect = false;
     if (const char *e = getenv("UVIC_CONVECT_ONEPASS")) h->exact_convect = atoi(e) != 0;
   }
+  HIPCHK(hipMalloc((void **)&h->rpm, N3 * 16 * (size_t)dims->nt));
+  HIPCHK(hipMemset(h->rpm, 0, N3 * 16 * (size_t)dims->nt));
   HIPCHK(hipMalloc((void **)&h->coef, N3 * 16 * CF_PAIRS));
   HIPCHK(hipMemset(h->coef, 0, N3 * 16 * CF_PAIRS));
   h->exact = false;
@@ -504,6 +508,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
   (void)hipFree(h->coef);
+  (void)hipFree(h->rpm);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
