@@ -12,7 +12,7 @@
 //   longitude wraps cyclically.
 //
 // The isopycnal flux terms are linear in the tracer with coefficients that do not
-// depend on the tracer: `coef_cell` folds Ai * slope (and metric factors, masks,
+// depend on the tracer: `ai_coef_cell` folds Ai * slope (and metric factors, masks,
 // background diffusivities) into 19 per-face coefficients ONCE per step, so the
 // 24 fp64 divisions per cell update of the reference formulation disappear from
 // the per-tracer work.  This re-associates floating-point products:
@@ -45,48 +45,120 @@ enum {
 #define CF_IDX(slot, q, N3) ((((size_t)((slot) / 2) * (N3)) + (q)) * 2 + ((slot) % 2))
 
 // ---------------------------------------------------------------------------
-// per-step coefficient folding; one thread per cell, i = 2..imt-1
+// ai_east / ai_north / ai_bottom (isopyc.F:559-921) and the coefficient folding in one pass over the
+// cell: every slope drod?/(drodz+eps) is formed once and serves the taper of Ai, K11/K22/K33 and the
+// folded coefficient Ai*slope (the separate passes divide twice by the same denominator and move the
+// 16 Ai planes through memory).  Column-kernel path only; Ai_* are not stored.  i = 2..imt-1,
+// k = 1..km, j = 1..jmt-1.
 // ---------------------------------------------------------------------------
-UVIC_DEV void coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
+UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
   UV_DIMS(c);
   const size_t q = X3(i, k, j);
+  const double sc = 1.0 / (c.slmxr * c.dtxsqr[k - 1]);
   const double dzt4r = 0.5 * c.dzt2r[k - 1];
-  if (j >= 2 && j <= jmt - 1) {  // east face: tracer.F:930-942, isopyc.F:953-1002, fdift.h:61-62
-    const double m = TMASK(i, k, j) * TMASK(i + 1, k, j);
-    const double cstdxur = c.cstr[j - 1] * c.dxur[i - 1];
-    cf[CF_IDX(CF_AE, q, N3)] = (c.diff_cet * cstdxur + c.K11[q] * cstdxur) * m;
+#define IDX(ii) X3(ii, k, j)
+  if (j >= 2) {  // east face
+    const double mm = TMASK(i, k, j) * TMASK(i + 1, k, j);
+    const double Ai0 = .5 * (c.fisop[XFIS(i, j, k)] + c.fisop[XFIS(i + 1, j, k)]) * c.ahisop + c.addisop[q];
+    double sumz = 0.0;
     for (int kr = 0; kr <= 1; ++kr)
-      for (int ip = 0; ip <= 1; ++ip)
-        cf[CF_IDX(CF_CE + ip + 2 * kr, q, N3)] =
-            -dzt4r * (c.Ai_ez[q + (size_t)(ip + 2 * kr) * N3] * drodxe(i, k, j, ip) / (drodze(i, k, j, ip, kr) + UV_EPSLN));
+      for (int ip = 0; ip <= 1; ++ip) {
+        const double sl = drodxe(i, k, j, ip) / (drodze(i, k, j, ip, kr) + UV_EPSLN);
+        const double sxe = dabs(sl);
+        double a;
+        if (sxe > sc) {
+          const double r = sc / (sxe + UV_EPSLN);
+          a = Ai0 * TMASK(i, k, j) * TMASK(i + 1, k, j) * (r * r);
+        } else {
+          a = Ai0 * TMASK(i, k, j) * TMASK(i + 1, k, j);
+        }
+        sumz = sumz + c.dzw[k - 1 + kr] * a;
+        if (j <= jmt - 1) cf[CF_IDX(CF_CE + ip + 2 * kr, q, N3)] = -dzt4r * (a * sl);
+      }
+    const double k11 = dzt4r * sumz;
+    UV_CYC_STORE(c.K11, IDX, i, k11);
+    if (j <= jmt - 1) {
+      const double cstdxur = c.cstr[j - 1] * c.dxur[i - 1];
+      cf[CF_IDX(CF_AE, q, N3)] = (c.diff_cet * cstdxur + k11 * cstdxur) * mm;
+    }
   }
-  if (j <= jmt - 1) {  // north face: tracer.F:948-961, isopyc.F:1008-1053, fdift.h:77-78
-    const double m = TMASK(i, k, j) * TMASK(i, k, j + 1);
-    cf[CF_IDX(CF_AN, q, N3)] = (c.diff_cnt * c.csu_dyur[j - 1] + c.K22[q] * c.csu_dyur[j - 1]) * m;
+  {  // north face
+    const double mm = TMASK(i, k, j) * TMASK(i, k, j + 1);
+    const double Ai0 = 0.5 * (c.fisop[XFIS(i, j, k)] + c.fisop[XFIS(i, j + 1, k)]) * c.ahisop;
     const double csu_dzt4r = c.csu[j - 1] * dzt4r;
+    double sumz = 0.0;
     for (int kr = 0; kr <= 1; ++kr)
-      for (int jq = 0; jq <= 1; ++jq)
-        cf[CF_IDX(CF_CN + jq + 2 * kr, q, N3)] =
-            -csu_dzt4r * (c.Ai_nz[q + (size_t)(jq + 2 * kr) * N3] * drodyn(i, k, j, jq) / (drodzn(i, k, j, jq, kr) + UV_EPSLN));
+      for (int jq = 0; jq <= 1; ++jq) {
+        const double sl = drodyn(i, k, j, jq) / (drodzn(i, k, j, jq, kr) + UV_EPSLN);
+        const double syn = dabs(sl);
+        double a;
+        if (syn > sc) {
+          const double r = sc / (syn + UV_EPSLN);
+          a = Ai0 * TMASK(i, k, j) * TMASK(i, k, j + 1) * (r * r);
+        } else {
+          a = Ai0 * TMASK(i, k, j) * TMASK(i, k, j + 1);
+        }
+        sumz = sumz + c.dzw[k - 1 + kr] * a;
+        cf[CF_IDX(CF_CN + jq + 2 * kr, q, N3)] = -csu_dzt4r * (a * sl);
+      }
+    const double k22 = dzt4r * sumz;
+    UV_CYC_STORE(c.K22, IDX, i, k22);
+    cf[CF_IDX(CF_AN, q, N3)] = (c.diff_cnt * c.csu_dyur[j - 1] + k22 * c.csu_dyur[j - 1]) * mm;
   }
-  if (j >= 2 && j <= jmt - 1) {  // bottom face: tracer.F:1025-1032, isopyc.F:1062-1107, fdift.h:83-88
+  if (j >= 2) {  // bottom face
     if (k <= km - 1) {
-      cf[CF_IDX(CF_BV, q, N3)] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
+      const double Ai0 = 0.5 * (c.fisop[XFIS(i, j, k + 1)] + c.fisop[XFIS(i, j, k)]) * c.ahisop;
+      double sumx = 0.0;
       for (int ip = 0; ip <= 1; ++ip)
-        for (int kr = 0; kr <= 1; ++kr)
-          cf[CF_IDX(CF_CBX + ip + 2 * kr, q, N3)] =
-              -c.dxt4r[i - 1] * (c.Ai_bx[q + (size_t)(ip + 2 * kr) * N3] * c.cstr[j - 1] * drodxb(i, k, j, ip, kr) /
-                                 (drodzb(i, k, j, kr) + UV_EPSLN));
-      for (int jq = 0; jq <= 1; ++jq)
-        for (int kr = 0; kr <= 1; ++kr)
-          cf[CF_IDX(CF_CBY + jq + 2 * kr, q, N3)] =
-              -c.dyt4r[j - 1] * c.cstr[j - 1] *
-              (c.Ai_by[q + (size_t)(jq + 2 * kr) * N3] * c.csu[j - 1 + jq - 1] * drodyb(i, k, j, jq, kr) /
-               (drodzb(i, k, j, kr) + UV_EPSLN));
-    } else {
+        for (int kr = 0; kr <= 1; ++kr) {
+          const double sl = drodxb(i, k, j, ip, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
+          const double sxb = dabs(sl);
+          double a;
+          if (sxb > sc) {
+            const double r = sc / (sxb + UV_EPSLN);
+            a = Ai0 * TMASK(i, k + 1, j) * (r * r);
+          } else {
+            a = Ai0 * TMASK(i, k + 1, j);
+          }
+          sumx = sumx + c.dxu[i - 1 + ip - 1] * a * (sxb * sxb);
+          if (j <= jmt - 1) cf[CF_IDX(CF_CBX + ip + 2 * kr, q, N3)] = -c.dxt4r[i - 1] * (a * c.cstr[j - 1] * sl);
+        }
+      double sumy = 0.0;
+      for (int jq = 0; jq <= 1; ++jq) {
+        const double facty = c.csu[j - 1 + jq - 1] * c.dyu[j - 1 + jq - 1];
+        for (int kr = 0; kr <= 1; ++kr) {
+          const double sl = drodyb(i, k, j, jq, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
+          const double syb = dabs(sl);
+          double a;
+          if (syb > sc) {
+            const double r = sc / (syb + UV_EPSLN);
+            a = Ai0 * TMASK(i, k + 1, j) * (r * r);
+          } else {
+            a = Ai0 * TMASK(i, k + 1, j);
+          }
+          sumy = sumy + facty * a * (syb * syb);
+          if (j <= jmt - 1) cf[CF_IDX(CF_CBY + jq + 2 * kr, q, N3)] = -c.dyt4r[j - 1] * c.cstr[j - 1] * (a * c.csu[j - 1 + jq - 1] * sl);
+        }
+      }
+      const double k33 = c.dxt4r[i - 1] * sumx + c.dyt4r[j - 1] * c.cstr[j - 1] * sumy;
+      UV_CYC_STORE(c.K33, IDX, i, k33);
+      if (j <= jmt - 1) {
+        // diff_cbt = background + K33 is what isopyc_column stores for this cell; a given diff_cbt (host or device
+        // vmixc) is read instead -- when vmixc runs on the device after isopyc, coef_bv_cell renews this slot
+        const double dcb = c.diff_cbt_given ? c.diff_cbt[q] : c.diff_cbt_bg[q] + k33;
+        cf[CF_IDX(CF_BV, q, N3)] = dcb * c.dzwr[k] * (1.0 - c.aidif);
+      }
+    } else if (j <= jmt - 1) {
       for (int p = CF_BV; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
     }
   }
+#undef IDX
+}
+// the vertical-diffusion coefficient alone (after a device vmixc has rewritten diff_cbt)
+UVIC_DEV void coef_bv_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
+  UV_DIMS(c);
+  const size_t q = X3(i, k, j);
+  if (j >= 2 && j <= jmt - 1 && k <= km - 1) cf[CF_IDX(CF_BV, q, N3)] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
 }
 
 #if defined(__HIPCC__)
@@ -289,7 +361,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
     const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
     const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
-    // ---- diffusive fluxes (coefficients folded by coef_cell) ---------------------------
+    // ---- diffusive fluxes (coefficients folded by ai_coef_cell) ------------------------
     const double dz_up = dz_c, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column (dz_up = dz_dn of the level above, 0 at the top)
     const double dze_up = dz_e, dze_dn = shfl_e(dz_dn);                   // east column
     const double dzs_up = dz_s, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row

@@ -115,10 +115,15 @@ __global__ void __launch_bounds__(256) k_vmixc(const uvic_ctx c) {
   if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
   vmixc_cell(c, i, k, j);
 }
-__global__ void __launch_bounds__(256) k_coef(const uvic_ctx c, double *cf) {
+__global__ void __launch_bounds__(256) k_ai_coef(const uvic_ctx c, double *cf) {
   CELL_DECODE(c);
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
-  coef_cell(c, cf, i, k, j);
+  ai_coef_cell(c, cf, i, k, j);
+}
+__global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
+  CELL_DECODE(c);
+  if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
+  coef_bv_cell(c, cf, i, k, j);
 }
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
   const int nblk = (g.total + 3) / 4;
@@ -658,16 +663,15 @@ static int launch_isopyc(uvic_gpu *h) {
   mark(h, "begin");
   hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
   mark(h, "isopyc_elements");
-  hipLaunchKernelGGL(k_isopyc_ai, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
+  if (h->exact)
+    hipLaunchKernelGGL(k_isopyc_ai, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
+  else   // column-kernel path: mixing tensor and folded coefficients in one pass (Ai_* stay in registers)
+    hipLaunchKernelGGL(k_ai_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c, h->coef);
   mark(h, "isopyc_ai");
   hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
   mark(h, "isopyc_adv");
   hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, c);
   mark(h, "isopyc_column");
-  if (!h->exact) {
-    hipLaunchKernelGGL(k_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c, h->coef);
-    mark(h, "coef");
-  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -794,6 +798,10 @@ static int launch_vmixc(uvic_gpu *h) {
   mark(h, "begin");
   hipLaunchKernelGGL(k_vmixc, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
   mark(h, "vmixc");
+  if (!h->exact) {   // the folded vertical-diffusion coefficient follows the new diff_cbt
+    hipLaunchKernelGGL(k_coef_bv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
+    mark(h, "coef_bv");
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
