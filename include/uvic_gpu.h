@@ -208,6 +208,9 @@ int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
 /* forward ("mixing") time step: t(tau-1) := t(tau) (u09/mom/loadmw.F:107-111, 569-584) by
  * aliasing the device buffers instead of copying; switch off again before the next step */
 int uvic_gpu_set_mixing(uvic_gpu *h, int on);
+/* the T,S-derived fields (isopyc products, folded coefficients) of the NEXT step on a second side stream; same calling
+ * rule as uvic_gpu_prefetch_sources: after uvic_gpu_step_async, before uvic_gpu_rotate, next step leapfrog */
+int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);
 

@@ -338,6 +338,12 @@ struct uvic_gpu {
   bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
   // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
   hipStream_t side;
+  // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
+  hipStream_t side2;
+  hipEvent_t ev_iso_next;
+  void *iso_alt[UVIC_F_COUNT];
+  double *work_alt[3], *coef_alt;
+  bool iso_prefetch_pending, iso_from_prefetch;
   hipEvent_t ev_step_begin, ev_src_next;
   void *src_alt;
   bool prefetch_pending, src_from_prefetch, mixing;
@@ -345,8 +351,8 @@ struct uvic_gpu {
   size_t fct_lds, upd_lds;
   // profiling
   bool profiling;
-  std::vector<hipEvent_t> ev[2];            // [0] main stream, [1] side stream
-  std::vector<const char *> ev_names[2];
+  std::vector<hipEvent_t> ev[3];            // [0] main stream, [1] MOBI side stream, [2] isopyc side stream
+  std::vector<const char *> ev_names[3];
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -427,6 +433,11 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   memset(&h->mobi, 0, sizeof h->mobi);
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next, hipEventDisableTiming));
+  for (int f = 0; f < UVIC_F_COUNT; ++f) h->iso_alt[f] = nullptr;
+  h->work_alt[0] = h->work_alt[1] = h->work_alt[2] = nullptr; h->coef_alt = nullptr;
+  h->iso_prefetch_pending = h->iso_from_prefetch = false;
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_src_next, hipEventDisableTiming));
   h->src_alt = nullptr;
@@ -529,6 +540,11 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipEventDestroy(h->ev_step_begin);
   (void)hipEventDestroy(h->ev_src_next);
   (void)hipStreamDestroy(h->side);
+  (void)hipStreamDestroy(h->side2);
+  (void)hipEventDestroy(h->ev_iso_next);
+  for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->iso_alt[f]);
+  for (int q = 0; q < 3; ++q) (void)hipFree(h->work_alt[q]);
+  (void)hipFree(h->coef_alt);
   (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -568,6 +584,13 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
   if (offset < 0 || count < 0 || offset + count > n) return fail_msg(std::string("uvic_gpu_upload: range outside field ") + FIELDS[field].name);
   HIPCHK(hipSetDevice(h->device));
   const size_t es = elem_size(field);
+  if (field == UVIC_F_T_TAUM1 || field == UVIC_F_T_TAU || field == UVIC_F_T_TAUP1) {
+    // new state from the host: whatever the side streams computed ahead from the old one is void
+    HIPCHK(hipStreamSynchronize(h->side));
+    HIPCHK(hipStreamSynchronize(h->side2));
+    h->prefetch_pending = h->src_from_prefetch = false;
+    h->iso_prefetch_pending = h->iso_from_prefetch = false;
+  }
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (field == UVIC_F_KMT) return make_tmask(h);
@@ -637,14 +660,14 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
 // -- launch helpers ------------------------------------------------------------
 static void mark_on(uvic_gpu *h, const char *name, int sid) {
   if (!h->profiling) return;
-  const size_t used = h->ev[0].size() + h->ev[1].size();
+  const size_t used = h->ev[0].size() + h->ev[1].size() + h->ev[2].size();
   if (used >= h->ev_pool.size()) {
     hipEvent_t e;
     (void)hipEventCreate(&e);
     h->ev_pool.push_back(e);
   }
   hipEvent_t e = h->ev_pool[used];
-  (void)hipEventRecord(e, sid ? h->side : h->stream);
+  (void)hipEventRecord(e, sid == 0 ? h->stream : (sid == 1 ? h->side : h->side2));
   h->ev[sid].push_back(e);
   h->ev_names[sid].push_back(name);
 }
@@ -658,22 +681,31 @@ static unsigned col_blocks(const uvic_gpu *h, int bs) {
   return (unsigned)((n + bs - 1) / bs);
 }
 
-static int launch_isopyc(uvic_gpu *h) {
-  const uvic_ctx &c = h->ctx;
-  mark(h, "begin");
-  hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
-  mark(h, "isopyc_elements");
+// the T,S-derived fields of a step (mixing tensor, GM velocities, folded coefficients): ctx `c` says what is read
+// (t_taum1) and where the products go; `sid` 0 = main stream, 2 = the isopyc side stream
+static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStream_t st, int sid) {
+  mark_on(h, "begin", sid);
+  hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
+  mark_on(h, "isopyc_elements", sid);
   if (h->exact)
-    hipLaunchKernelGGL(k_isopyc_ai, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
+    hipLaunchKernelGGL(k_isopyc_ai, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
   else   // column-kernel path: mixing tensor and folded coefficients in one pass (Ai_* stay in registers)
-    hipLaunchKernelGGL(k_ai_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c, h->coef);
-  mark(h, "isopyc_ai");
-  hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, c);
-  mark(h, "isopyc_adv");
-  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, c);
-  mark(h, "isopyc_column");
+    hipLaunchKernelGGL(k_ai_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef);
+  mark_on(h, "isopyc_ai", sid);
+  hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
+  mark_on(h, "isopyc_adv", sid);
+  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, st, c);
+  mark_on(h, "isopyc_column", sid);
   HIPCHK(hipGetLastError());
   return 0;
+}
+static int launch_isopyc(uvic_gpu *h) {
+  if (h->iso_from_prefetch) {   // computed one step ahead on its side stream (uvic_gpu_prefetch_isopyc)
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_iso_next, 0));
+    h->iso_from_prefetch = false;
+    return 0;
+  }
+  return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
 }
 static int launch_transport(uvic_gpu *h) {
   const uvic_ctx &c = h->ctx;
@@ -937,6 +969,50 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   h->prefetch_pending = true;
   return 0;
 }
+// The T,S-derived fields of the NEXT step (isopyc reads T,S at tau-1 of that step = tau of this one) on a second
+// side stream, overlapped with this step.  Same calling rule as uvic_gpu_prefetch_sources.
+static const int ISO_FIELDS[] = {UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT, UVIC_F_AI_EZ, UVIC_F_AI_NZ,
+                                 UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33, UVIC_F_ADV_VETISO,
+                                 UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO, UVIC_F_DIFF_CBT};
+static void swap_iso_buffers(uvic_gpu *h) {
+  for (int f : ISO_FIELDS) std::swap(h->buf[f], h->iso_alt[f]);
+  for (int q = 0; q < 3; ++q) std::swap(h->work[q], h->work_alt[q]);
+  std::swap(h->coef, h->coef_alt);
+}
+extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  if (h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_prefetch_isopyc: not with an uploaded diff_cbt (diff_cbt_has_k33 = 1)");
+  HIPCHK(hipSetDevice(h->device));
+  const uvic_dims &d = h->d;
+  if (!h->coef_alt) {   // the alternate set, zero-filled like the primary one
+    for (int f : ISO_FIELDS) {
+      const size_t bytes = (size_t)field_elems(d, f) * 8;
+      HIPCHK(hipMalloc(&h->iso_alt[f], bytes));
+      HIPCHK(hipMemsetAsync(h->iso_alt[f], 0, bytes, h->side2));
+    }
+    const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt;
+    const size_t wsz[3] = {N3, N3, NF};
+    for (int q = 0; q < 3; ++q) {
+      HIPCHK(hipMalloc((void **)&h->work_alt[q], wsz[q] * 8));
+      HIPCHK(hipMemsetAsync(h->work_alt[q], 0, wsz[q] * 8, h->side2));
+    }
+    HIPCHK(hipMalloc((void **)&h->coef_alt, N3 * 16 * CF_PAIRS));
+    HIPCHK(hipMemsetAsync(h->coef_alt, 0, N3 * 16 * CF_PAIRS, h->side2));
+  }
+  // a context that reads this step's t(tau) as t(tau-1) and writes the alternate set
+  swap_iso_buffers(h);
+  bind_ctx(h);
+  uvic_ctx c = h->ctx;
+  double *coef = h->coef;
+  swap_iso_buffers(h);
+  bind_ctx(h);
+  c.t_taum1 = h->ctx.t_tau;
+  HIPCHK(hipStreamWaitEvent(h->side2, h->ev_step_begin, 0));
+  if (int rc = launch_isopyc_on(h, c, coef, h->side2, 2)) return rc;
+  HIPCHK(hipEventRecord(h->ev_iso_next, h->side2));
+  h->iso_prefetch_pending = true;
+  return 0;
+}
 // forward (mixing) step: t(tau-1) aliases t(tau) until switched off again
 extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on) {
   if (!h) return fail_msg("null handle");
@@ -970,25 +1046,32 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->prefetch_pending = false;
     h->src_from_prefetch = true;
   }
+  if (h->iso_prefetch_pending) {   // likewise the T,S-derived fields
+    swap_iso_buffers(h);
+    h->iso_prefetch_pending = false;
+    h->iso_from_prefetch = true;
+  }
   bind_ctx(h);
   return 0;
 }
 extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
 static void profile_reset(uvic_gpu *h) {
-  for (int q = 0; q < 2; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
+  for (int q = 0; q < 3; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
 }
 // mean duration per kernel name from the recorded events (consecutive events of one stream)
 static int profile_collect(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
   HIPCHK(hipStreamSynchronize(h->side));
+  HIPCHK(hipStreamSynchronize(h->side2));
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<KernelStat> st;
-  for (int q = 0; q < 2; ++q)
+  for (int q = 0; q < 3; ++q)
     for (size_t e = 1; e < h->ev[q].size(); ++e) {
       if (strcmp(h->ev_names[q][e], "begin") == 0) continue;
       float ms = 0.f;

@@ -192,6 +192,10 @@ class TracerModel:
                                f"(joff=0, js={js_expected[0]}, je={js_expected[1]}, is=2, ie=imt-1)")
         return True
 
+    def prefetch_isopyc(self):
+        """The T,S-derived fields of the next (leapfrog) step on a side stream, beside this step."""
+        check(self.lib.uvic_gpu_prefetch_isopyc(self.h), "prefetch_isopyc")
+
     def isopyc(self, joff=0, js=1, je=None, is_=2, ie=None):
         je = self.jmt if je is None else je
         ie = self.imt - 1 if ie is None else ie
@@ -274,8 +278,11 @@ class TimeLoop:
             self.shard.step(m)
         else:
             m.step_async()
-        if self.prefetch and m.has_mobi and not self._mixing(self.itt + 1):
-            m.prefetch_sources(2.0 * self.dtts)
+        if self.prefetch and not self._mixing(self.itt + 1):
+            if m.has_mobi:
+                m.prefetch_sources(2.0 * self.dtts)
+            if not m.params.diff_cbt_has_k33:
+                m.prefetch_isopyc()
         m.rotate()
         if mixing:
             m.set_mixing(False)
