@@ -7,10 +7,10 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "?")))
 rows.sort()
-# last three steps: find the last 4 k_isopyc_elements
+# four steps from the middle of the first (uninstrumented) timed loop of bench.py
 idx = [n for n, r in enumerate(rows) if "isopyc_elements" in r[2]]
-first = idx[-21] if len(idx) >= 21 else idx[0]
-last = idx[-17] if len(idx) >= 21 else len(rows)
+first = idx[12] if len(idx) >= 17 else idx[0]
+last = idx[16] if len(idx) >= 17 else len(rows)
 t0 = rows[first][0]
 for s, e, name, q in rows[first:last]:
     print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f} us  q{q}  {name}")
