@@ -157,3 +157,20 @@ def test_error_behaviour():
     with pytest.raises(UvicGpuError):
         m.transport()               # c2dtts not set
     m.close()
+
+
+def test_twenty_steps_time_loop_with_lookahead_match_golden_run_p2():
+    """The same 20 steps through TimeLoop, where the isopyc products of step n+1 are computed one step ahead on a
+    side stream into an alternate buffer set (uvic_gpu_prefetch_isopyc): bit-identical with the exact kernels."""
+    from uvic29_amd.tracer import TimeLoop
+    oc = synthetic.make_ocean("p2", 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    g = np.load(GOLD / "run_p2_14x14x6_n20.npz")
+    m = _model(oc, to, so, c)
+    loop = TimeLoop(m, oc.params.dtts, oc.params.nmix)
+    for _ in range(20):
+        loop.step()
+    m.sync()
+    got = m.download("t_tau")
+    assert np.array_equal(got[:, :, 1:13], g["t"][:, :, 1:13])
+    m.close()
