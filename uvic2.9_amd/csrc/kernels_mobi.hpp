@@ -833,10 +833,10 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     mobi_src(T, P, S, bioin, PRE(MP_BCT), impo, impo_phos, P->wd[k - 1], PRE(MP_NUD), P->nudop0, P->nudon0, snpzd, PRE(MP_BCTZ),
              rn15impo, rc13impo, PRE(MP_AC13B), impofe, PRE(MP_O2F), PRE(MP_AOUT), PRE(MP_AVEJ), PRE(MP_AVEJD), &so);
     expo = so.expo; expo_phos = so.expo_phos; rn15expo = so.rn15expo; rc13expo = so.rc13expo; expofe = so.expofe;
-    // tendency = (new pool - clamped input) / twodt; the input is read again rather than kept in
-    // registers through the sub-steps
+    // tendency = (new pool - clamped input) / twodt; mobi_src left the clamped inputs in bioin, and a wave keeps
+    // only those of the pools it owns
     _Pragma("unroll") for (int m = 0; m < MI::count; ++m)
-      if (MINE(MOBI_OWNER[m])) snpzd[m] = (snpzd[m] - TNC(k, m + 1)) * S.rdtts;
+      if (MINE(MOBI_OWNER[m])) snpzd[m] = (snpzd[m] - bioin[m]) * S.rdtts;
     expofe = expofe * S.rnbio;
     expo = expo * S.rnbio;
     expo_phos = expo_phos * S.rnbio;
@@ -852,7 +852,7 @@ UVIC_DEV void mobi_column_body(Team &T, const uvic_ctx &c, const mobi_dev &M, in
     // calcite production of the column, mobi.F:1228-1266 (bioin is clamped now)
     const double dprca = rcalpro_k * 1e-3;
     const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
-    double rtdic13 = dmax(TNC(k, MI::dic13), r13min) / dmax(dic_in, UV_TRCMIN);
+    double rtdic13 = dmax(bioin[MI::dic13 - 1], r13min) / dmax(dic_in, UV_TRCMIN);
     rtdic13 = dmin(rtdic13, 2. * UV_RC13STD / (1 + UV_RC13STD));
     rtdic13 = dmax(rtdic13, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
     if (k <= kmx) {   // levels below the sea floor are walked only for the team's barriers
