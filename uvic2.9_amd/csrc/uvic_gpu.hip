@@ -340,6 +340,12 @@ struct uvic_gpu {
   hipStream_t side;
   // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
   hipStream_t side2;
+  // T and S finish pass B and the convective T,S walk on a third side stream while pass B of the other tracers runs
+  hipStream_t side3;
+  hipEvent_t ev_fct_done, ev_ts_done;
+  bool ts_ahead;      // this step's convect_ts was already issued on side3
+  bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
+  bool ts_no_src;     // itrc(1) = itrc(2) = 0: T and S have no source term (known from the upload of itrc)
   hipEvent_t ev_iso_next;
   void *iso_alt[UVIC_F_COUNT];
   double *work_alt[3], *coef_alt;
@@ -351,8 +357,8 @@ struct uvic_gpu {
   size_t fct_lds, upd_lds;
   // profiling
   bool profiling;
-  std::vector<hipEvent_t> ev[3];            // [0] main stream, [1] MOBI side stream, [2] isopyc side stream
-  std::vector<const char *> ev_names[3];
+  std::vector<hipEvent_t> ev[4];            // [0] main stream, [1] MOBI, [2] isopyc, [3] T,S side streams
+  std::vector<const char *> ev_names[4];
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -434,6 +440,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
+  h->ts_ahead = false; h->serial = false; h->ts_no_src = false;
   HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next, hipEventDisableTiming));
   for (int f = 0; f < UVIC_F_COUNT; ++f) h->iso_alt[f] = nullptr;
   h->work_alt[0] = h->work_alt[1] = h->work_alt[2] = nullptr; h->coef_alt = nullptr;
@@ -541,6 +551,9 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipEventDestroy(h->ev_src_next);
   (void)hipStreamDestroy(h->side);
   (void)hipStreamDestroy(h->side2);
+  (void)hipStreamDestroy(h->side3);
+  (void)hipEventDestroy(h->ev_fct_done);
+  (void)hipEventDestroy(h->ev_ts_done);
   (void)hipEventDestroy(h->ev_iso_next);
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->iso_alt[f]);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->work_alt[q]);
@@ -593,6 +606,10 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
   }
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (field == UVIC_F_ITRC && offset == 0 && count >= 2) {
+    const int32_t *it = (const int32_t *)host;
+    h->ts_no_src = it[0] == 0 && it[1] == 0;
+  }
   if (field == UVIC_F_KMT) return make_tmask(h);
   return 0;
 }
@@ -660,14 +677,14 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
 // -- launch helpers ------------------------------------------------------------
 static void mark_on(uvic_gpu *h, const char *name, int sid) {
   if (!h->profiling) return;
-  const size_t used = h->ev[0].size() + h->ev[1].size() + h->ev[2].size();
+  const size_t used = h->ev[0].size() + h->ev[1].size() + h->ev[2].size() + h->ev[3].size();
   if (used >= h->ev_pool.size()) {
     hipEvent_t e;
     (void)hipEventCreate(&e);
     h->ev_pool.push_back(e);
   }
   hipEvent_t e = h->ev_pool[used];
-  (void)hipEventRecord(e, sid == 0 ? h->stream : (sid == 1 ? h->side : h->side2));
+  (void)hipEventRecord(e, sid == 0 ? h->stream : (sid == 1 ? h->side : (sid == 2 ? h->side2 : h->side3)));
   h->ev[sid].push_back(e);
   h->ev_names[sid].push_back(name);
 }
@@ -726,12 +743,43 @@ static int launch_transport(uvic_gpu *h) {
     const unsigned nb = (unsigned)((((b.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
     hipLaunchKernelGGL(k_colfct, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
     mark(h, "colfct");
+    const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
+    // T and S (no source terms, and all the convective T,S walk needs) take their pass B and that walk on a side
+    // stream beside pass B of the other tracers; not under tracer sharding, where convection follows the exchange
+    const bool split = !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
+                       h->ts_no_src;
+    if (split) {
+      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
+      HIPCHK(hipStreamWaitEvent(h->side3, h->ev_fct_done, 0));
+      uvic_ctx cts = c;
+      cts.nt_local = 2;
+      ColGrid bts = b;
+      bts.total = bts.nrows * 2 * bts.nseg;
+      const unsigned nbts = (unsigned)((((bts.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
+      mark_on(h, "begin", 3);
+      hipLaunchKernelGGL(k_colupd, dim3(nbts), dim3(64, COLUPD_WAVES), upd_lds, h->side3, cts, (const double *)S, bts);
+      mark_on(h, "colupd_ts", 3);
+      hipLaunchKernelGGL(k_convect_ts, dim3(col_blocks(h, 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side3, c);
+      mark_on(h, "convect_ts", 3);
+      HIPCHK(hipEventRecord(h->ev_ts_done, h->side3));
+      h->ts_ahead = true;
+    }
     if (h->src_from_prefetch) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
       h->src_from_prefetch = false;
     }
-    hipLaunchKernelGGL(k_colupd, dim3(nb), dim3(64, COLUPD_WAVES), (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8, h->stream, c,
-                       (const double *)S, b);
+    if (split) {   // the other tracers: work arrays are indexed from the group's first tracer
+      const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+      uvic_ctx cr = c;
+      cr.n0 = 2; cr.nt_local = c.nt - 2;
+      cr.Rpm = c.Rpm + 2 * N3 * 2;
+      ColGrid br = b;
+      br.total = br.nrows * cr.nt_local * br.nseg;
+      const unsigned nbr = (unsigned)((((br.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
+      hipLaunchKernelGGL(k_colupd, dim3(nbr), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+    } else {
+      hipLaunchKernelGGL(k_colupd, dim3(nb), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
+    }
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
     return 0;
@@ -762,8 +810,13 @@ static int launch_convect(uvic_gpu *h) {
     hipLaunchKernelGGL(k_convect, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx);
     mark(h, "convect");
   } else {
-    hipLaunchKernelGGL(k_convect_ts, dim3(col_blocks(h, 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx);
-    mark(h, "convect_ts");
+    if (h->ts_ahead) {      // issued on the T,S side stream by launch_transport
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
+      h->ts_ahead = false;
+    } else {
+      hipLaunchKernelGGL(k_convect_ts, dim3(col_blocks(h, 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx);
+      mark(h, "convect_ts");
+    }
     if (h->d.nt > 2) {
       const long long n = (long long)h->d.imt * h->d.jmt * (h->d.nt - 2);
       hipLaunchKernelGGL(k_convect_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx);
@@ -1058,20 +1111,22 @@ extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
+  HIPCHK(hipStreamSynchronize(h->side3));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
 static void profile_reset(uvic_gpu *h) {
-  for (int q = 0; q < 3; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
+  for (int q = 0; q < 4; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
 }
 // mean duration per kernel name from the recorded events (consecutive events of one stream)
 static int profile_collect(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
   HIPCHK(hipStreamSynchronize(h->side));
   HIPCHK(hipStreamSynchronize(h->side2));
+  HIPCHK(hipStreamSynchronize(h->side3));
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<KernelStat> st;
-  for (int q = 0; q < 3; ++q)
+  for (int q = 0; q < 4; ++q)
     for (size_t e = 1; e < h->ev[q].size(); ++e) {
       if (strcmp(h->ev_names[q][e], "begin") == 0) continue;
       float ms = 0.f;
@@ -1099,12 +1154,14 @@ extern "C" int uvic_gpu_profile(uvic_gpu *h, int nrep, int max_kernels, const ch
   HIPCHK(hipSetDevice(h->device));
   profile_reset(h);
   h->profiling = true;
+  h->serial = true;
   int rc = 0;
   for (int r = 0; r < nrep && !rc; ++r) {
     rc = launch_isopyc(h);
     if (!rc) rc = launch_tracer(h);
   }
   h->profiling = false;
+  h->serial = false;
   if (rc) return rc;
   return profile_collect(h, max_kernels, names, mean_ms, nkernels);
 }
