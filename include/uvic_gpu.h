@@ -202,14 +202,15 @@ int uvic_gpu_sync(uvic_gpu *h);
 int uvic_gpu_step_async(uvic_gpu *h);
 /* start computing the MOBI sources of the NEXT step from t(tau) on a side stream,
  * overlapped with this step's transport (the source terms of a leapfrog step depend only
- * on t(tau-1), which is this step's t(tau)); call between uvic_gpu_step_async and
+ * on t(tau-1), which is this step's t(tau)); call before uvic_gpu_step_async of this step (preferred:
+ * the chain is then queued ahead of the step's own side-stream work) or between it and
  * uvic_gpu_rotate, only when the next step is a leapfrog step with `c2dtts_next` */
 int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
 /* forward ("mixing") time step: t(tau-1) := t(tau) (u09/mom/loadmw.F:107-111, 569-584) by
  * aliasing the device buffers instead of copying; switch off again before the next step */
 int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 /* the T,S-derived fields (isopyc products, folded coefficients) of the NEXT step on a second side stream; same calling
- * rule as uvic_gpu_prefetch_sources: after uvic_gpu_step_async, before uvic_gpu_rotate, next step leapfrog */
+ * rule as uvic_gpu_prefetch_sources: before uvic_gpu_rotate of this step, next step leapfrog */
 int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);

@@ -204,6 +204,32 @@ struct LaneTable {
     return __hiloint2double(__builtin_amdgcn_readlane(hi, idx), __builtin_amdgcn_readlane(lo, idx));
   }
 };
+// Buffer addressing (`buffer_load_dwordx2 v, v_off, s[rsrc], s_off offen`): address = descriptor base + a
+// wave-uniform byte offset in ONE scalar register + the lane's 32-bit byte offset, formed by the memory
+// pipeline.  The flat form costs a 64-bit VALU add per load (v_lshl_add_u64: 25 of ~400 VALU instructions
+// per level of pass A) and two scalar adds per pointer.  num_records bounds the lane offset, so a lane
+// that strays reads zero instead of faulting.
+typedef unsigned uv2 __attribute__((ext_vector_type(2)));
+typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+typedef double dv2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t brsrc;
+__device__ __forceinline__ brsrc mkbuf(const void *p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+__device__ __forceinline__ double bld(brsrc r, unsigned voff, int soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ double2 bld2(brsrc r, unsigned voff, int soff) {
+  const dv2 v = __builtin_bit_cast(dv2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void bst(brsrc r, unsigned voff, int soff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uv2, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void bst2(brsrc r, unsigned voff, int soff, double a, double b) {
+  dv2 v; v.x = a; v.y = b;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uv4, v), r, voff, soff, 0);
+}
 // v_max_f64 / v_min_f64: one instruction instead of compare + two selects (operands are never NaN here)
 __device__ __forceinline__ double fmx(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double fmn(double a, double b) { return __builtin_fmin(a, b); }
@@ -211,14 +237,24 @@ __device__ __forceinline__ double upstream(double v, double a, double b) { retur
 __device__ __forceinline__ double limited(double cpos, double cneg, double f) {
   return 0.5 * ((cpos + cneg) * f + (cpos - cneg) * dabs(f));
 }
+// x / y for the limiter ratios.  x is finite, y = P + epsln lies in [1e-20, ~1e6]: the range handling of the IEEE
+// division sequence (two v_div_scale, v_div_fmas, v_div_fixup) is dead weight here.  v_rcp_f64, two Newton steps
+// and one correction of the quotient: 8 instructions instead of 12, result within 1 ulp of x / y.
+__device__ __forceinline__ double div_pos(double x, double y) {
+  double r = __builtin_amdgcn_rcp(y);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  const double q = x * r;
+  return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+}
 // R+ and R- of Zalesak's limiter for one cell (tracer_adv_flx.F:672-690)
 __device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, double scale, double flxlft, double flxrgt,
                                           double mask, double &rp, double &rm) {
   const double trmax = fmx(fmx(fxa, fxb), tlo), trmin = fmn(fmn(fxa, fxb), tlo);
   const double pplus = scale * (fmx(0.0, flxlft) - fmn(0.0, flxrgt));
   const double pminus = scale * (fmx(0.0, flxrgt) - fmn(0.0, flxlft));
-  rp = fmn(1., mask * (trmax - tlo) / (pplus + UV_EPSLN));
-  rm = fmn(1., mask * (tlo - trmin) / (pminus + UV_EPSLN));
+  rp = fmn(1., div_pos(mask * (trmax - tlo), pplus + UV_EPSLN));
+  rm = fmn(1., div_pos(mask * (tlo - trmin), pminus + UV_EPSLN));
 }
 
 __device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
@@ -271,6 +307,9 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   LaneTable t_dzt2r, t_dtxcel, t_dztr;
   t_dzt2r.load(c.dzt2r, km); t_dtxcel.load(c.dtxcel, km); t_dztr.load(c.dztr, km);
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
+  // no ocean among the owned columns: R+- of land is zero and stays zero (the buffer is cleared with kmt), and
+  // pass B does not read S of a segment it skips on the same test
+  if (!c.no_landskip && __builtin_amdgcn_ballot_w64(owned && kz > 0) == 0) return;
   const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
   const double cstr_r = kload(c.cstr, r - 1);
   const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
@@ -278,21 +317,24 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const double c2dtts = c.c2dtts;
   const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
   const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
-  // addresses = wave-uniform pointer (scalar registers, scalar arithmetic) + the lane's 32-bit column offset
-  const size_t rowstride = (size_t)imt * km;
-  const size_t rbase = X3(1, 1, r);  // level k of row r starts at rbase + (k-1)*imt
-  const unsigned lb = (unsigned)(i - 1) * 8u;   // byte offset: `global_load v, v_off, s[base]` needs no per-load VALU address
-#define ATB(p) (*(decltype(p))((const char *)(p) + lb))
-#define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
-#define LD(p, k, dj) AT(p, k, dj)
+  // addresses = buffer descriptor + wave-uniform byte offset (one scalar register) + the lane's 32-bit column offset
+  const int rowstride = imt * km;
+  const int rbase = (r - 1) * rowstride;        // level k of row r starts at element rbase + (k-1)*imt
+  const unsigned lb = (unsigned)(i - 1) * 8u;   // the lane's byte offset within a row of a level
   const unsigned lb2 = (unsigned)(i - 1) * 16u;
-#define CFP(pair, k, dj) (*(const double2 *)((const char *)(cf + ((size_t)(pair) * N3 + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride) * 2) + lb2))
-  const size_t fbase = XF(1, 0, r);  // face k of row r starts at fbase + k*imt
+  const brsrc b_tm = mkbuf(tm, N3 * 8), b_tt = mkbuf(tt, N3 * 8), b_te = mkbuf(c.tot_e, N3 * 8), b_tn = mkbuf(c.tot_n, N3 * 8);
+  const brsrc b_tb = mkbuf(c.tot_b, NF * 8), b_vb = mkbuf(c.adv_vbt, NF * 8);
+  const brsrc b_cf = mkbuf(cf, N3 * 16 * CF_PAIRS), b_S = mkbuf(Sn, N3 * 8), b_R = mkbuf(Rpm, N3 * 16);
+#define OC(k, dj) ((rbase + ((k)-1) * imt + (dj) * rowstride) * 8)   /* byte offset of level k of row r+dj */
+#define LD(b, k, dj) bld(b_##b, lb, OC(k, dj))
+#define CFP(pair, k, dj) bld2(b_cf, lb2, ((int)(pair) * (int)N3 + rbase + ((k)-1) * imt + (dj) * rowstride) * 16)
+  const int fbase = (r - 1) * imt * (km + 1);  // face k of row r starts at element fbase + k*imt
+#define OF(kf) ((fbase + (kf) * imt) * 8)
   double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
   double tc0, tc1;                                                        // levels s-1 and s of t(tau)
   tc0 = tc1 = LD(tt, 1, 0);
   // surface faces
-  const double vb0 = ATB(c.adv_vbt + fbase);
+  const double vb0 = bld(b_vb, lb, OF(0));
   double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
   double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
   double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
@@ -308,8 +350,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const int sp = last ? km : s + 1;
     const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1), tc2 = LD(tt, sp, 0);
     const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
-    const double ve = AT(c.tot_e, s, 0), vn = AT(c.tot_n, s, 0), vs = AT(c.tot_n, s, -1);
-    const double vb = (s < km) ? ATB(c.tot_b + fbase + (size_t)s * imt) : ATB(c.adv_vbt + fbase + (size_t)km * imt);
+    const double ve = LD(te, s, 0), vn = LD(tn, s, 0), vs = LD(tn, s, -1);
+    const double vb = (s < km) ? bld(b_tb, lb, OF(s)) : bld(b_vb, lb, OF(km));
     double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
     _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
       const double2 v = CFP(p, s, 0);
@@ -356,7 +398,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
       fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up, mk, rzp, rzm);
     }
-    if (owned) *(double2 *)((char *)(Rpm + (rbase + (size_t)(s - 1) * imt) * 2) + lb2) = make_double2(ryp, rym);
+    if (owned) bst2(b_R, lb2, OC(s, 0) * 2, ryp, rym);
     // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
     const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
     const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
@@ -391,13 +433,13 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     if (s >= 2) {
       const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
       const double ADV_Tz = (fbfin_up - fbfin) * t_dzt2r.at(s - 2);
-      if (owned) AT(Sn, s - 1, 0) = spart_prev - ADV_Tz;
+      if (owned) bst(b_S, lb, OC(s - 1, 0), spart_prev - ADV_Tz);
       fbfin_up = fbfin;
     }
     if (last) {  // bottom face of the column (tracer.F:1065); vb holds adv_vbt there
       const double fbfin = vb * tt_c;
       const double ADV_Tz = (fbfin_up - fbfin) * dzt2r_s;
-      if (owned) AT(Sn, km, 0) = spart - ADV_Tz;
+      if (owned) bst(b_S, lb, OC(km, 0), spart - ADV_Tz);
     }
     // ---- roll ---------------------------------------------------------------------------
     rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
@@ -407,8 +449,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   }
 #undef LD
 #undef CFP
-#undef AT
-#undef ATB
+#undef OC
+#undef OF
 }
 
 // ===========================================================================
@@ -423,7 +465,17 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const int i = i0 + lane;
   LaneTable t_dtxcel, t_dztur, t_dztlr, t_dztr;   // filled while every lane is still active
   t_dtxcel.load(c.dtxcel, c.km); t_dztur.load(c.dztur, c.km); t_dztlr.load(c.dztlr, c.km); t_dztr.load(c.dztr, c.km);
+  const bool any_ocean = __builtin_amdgcn_ballot_w64(i <= i1 && c.kmt[X2(imin(i, i1), r)] > 0) != 0;
   if (i > i1) return;
+  if (!any_ocean && !c.no_landskip) {   // a segment of land: t(tau+1) = 0 there (the update is masked, tracer.F:1109-1130), nothing to read
+    double *tp0 = c.t_taup1 + (size_t)(n1 - 1) * N3;
+    const int ic0 = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
+    for (int k = 1; k <= km; ++k) {
+      tp0[X3(i, k, r)] = 0.0;
+      if (ic0) tp0[X3(ic0, k, r)] = 0.0;
+    }
+    return;
+  }
   const size_t nloc = (size_t)(n1 - 1 - c.n0);
   const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
@@ -436,13 +488,12 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   if (c.src && c.itrc[n1 - 1] != 0) source = c.src + (size_t)(c.itrc[n1 - 1] - 1) * N3;
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)];
   const double cstdyt2r = kload(c.cstdyt2r, r - 1);
-  const size_t rowstride = (size_t)imt * km;
-  const size_t rbase = X3(1, 1, r);   // wave-uniform part of every address; the lane adds its 32-bit column offset
-  const unsigned lb = (unsigned)(i - 1) * 8u;
-#define ATB(p) (*(decltype(p))((const char *)(p) + lb))
-#define AT(p, k, dj) ATB((p) + rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride)
-  const unsigned lb2 = (unsigned)(i - 1) * 16u;
-#define RPM(k, dj) (*(const double2 *)((const char *)(Rpm + (rbase + (size_t)((k)-1) * imt + (dj) * (ptrdiff_t)rowstride) * 2) + lb2))
+  const int rowstride = imt * km;
+  const int rbase = (r - 1) * rowstride;   // wave-uniform part of every address; the lane adds its 32-bit column offset
+  const unsigned lb = (unsigned)(i - 1) * 8u, lb2 = (unsigned)(i - 1) * 16u;
+#define OC(k, dj) ((rbase + ((k)-1) * imt + (dj) * rowstride) * 8)
+#define AT(b, k, dj) bld(b, lb, OC(k, dj))
+#define RPM(k, dj) bld2(b_R, lb2, OC(k, dj) * 2)
   const double topbc = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt], botbc = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt];
   const double aidif = c.aidif, eps = 1.e-30;
   const int kb = imax(2, kz);
@@ -453,22 +504,24 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   // number of loads in flight is the same on every path and the waits stay exact
   const bool has_src = source != 0;
   const double *srcp = has_src ? source : Sn;
+  const brsrc b_tm = mkbuf(tm, N3 * 8), b_tt = mkbuf(tt, N3 * 8), b_tn = mkbuf(c.tot_n, N3 * 8), b_R = mkbuf(Rpm, N3 * 16);
+  const brsrc b_S = mkbuf(Sn, N3 * 8), b_src = mkbuf(srcp, N3 * 8), b_dcb = mkbuf(c.diff_cbt, N3 * 8), b_tp = mkbuf(tp, N3 * 8);
   // The sweep is one dependent chain per column (Thomas recurrence): what a level reads is fetched one
   // level ahead into the other of two register sets so that the chain never waits for memory.
   struct Lvl {
     double m_c, m_s, m_n, t_c, t_s, t_n, vn, vs, rp0, rm0, rps, rms, rpn, rmn, sn, src, dcb;
   };
   auto load_level = [&](Lvl &L, int k) {
-    L.m_c = AT(tm, k, 0); L.m_s = AT(tm, k, -1); L.m_n = AT(tm, k, 1);
-    L.t_c = AT(tt, k, 0); L.t_s = AT(tt, k, -1); L.t_n = AT(tt, k, 1);
-    L.vn = AT(c.tot_n, k, 0); L.vs = AT(c.tot_n, k, -1);
+    L.m_c = AT(b_tm, k, 0); L.m_s = AT(b_tm, k, -1); L.m_n = AT(b_tm, k, 1);
+    L.t_c = AT(b_tt, k, 0); L.t_s = AT(b_tt, k, -1); L.t_n = AT(b_tt, k, 1);
+    L.vn = AT(b_tn, k, 0); L.vs = AT(b_tn, k, -1);
     {
       const double2 r0 = RPM(k, 0), rs = RPM(k, -1), rn = RPM(k, 1);
       L.rp0 = r0.x; L.rm0 = r0.y; L.rps = rs.x; L.rms = rs.y; L.rpn = rn.x; L.rmn = rn.y;
     }
-    L.sn = AT(Sn, k, 0);
-    L.src = AT(srcp, k, 0);
-    L.dcb = AT(c.diff_cbt, k, 0);
+    L.sn = AT(b_S, k, 0);
+    L.src = AT(b_src, k, 0);
+    L.dcb = AT(b_dcb, k, 0);
   };
   double dcb_up = 0.0;   // diff_cbt of the level above (the reference reads level max(1,k-1); at k=1 its factor is zeroed)
   auto level = [&](const Lvl &L, int k) {
@@ -530,11 +583,11 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
 #endif
   // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155)
   double znext = zprev;
-  AT(tp, km, 0) = znext;
+  bst(b_tp, lb, OC(km, 0), znext);
   if (ic) tp[X3(ic, km, r)] = znext;
   for (int k = km - 1; k >= 1; --k) {
     const double zk = zwork[(size_t)k * 64 + lane] - ework[(size_t)(k + 1) * 64 + lane] * znext;
-    AT(tp, k, 0) = zk;
+    bst(b_tp, lb, OC(k, 0), zk);
     if (ic) tp[X3(ic, k, r)] = zk;
     znext = zk;
   }
@@ -544,7 +597,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
 #endif
 }
 #undef AT
-#undef ATB
+#undef OC
 #undef RPM
 #endif  // __HIPCC__
 

@@ -993,7 +993,7 @@ UVIC_DEV void mobi_post_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k,
 struct mobi_store {
   void *params;
   double *f[8];
-  double *work, *work_side;     // work planes, one set per stream: the side stream works one step ahead
+  double *work, *work_side[2];  // work planes, one set per stream: the two side streams work ahead in turn
 };
 static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp, const uvic_mobi_forcing *hf, mobi_dev *dev,
                             mobi_store *st, hipStream_t stream, std::string &err) {
@@ -1020,8 +1020,10 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
     const size_t wb = mobi_work_doubles(imt, jmt, km) * 8;
     if ((e = hipMalloc((void **)&st->work, wb)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
     if ((e = hipMemsetAsync(st->work, 0, wb, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
-    if ((e = hipMalloc((void **)&st->work_side, wb)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
-    if ((e = hipMemsetAsync(st->work_side, 0, wb, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    for (int q = 0; q < 2; ++q) {
+      if ((e = hipMalloc((void **)&st->work_side[q], wb)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+      if ((e = hipMemsetAsync(st->work_side[q], 0, wb, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    }
   }
   if ((e = hipMemcpyAsync(st->params, hp, sizeof(uvic_mobi_params), hipMemcpyHostToDevice, stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
   for (int q = 0; q < 8; ++q) {

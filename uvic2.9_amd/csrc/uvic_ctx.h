@@ -67,6 +67,8 @@ typedef struct uvic_ctx {
   const double *tlat;                                             /* (imt,jmt) */
   const double *edrm2, *edrs2, *edrk1, *edro1;                    /* (imt,km,jmt) */
   double kappa_h, zetar, ogamma, gravrho0r;
+  int no_landskip;   /* debug */
+  int prio;          /* experiment: bit0 MOBI team waves at normal issue priority, bit1 transport waves raised */
 } uvic_ctx;
 
 #endif

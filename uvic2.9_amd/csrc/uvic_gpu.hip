@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row, tracer and segment live in scalar registers
   if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(2);
   colfct_wave(c, cf, S, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, 
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, r, n1, i0, i1)) return;
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(2);
   colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
@@ -149,29 +151,44 @@ __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   convect_column(c, i, j);
 }
 // convection in two passes (kernels_fct.hpp): T,S walk with the column staged in LDS, then replay
-__global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c) {
+// Column-local kernels (convection, MOBI) run over the ocean columns only: `ij` lists the columns with
+// kmt > 0 among i = 2..imt-1, j = 2..jmt-1 as (i-1) + imt*(j-1), row by row, so that a latitude slab is a
+// contiguous range [first, first+count) and neighbouring lanes still read neighbouring addresses.  Land
+// columns are never touched (their sources stay zero, see src_clean()).
+struct WetCols {
+  const int *ij;
+  int first, count;
+};
+#define WET_DECODE(w, cc)                          \
+  const int wid_ = (w).ij[(w).first + (cc)];       \
+  const int i = wid_ % c.imt + 1, j = wid_ / c.imt + 1
+__global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCols w) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
-  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  if (gid >= w.count) return;
+  WET_DECODE(w, gid);
   convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
 }
-__global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = (int)(gid % c.imt) + 1;
-  const int j = (int)((gid / c.imt) % c.jmt) + 1;
-  const int n = (int)(gid / ((long long)c.imt * c.jmt)) + 3;
-  if (n > c.nt || j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+__global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c, const WetCols w) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = gid / w.count + 3;
+  if (n > c.nt) return;
+  WET_DECODE(w, gid % w.count);
   convect_apply_cell(c, i, j, n);
 }
-__global__ void __launch_bounds__(128) k_mobi_pre(const uvic_ctx c, const mobi_dev m) {
-  CELL_DECODE(c);
-  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+// cell-parallel MOBI passes: thread = (ocean column, level), columns fastest
+__global__ void __launch_bounds__(128) k_mobi_pre(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = gid / w.count + 1;
+  if (k > c.km) return;
+  WET_DECODE(w, gid % w.count);
   mobi_pre_cell(c, m, i, k, j);
 }
-__global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_dev m) {
-  CELL_DECODE(c);
-  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+__global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = gid / w.count + 1;
+  if (k > c.km) return;
+  WET_DECODE(w, gid % w.count);
   mobi_post_cell(c, m, i, k, j);
 }
 // polar Fourier filter: one workgroup per (strip of a level of a row, local tracer)
@@ -221,16 +238,15 @@ __device__ __forceinline__ void mobi_team_role(const uvic_ctx &c, const mobi_dev
 #endif
 // register budget: the team's waves are resident for the whole MOBI pass on a side stream, so what
 // matters is how many transport waves still fit beside one of them on a SIMD
-__global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c, const mobi_dev m) {
+__global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * 64 + threadIdx.x;
-  int i = gid % c.imt + 1, j = gid / c.imt + 1;
-  const bool live = j >= c.js && j <= c.je && i >= 2 && i <= c.imt - 1;
-  if (!live) { i = 2; j = c.js; }
+  const bool live = gid < w.count;
+  WET_DECODE(w, live ? gid : 0);   // lanes beyond the list walk the first column and store nothing
   int kmax = live ? c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)] : 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
-  __builtin_amdgcn_s_setprio(3);
+  if (!(c.prio & 1)) __builtin_amdgcn_s_setprio(3);
   switch (threadIdx.y) {   // wave-uniform: every wave runs the code specialised for its role
     case 0: mobi_team_role<0>(c, m, lds, i, j, live, kmax); break;
     case 1: mobi_team_role<1>(c, m, lds, i, j, live, kmax); break;
@@ -238,10 +254,10 @@ __global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c,
     default: mobi_team_role<3>(c, m, lds, i, j, live, kmax); break;
   }
 }
-__global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m) {
+__global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
-  if (j < c.js || j > c.je || i < 2 || i > c.imt - 1) return;
+  if (gid >= w.count) return;
+  WET_DECODE(w, gid);
   // few, long, latency-bound waves: let them win issue arbitration over the streaming kernels
   // that share their SIMDs when the sources are computed one step ahead on the side stream
   __builtin_amdgcn_s_setprio(3);
@@ -325,6 +341,11 @@ struct uvic_gpu {
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
   double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
+  // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
+  int *wet_dev;
+  std::vector<int> wet_row_start;
+  // source buffers known to hold zeros on land (MOBI writes ocean columns only): see src_clean()
+  std::vector<void *> src_zeroed;
   uvic_ctx ctx;
   mobi_dev mobi;
   mobi_store mobi_st;
@@ -336,29 +357,37 @@ struct uvic_gpu {
   int flt_nitems, flt_threads;
   double mobi_dtnpzd;
   bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
-  // one-step-ahead source terms on a side stream (uvic_gpu_prefetch_sources)
-  hipStream_t side;
+  // one-step-ahead source terms on side streams (uvic_gpu_prefetch_sources): two of them, taken in turn, so that
+  // the MOBI chain of step n+2 (pre -> team -> post) may start while that of step n+1 is still running
+  hipStream_t side_m[2];
+  int mobi_flip;            // which of the two the next prefetch uses
+  bool mobi_two_streams;    // UVIC_MOBI_STREAMS=1 keeps every chain on the first (measurement)
+  // events of the look-ahead chains alternate, because the chain of step n+1 is queued (and records its event)
+  // before step n waits for the chain of step n: `_pending` = recorded during this step, `_ready` = what this step waits for
+  int ev_flip;
+  hipEvent_t ev_src_ready, ev_src_pending, ev_iso_ready, ev_iso_pending;
   // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
   hipStream_t side2;
-  // T and S finish pass B and the convective T,S walk on a third side stream while pass B of the other tracers runs
-  hipStream_t side3;
+  // (T and S finish pass B and the convective T,S walk on side2 as well, beside pass B of the other tracers: the
+  // device offers four hardware queues, and a fifth stream would share one with another and wait behind its barriers)
+  bool step_begun;    // ev_step_begin of the current step is recorded (uvic_gpu_rotate ends the step)
   hipEvent_t ev_fct_done, ev_ts_done;
-  bool ts_ahead;      // this step's convect_ts was already issued on side3
+  bool ts_ahead;      // this step's convect_ts was already issued on side2
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
   bool ts_no_src;     // itrc(1) = itrc(2) = 0: T and S have no source term (known from the upload of itrc)
-  hipEvent_t ev_iso_next;
+  hipEvent_t ev_iso_next[2];
   void *iso_alt[UVIC_F_COUNT];
   double *work_alt[3], *coef_alt;
   bool iso_prefetch_pending, iso_from_prefetch;
-  hipEvent_t ev_step_begin, ev_src_next;
+  hipEvent_t ev_step_begin, ev_src_next[2];
   void *src_alt;
   bool prefetch_pending, src_from_prefetch, mixing;
   int nchunk, fct_threads, upd_threads;
   size_t fct_lds, upd_lds;
   // profiling
   bool profiling;
-  std::vector<hipEvent_t> ev[4];            // [0] main stream, [1] MOBI, [2] isopyc, [3] T,S side streams
-  std::vector<const char *> ev_names[4];
+  std::vector<hipEvent_t> ev[5];            // [0] main stream, [1] MOBI, [2] isopyc, [3] T,S side streams, [4] MOBI (odd steps)
+  std::vector<const char *> ev_names[5];
   std::vector<hipEvent_t> ev_pool;
 };
 
@@ -435,21 +464,36 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->have_mobi = false;
   h->have_vmix = false;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
+  h->wet_dev = nullptr;
+  h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
-  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  const int prio_exp = getenv("UVIC_PRIO") ? atoi(getenv("UVIC_PRIO")) : 0;
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lower = higher priority
+  if (prio_exp & 4) HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+  else HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->mobi_flip = 0;
+  h->mobi_two_streams = true;
+  if (const char *e = getenv("UVIC_MOBI_STREAMS")) h->mobi_two_streams = atoi(e) != 1;
+  if (prio_exp & 8) HIPCHK(hipStreamCreateWithPriority(&h->side_m[0], hipStreamNonBlocking, prio_lo));
+  else HIPCHK(hipStreamCreateWithFlags(&h->side_m[0], hipStreamNonBlocking));
+  if (h->mobi_two_streams && (prio_exp & 8)) HIPCHK(hipStreamCreateWithPriority(&h->side_m[1], hipStreamNonBlocking, prio_lo));
+  else if (h->mobi_two_streams) HIPCHK(hipStreamCreateWithFlags(&h->side_m[1], hipStreamNonBlocking));
+  else h->side_m[1] = h->side_m[0];
   HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
-  h->ts_ahead = false; h->serial = false; h->ts_no_src = false;
-  HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next, hipEventDisableTiming));
+  h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false;
+  for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next[q], hipEventDisableTiming));
+  h->ev_iso_ready = h->ev_iso_pending = h->ev_iso_next[0];
+  h->ev_flip = 0;
   for (int f = 0; f < UVIC_F_COUNT; ++f) h->iso_alt[f] = nullptr;
   h->work_alt[0] = h->work_alt[1] = h->work_alt[2] = nullptr; h->coef_alt = nullptr;
   h->iso_prefetch_pending = h->iso_from_prefetch = false;
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_src_next, hipEventDisableTiming));
+  for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
+  h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
   h->src_alt = nullptr;
   h->mobi_team = true;
   if (const char *e = getenv("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
@@ -493,6 +537,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   bind_ctx(h);
   h->ctx.n0 = 0; h->ctx.nt_local = dims->nt; h->ctx.js = 2; h->ctx.je = dims->jmt - 1;
   h->ctx.c2dtts = 0.0; h->ctx.aidif = 0.5;
+  h->ctx.no_landskip = getenv("UVIC_NO_LANDSKIP") ? 1 : 0;
+  h->ctx.prio = getenv("UVIC_PRIO") ? atoi(getenv("UVIC_PRIO")) : 0;
   // tile geometry: keep the FCT tile within the LDS budget
   int budget_kb = 150;
   if (const char *e = getenv("UVIC_LDS_BUDGET_KB")) budget_kb = atoi(e);
@@ -535,6 +581,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree((void *)h->ctx.tmask);
   (void)hipFree(h->coef);
   (void)hipFree(h->rpm);
+  (void)hipFree(h->wet_dev);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
@@ -542,19 +589,19 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
     (void)hipFree(h->mobi_st.work);
-    (void)hipFree(h->mobi_st.work_side);
+    for (int q = 0; q < 2; ++q) (void)hipFree(h->mobi_st.work_side[q]);
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
   }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
-  (void)hipEventDestroy(h->ev_src_next);
-  (void)hipStreamDestroy(h->side);
+  for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_src_next[q]);
+  (void)hipStreamDestroy(h->side_m[0]);
+  if (h->side_m[1] != h->side_m[0]) (void)hipStreamDestroy(h->side_m[1]);
   (void)hipStreamDestroy(h->side2);
-  (void)hipStreamDestroy(h->side3);
   (void)hipEventDestroy(h->ev_fct_done);
   (void)hipEventDestroy(h->ev_ts_done);
-  (void)hipEventDestroy(h->ev_iso_next);
+  for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_iso_next[q]);
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->iso_alt[f]);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->work_alt[q]);
   (void)hipFree(h->coef_alt);
@@ -587,6 +634,43 @@ static int make_tmask(uvic_gpu *h) {
                      (double *)h->ctx.tmask, h->d.imt, h->d.km, h->d.jmt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
+  // the ocean columns (WetCols) follow kmt
+  const int imt = h->d.imt, jmt = h->d.jmt;
+  std::vector<int> kmt((size_t)imt * jmt), wet;
+  HIPCHK(hipMemcpy(kmt.data(), h->buf[UVIC_F_KMT], kmt.size() * 4, hipMemcpyDeviceToHost));
+  h->wet_row_start.assign((size_t)jmt + 2, 0);
+  for (int j = 1; j <= jmt; ++j) {
+    h->wet_row_start[j] = (int)wet.size();
+    if (j >= 2 && j <= jmt - 1)
+      for (int i = 2; i <= imt - 1; ++i)
+        if (kmt[(size_t)(i - 1) + (size_t)imt * (j - 1)] > 0) wet.push_back((i - 1) + imt * (j - 1));
+  }
+  h->wet_row_start[jmt + 1] = (int)wet.size();
+  (void)hipFree(h->wet_dev);
+  h->wet_dev = nullptr;
+  HIPCHK(hipMalloc((void **)&h->wet_dev, (wet.size() + 1) * 4));
+  if (!wet.empty()) HIPCHK(hipMemcpy(h->wet_dev, wet.data(), wet.size() * 4, hipMemcpyHostToDevice));
+  h->src_zeroed.clear();   // what was ocean may be land now
+  // all-land waves of pass A leave R+- alone
+  HIPCHK(hipMemsetAsync(h->rpm, 0, (size_t)imt * h->d.km * jmt * 16 * (size_t)h->d.nt, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// the ocean columns of rows js..je
+static WetCols wet_range(const uvic_gpu *h, int js, int je) {
+  WetCols w;
+  w.ij = h->wet_dev;
+  w.first = h->wet_row_start[js];
+  w.count = h->wet_row_start[je + 1] - w.first;
+  return w;
+}
+// MOBI writes the sources of ocean columns only; a buffer it is about to fill for the first time (or the first
+// time since kmt or src came from the host) is cleared on the same stream before
+static int src_clean(uvic_gpu *h, void *src, hipStream_t st) {
+  for (void *p : h->src_zeroed)
+    if (p == src) return 0;
+  HIPCHK(hipMemsetAsync(src, 0, (size_t)field_elems(h->d, UVIC_F_SRC) * 8, st));
+  h->src_zeroed.push_back(src);
   return 0;
 }
 
@@ -599,7 +683,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
   const size_t es = elem_size(field);
   if (field == UVIC_F_T_TAUM1 || field == UVIC_F_T_TAU || field == UVIC_F_T_TAUP1) {
     // new state from the host: whatever the side streams computed ahead from the old one is void
-    HIPCHK(hipStreamSynchronize(h->side));
+    for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
     HIPCHK(hipStreamSynchronize(h->side2));
     h->prefetch_pending = h->src_from_prefetch = false;
     h->iso_prefetch_pending = h->iso_from_prefetch = false;
@@ -610,6 +694,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
     const int32_t *it = (const int32_t *)host;
     h->ts_no_src = it[0] == 0 && it[1] == 0;
   }
+  if (field == UVIC_F_SRC) h->src_zeroed.clear();
   if (field == UVIC_F_KMT) return make_tmask(h);
   return 0;
 }
@@ -635,6 +720,7 @@ static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, boo
   const int64_t ex = extra_of(h->d, FIELDS[field].extra);
   const int64_t nrows = jhi - jlo + 1;
   HIPCHK(hipSetDevice(h->device));
+  if (up && field == UVIC_F_SRC) h->src_zeroed.clear();
   for (int64_t e = 0; e < ex; ++e) {
     char *dev = (char *)h->buf[field] + (e * plane(h->d, kd) + (int64_t)(jlo - 1) * rowlen) * 8;
     char *hst = (char *)host + e * nrows * rowlen * 8;
@@ -677,14 +763,16 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
 // -- launch helpers ------------------------------------------------------------
 static void mark_on(uvic_gpu *h, const char *name, int sid) {
   if (!h->profiling) return;
-  const size_t used = h->ev[0].size() + h->ev[1].size() + h->ev[2].size() + h->ev[3].size();
+  size_t used = 0;
+  for (int q = 0; q < 5; ++q) used += h->ev[q].size();
   if (used >= h->ev_pool.size()) {
     hipEvent_t e;
     (void)hipEventCreate(&e);
     h->ev_pool.push_back(e);
   }
   hipEvent_t e = h->ev_pool[used];
-  (void)hipEventRecord(e, sid == 0 ? h->stream : (sid == 1 ? h->side : (sid == 2 ? h->side2 : h->side3)));
+  hipStream_t sts[5] = {h->stream, h->side_m[0], h->side2, h->side2, h->side_m[1]};
+  (void)hipEventRecord(e, sts[sid]);
   h->ev[sid].push_back(e);
   h->ev_names[sid].push_back(name);
 }
@@ -718,7 +806,7 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
 }
 static int launch_isopyc(uvic_gpu *h) {
   if (h->iso_from_prefetch) {   // computed one step ahead on its side stream (uvic_gpu_prefetch_isopyc)
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_iso_next, 0));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_iso_ready, 0));
     h->iso_from_prefetch = false;
     return 0;
   }
@@ -750,22 +838,24 @@ static int launch_transport(uvic_gpu *h) {
                        h->ts_no_src;
     if (split) {
       HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
-      HIPCHK(hipStreamWaitEvent(h->side3, h->ev_fct_done, 0));
+      HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fct_done, 0));
       uvic_ctx cts = c;
       cts.nt_local = 2;
       ColGrid bts = b;
       bts.total = bts.nrows * 2 * bts.nseg;
       const unsigned nbts = (unsigned)((((bts.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
       mark_on(h, "begin", 3);
-      hipLaunchKernelGGL(k_colupd, dim3(nbts), dim3(64, COLUPD_WAVES), upd_lds, h->side3, cts, (const double *)S, bts);
+      hipLaunchKernelGGL(k_colupd, dim3(nbts), dim3(64, COLUPD_WAVES), upd_lds, h->side2, cts, (const double *)S, bts);
       mark_on(h, "colupd_ts", 3);
-      hipLaunchKernelGGL(k_convect_ts, dim3(col_blocks(h, 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side3, c);
+      const WetCols w = wet_range(h, c.js, c.je);
+      if (w.count > 0)
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side2, c, w);
       mark_on(h, "convect_ts", 3);
-      HIPCHK(hipEventRecord(h->ev_ts_done, h->side3));
+      HIPCHK(hipEventRecord(h->ev_ts_done, h->side2));
       h->ts_ahead = true;
     }
     if (h->src_from_prefetch) {
-      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
       h->src_from_prefetch = false;
     }
     if (split) {   // the other tracers: work arrays are indexed from the group's first tracer
@@ -796,7 +886,7 @@ static int launch_transport(uvic_gpu *h) {
   hipLaunchKernelGGL(k_fct_rows, dim3((unsigned)(((g1.total + 7) / 8) * 8)), dim3(h->fct_threads), h->fct_lds, h->stream, c, g1);
   mark(h, "fct_rows");
   if (h->src_from_prefetch) {  // the FCT kernel does not read the sources; only the update does
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_next, 0));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
     h->src_from_prefetch = false;
   }
   hipLaunchKernelGGL(k_update_rows, dim3((unsigned)(((g2.total + 7) / 8) * 8)), dim3(h->upd_threads), h->upd_lds, h->stream, c, g2);
@@ -810,16 +900,18 @@ static int launch_convect(uvic_gpu *h) {
     hipLaunchKernelGGL(k_convect, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx);
     mark(h, "convect");
   } else {
+    const WetCols w = wet_range(h, h->ctx.js, h->ctx.je);
     if (h->ts_ahead) {      // issued on the T,S side stream by launch_transport
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
       h->ts_ahead = false;
     } else {
-      hipLaunchKernelGGL(k_convect_ts, dim3(col_blocks(h, 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx);
+      if (w.count > 0)
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx, w);
       mark(h, "convect_ts");
     }
     if (h->d.nt > 2) {
-      const long long n = (long long)h->d.imt * h->d.jmt * (h->d.nt - 2);
-      hipLaunchKernelGGL(k_convect_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx);
+      const long long n = (long long)w.count * (h->d.nt - 2);
+      if (n > 0) hipLaunchKernelGGL(k_convect_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx, w);
       mark(h, "convect_apply");
     }
   }
@@ -849,22 +941,31 @@ static int mobi_step_scalars(uvic_gpu *h, double c2dtts, mobi_step &S) {
   S.declin = sin((fmod(h->mobi.relyr, 1.) - 0.22) * 2. * h->mobi.pi) * 0.4;
   return 0;
 }
+// the three MOBI passes over the ocean columns of the slab, on stream `st` (profile list `sid`)
+static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hipStream_t st, int sid) {
+  const WetCols w = wet_range(h, c.js, c.je);
+  if (int rc = src_clean(h, (void *)c.src, st)) return rc;
+  mark_on(h, "begin", sid);
+  const unsigned cells = (unsigned)(((long long)w.count * c.km + 127) / 128), cols = (unsigned)((w.count + 63) / 64);
+  if (w.count > 0) hipLaunchKernelGGL(k_mobi_pre, dim3(cells), dim3(128), 0, st, c, m, w);
+  mark_on(h, "mobi_pre", sid);
+  if (w.count > 0) {
+    if (h->mobi_team)
+      hipLaunchKernelGGL(k_mobi_team, dim3(cols), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, st, c, m, w);
+    else
+      hipLaunchKernelGGL(k_mobi, dim3(cols), dim3(64), 0, st, c, m, w);
+  }
+  mark_on(h, "mobi", sid);
+  if (w.count > 0) hipLaunchKernelGGL(k_mobi_post, dim3(cells), dim3(128), 0, st, c, m, w);
+  mark_on(h, "mobi_post", sid);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int launch_mobi(uvic_gpu *h) {
   if (!h->have_mobi) return 0;
   if (h->src_from_prefetch) return 0;  // computed one step ahead on the side stream; launch_transport waits for it
   if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.S)) return rc;
-  mark(h, "begin");
-  hipLaunchKernelGGL(k_mobi_pre, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
-  mark(h, "mobi_pre");
-  if (h->mobi_team)
-    hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->stream, h->ctx, h->mobi);
-  else
-    hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx, h->mobi);
-  mark(h, "mobi");
-  hipLaunchKernelGGL(k_mobi_post, dim3(cell_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx, h->mobi);
-  mark(h, "mobi_post");
-  HIPCHK(hipGetLastError());
-  return 0;
+  return launch_mobi_on(h, h->ctx, h->mobi, h->stream, 0);
 }
 
 // -- producers of the shared inputs (kernels_prep.hpp) ---------------------------------
@@ -981,15 +1082,23 @@ extern "C" int uvic_gpu_tracer(uvic_gpu *h) {
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+// The point on the main stream where the previous step is complete: what the look-ahead chains of this step wait
+// for.  Recorded once per step by whichever of step_async / step_pre_async / prefetch_* comes first.
+static int step_begin(uvic_gpu *h) {
+  if (h->step_begun) return 0;
+  HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));
+  h->step_begun = true;
+  return 0;
+}
 // asynchronous variants used by the time loop of bench.py: no host sync
 extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
-  HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));  // everything the next step's sources may read is done
+  if (int rc = step_begin(h)) return rc;
   if (int rc = launch_isopyc(h)) return rc;
   return launch_tracer(h);
 }
 // MOBI sources of the NEXT step from t(tau) (= next step's t(tau-1) on a leapfrog step) on
-// the side stream, overlapped with this step's transport.  Call after uvic_gpu_step_async
+// the side stream, overlapped with this step's transport.  Call before (preferred: its kernels are then queued ahead of this step's side-stream work) or after uvic_gpu_step_async
 // and before uvic_gpu_rotate; only valid when the next step is a leapfrog step.
 extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   if (!h) return fail_msg("null handle");
@@ -997,28 +1106,24 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   const size_t bytes = (size_t)field_elems(h->d, UVIC_F_SRC) * 8;
   if (!h->src_alt) {
     HIPCHK(hipMalloc(&h->src_alt, bytes));
-    HIPCHK(hipMemsetAsync(h->src_alt, 0, bytes, h->side));
   }
   uvic_ctx c = h->ctx;
   mobi_dev m = h->mobi;
   c.t_taum1 = h->ctx.t_tau;
-  mobi_set_work(&m, h->mobi_st.work_side, h->d.imt, h->d.jmt, h->d.km);
+  const int q = h->mobi_flip;          // this chain's stream, work planes and event; the next prefetch takes the other set
+  if (h->mobi_two_streams) h->mobi_flip ^= 1;
+  hipStream_t st = h->side_m[q];
+  const int sid = q ? 4 : 1;
+  mobi_set_work(&m, h->mobi_st.work_side[q], h->d.imt, h->d.jmt, h->d.km);
   c.src = (const double *)h->src_alt;
   c.c2dtts = c2dtts_next;
   if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
-  HIPCHK(hipStreamWaitEvent(h->side, h->ev_step_begin, 0));
-  mark_on(h, "begin", 1);
-  hipLaunchKernelGGL(k_mobi_pre, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
-  mark_on(h, "mobi_pre", 1);
-  if (h->mobi_team)
-    hipLaunchKernelGGL(k_mobi_team, dim3(col_blocks(h, 64)), dim3(64, 4), UV_MOBI_LDS_DOUBLES * 8, h->side, c, m);
-  else
-    hipLaunchKernelGGL(k_mobi, dim3(col_blocks(h, 64)), dim3(64), 0, h->side, c, m);
-  mark_on(h, "mobi", 1);
-  hipLaunchKernelGGL(k_mobi_post, dim3(cell_blocks(h, 128)), dim3(128), 0, h->side, c, m);
-  mark_on(h, "mobi_post", 1);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(h->ev_src_next, h->side));
+  if (int rc = step_begin(h)) return rc;
+  // src_alt was read last by pass B of the previous step (before ev_step_begin); the other chain writes the other buffer
+  HIPCHK(hipStreamWaitEvent(st, h->ev_step_begin, 0));
+  if (int rc = launch_mobi_on(h, c, m, st, sid)) return rc;
+  h->ev_src_pending = h->ev_src_next[h->ev_flip];
+  HIPCHK(hipEventRecord(h->ev_src_pending, st));
   h->prefetch_pending = true;
   return 0;
 }
@@ -1060,9 +1165,11 @@ extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h) {
   swap_iso_buffers(h);
   bind_ctx(h);
   c.t_taum1 = h->ctx.t_tau;
+  if (int rc = step_begin(h)) return rc;
   HIPCHK(hipStreamWaitEvent(h->side2, h->ev_step_begin, 0));
   if (int rc = launch_isopyc_on(h, c, coef, h->side2, 2)) return rc;
-  HIPCHK(hipEventRecord(h->ev_iso_next, h->side2));
+  h->ev_iso_pending = h->ev_iso_next[h->ev_flip];
+  HIPCHK(hipEventRecord(h->ev_iso_pending, h->side2));
   h->iso_prefetch_pending = true;
   return 0;
 }
@@ -1076,7 +1183,7 @@ extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on) {
 // sharded time loop: everything before the exchange of t(tau+1) ...
 extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
-  HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));
+  if (int rc = step_begin(h)) return rc;
   if (int rc = launch_isopyc(h)) return rc;
   if (int rc = launch_mobi(h)) return rc;
   return launch_transport(h);
@@ -1088,6 +1195,8 @@ extern "C" int uvic_gpu_convect_async(uvic_gpu *h) {
 }
 extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
+  h->step_begun = false;
+  h->ev_flip ^= 1;
   void *m1 = h->buf[UVIC_F_T_TAUM1], *t0 = h->buf[UVIC_F_T_TAU], *p1 = h->buf[UVIC_F_T_TAUP1];
   h->buf[UVIC_F_T_TAUM1] = t0;
   h->buf[UVIC_F_T_TAU] = p1;
@@ -1098,35 +1207,35 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->src_alt = s0;
     h->prefetch_pending = false;
     h->src_from_prefetch = true;
+    h->ev_src_ready = h->ev_src_pending;
   }
   if (h->iso_prefetch_pending) {   // likewise the T,S-derived fields
     swap_iso_buffers(h);
     h->iso_prefetch_pending = false;
     h->iso_from_prefetch = true;
+    h->ev_iso_ready = h->ev_iso_pending;
   }
   bind_ctx(h);
   return 0;
 }
 extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
-  HIPCHK(hipStreamSynchronize(h->side));
+  for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
   HIPCHK(hipStreamSynchronize(h->side2));
-  HIPCHK(hipStreamSynchronize(h->side3));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
 static void profile_reset(uvic_gpu *h) {
-  for (int q = 0; q < 4; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
+  for (int q = 0; q < 5; ++q) { h->ev[q].clear(); h->ev_names[q].clear(); }
 }
 // mean duration per kernel name from the recorded events (consecutive events of one stream)
 static int profile_collect(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
-  HIPCHK(hipStreamSynchronize(h->side));
+  for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
   HIPCHK(hipStreamSynchronize(h->side2));
-  HIPCHK(hipStreamSynchronize(h->side3));
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<KernelStat> st;
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 5; ++q)
     for (size_t e = 1; e < h->ev[q].size(); ++e) {
       if (strcmp(h->ev_names[q][e], "begin") == 0) continue;
       float ms = 0.f;
