@@ -164,6 +164,7 @@ UVIC_DEV void coef_bv_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
 #if defined(__HIPCC__)
 struct ColGrid {
   int r0, nrows, nseg, total;  // total = nrows * nt_local * nseg work items (one wave each)
+  int fuse_convect;            // pass B: replay the convective mixing found by the T,S walk before t(tau+1) is stored
 };
 #define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
 #define COLUPD_WAVES 2  // waves per workgroup of pass B: 2 x 2 x (km+1) x 512 B of LDS each, three workgroups per CU at km = 19
@@ -459,7 +460,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 // [k][lane], so that the forward sweep writes t(tau+1) nowhere and the back substitution stores it once
 // ===========================================================================
 __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int r, int n1,
-                                            int i0, int i1) {
+                                            int i0, int i1, int fuse_convect) {
   UV_DIMS(c);
   const int lane = threadIdx.x;
   const int i = i0 + lane;
@@ -581,6 +582,33 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
 #ifdef UV_COL_TIMING
   const long long tq1 = clock64();
 #endif
+  // Convection fused in (the T,S walk of this step has run already, on the side stream): when a column of the
+  // wave has a mixed segment, the back substitution leaves t(tau+1) in LDS, the segments are replayed in the
+  // order they were found (convect.F:257-271: tsm = sum t*dztxcl over kt..kb, in that order, / zsm) and the column
+  // is stored once.  Same arithmetic as convect_apply_cell, which this replaces.
+  const int ncv = fuse_convect ? c.cv_nseg[X2(i, r)] : 0;
+  if (__builtin_amdgcn_ballot_w64(ncv > 0) != 0) {
+    double zn = zprev;
+    for (int k = km - 1; k >= 1; --k) {
+      const double zk = zwork[(size_t)k * 64 + lane] - ework[(size_t)(k + 1) * 64 + lane] * zn;
+      zwork[(size_t)k * 64 + lane] = zk;
+      zn = zk;
+    }
+    for (int sg = 1; sg <= ncv; ++sg) {
+      const int kt = c.cv_kt[X3(i, sg, r)], kb = c.cv_kb[X3(i, sg, r)];
+      const double zsm = c.cv_z[X3(i, sg, r)];
+      double tsm3 = 0.0;
+      for (int k = kt; k <= kb; ++k) tsm3 = tsm3 + zwork[(size_t)k * 64 + lane] * c.dztxcl[k - 1];
+      const double tmx3 = tsm3 / zsm;
+      for (int k = kt; k <= kb; ++k) zwork[(size_t)k * 64 + lane] = tmx3;
+    }
+    for (int k = 1; k <= km; ++k) {
+      const double zk = zwork[(size_t)k * 64 + lane];
+      bst(b_tp, lb, OC(k, 0), zk);
+      if (ic) tp[X3(ic, k, r)] = zk;
+    }
+    return;
+  }
   // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155)
   double znext = zprev;
   bst(b_tp, lb, OC(km, 0), znext);

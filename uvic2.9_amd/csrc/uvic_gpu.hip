@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row, tracer and segment live in scalar registers
   if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
-  if (c.prio & 2) __builtin_amdgcn_s_setprio(2);
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
   colfct_wave(c, cf, S, r, n1, i0, i1);
 }
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
@@ -141,8 +141,8 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, 
   int r, n1, i0, i1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, r, n1, i0, i1)) return;
-  if (c.prio & 2) __builtin_amdgcn_s_setprio(2);
-  colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, r, n1, i0, i1);
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
+  colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, r, n1, i0, i1, g.fuse_convect);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCo
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= w.count) return;
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
   WET_DECODE(w, gid);
   convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
 }
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c,
   int kmax = live ? c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)] : 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
-  if (!(c.prio & 1)) __builtin_amdgcn_s_setprio(3);
+  if (!(c.prio & 1)) __builtin_amdgcn_s_setprio(2);
   switch (threadIdx.y) {   // wave-uniform: every wave runs the code specialised for its role
     case 0: mobi_team_role<0>(c, m, lds, i, j, live, kmax); break;
     case 1: mobi_team_role<1>(c, m, lds, i, j, live, kmax); break;
@@ -371,6 +372,7 @@ struct uvic_gpu {
   // (T and S finish pass B and the convective T,S walk on side2 as well, beside pass B of the other tracers: the
   // device offers four hardware queues, and a fifth stream would share one with another and wait behind its barriers)
   bool step_begun;    // ev_step_begin of the current step is recorded (uvic_gpu_rotate ends the step)
+  hipStream_t side_ts; // the T,S passes: side2, or a stream of its own when the runtime has more than four hardware queues
   hipEvent_t ev_fct_done, ev_ts_done;
   bool ts_ahead;      // this step's convect_ts was already issued on side2
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
@@ -482,6 +484,11 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   else if (h->mobi_two_streams) HIPCHK(hipStreamCreateWithFlags(&h->side_m[1], hipStreamNonBlocking));
   else h->side_m[1] = h->side_m[0];
   HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+  h->side_ts = h->side2;
+  {
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    if (q && atoi(q) >= 5) HIPCHK(hipStreamCreateWithFlags(&h->side_ts, hipStreamNonBlocking));
+  }
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
   h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false;
@@ -598,6 +605,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_src_next[q]);
   (void)hipStreamDestroy(h->side_m[0]);
   if (h->side_m[1] != h->side_m[0]) (void)hipStreamDestroy(h->side_m[1]);
+  if (h->side_ts != h->side2) (void)hipStreamDestroy(h->side_ts);
   (void)hipStreamDestroy(h->side2);
   (void)hipEventDestroy(h->ev_fct_done);
   (void)hipEventDestroy(h->ev_ts_done);
@@ -685,6 +693,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
     // new state from the host: whatever the side streams computed ahead from the old one is void
     for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
     HIPCHK(hipStreamSynchronize(h->side2));
+  HIPCHK(hipStreamSynchronize(h->side_ts));
     h->prefetch_pending = h->src_from_prefetch = false;
     h->iso_prefetch_pending = h->iso_from_prefetch = false;
   }
@@ -771,7 +780,7 @@ static void mark_on(uvic_gpu *h, const char *name, int sid) {
     h->ev_pool.push_back(e);
   }
   hipEvent_t e = h->ev_pool[used];
-  hipStream_t sts[5] = {h->stream, h->side_m[0], h->side2, h->side2, h->side_m[1]};
+  hipStream_t sts[5] = {h->stream, h->side_m[0], h->side2, h->side_ts, h->side_m[1]};
   (void)hipEventRecord(e, sts[sid]);
   h->ev[sid].push_back(e);
   h->ev_names[sid].push_back(name);
@@ -826,49 +835,63 @@ static int launch_transport(uvic_gpu *h) {
     b = a;
     b.r0 = c.js; b.nrows = c.je - c.js + 1; b.total = b.nrows * c.nt_local * b.nseg;
     double *S = h->work[3];
-    mark(h, "begin");
-    const unsigned na = (unsigned)((((a.total + 3) / 4 + 7) / 8) * 8);
-    const unsigned nb = (unsigned)((((b.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_colfct, dim3(na), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
-    mark(h, "colfct");
+    a.fuse_convect = b.fuse_convect = 0;
     const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
-    // T and S (no source terms, and all the convective T,S walk needs) take their pass B and that walk on a side
-    // stream beside pass B of the other tracers; not under tracer sharding, where convection follows the exchange
+    auto blocks_a = [](const ColGrid &g) { return (unsigned)((((g.total + 3) / 4 + 7) / 8) * 8); };
+    auto blocks_b = [](const ColGrid &g) { return (unsigned)((((g.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8); };
+    // T and S first: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both passes and
+    // the walk run on the side stream while the main stream works on the other tracers, whose pass B then finds the
+    // mixed segments ready and replays them itself (no separate convection pass over t(tau+1)).  Not under tracer
+    // sharding, where convection follows the exchange.
     const bool split = !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
                        h->ts_no_src;
     if (split) {
-      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
-      HIPCHK(hipStreamWaitEvent(h->side2, h->ev_fct_done, 0));
+      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));       // here: this step's T,S-derived fields are complete on the main stream
+      HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
       uvic_ctx cts = c;
       cts.nt_local = 2;
-      ColGrid bts = b;
+      cts.prio |= 2;
+      ColGrid ats = a, bts = b;
+      ats.total = ats.nrows * 2 * ats.nseg;
       bts.total = bts.nrows * 2 * bts.nseg;
-      const unsigned nbts = (unsigned)((((bts.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
       mark_on(h, "begin", 3);
-      hipLaunchKernelGGL(k_colupd, dim3(nbts), dim3(64, COLUPD_WAVES), upd_lds, h->side2, cts, (const double *)S, bts);
+      hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+      mark_on(h, "colfct_ts", 3);
+      hipLaunchKernelGGL(k_colupd, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
       mark_on(h, "colupd_ts", 3);
       const WetCols w = wet_range(h, c.js, c.je);
       if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side2, c, w);
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side_ts, cts, w);
       mark_on(h, "convect_ts", 3);
-      HIPCHK(hipEventRecord(h->ev_ts_done, h->side2));
+      HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
       h->ts_ahead = true;
-    }
-    if (h->src_from_prefetch) {
-      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
-      h->src_from_prefetch = false;
-    }
-    if (split) {   // the other tracers: work arrays are indexed from the group's first tracer
+      // the other tracers on the main stream: work arrays are indexed from the group's first tracer
       const size_t N3 = (size_t)c.imt * c.km * c.jmt;
       uvic_ctx cr = c;
       cr.n0 = 2; cr.nt_local = c.nt - 2;
       cr.Rpm = c.Rpm + 2 * N3 * 2;
-      ColGrid br = b;
+      ColGrid ar = a, br = b;
+      ar.total = ar.nrows * cr.nt_local * ar.nseg;
       br.total = br.nrows * cr.nt_local * br.nseg;
-      const unsigned nbr = (unsigned)((((br.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8);
-      hipLaunchKernelGGL(k_colupd, dim3(nbr), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+      br.fuse_convect = 1;
+      mark(h, "begin");
+      hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ar)), dim3(64, 4), 0, h->stream, cr, (const double *)h->coef, S + 2 * N3, ar);
+      mark(h, "colfct");
+      if (h->src_from_prefetch) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+        h->src_from_prefetch = false;
+      }
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
+      hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
     } else {
-      hipLaunchKernelGGL(k_colupd, dim3(nb), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
+      mark(h, "begin");
+      hipLaunchKernelGGL(k_colfct, dim3(blocks_a(a)), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+      mark(h, "colfct");
+      if (h->src_from_prefetch) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+        h->src_from_prefetch = false;
+      }
+      hipLaunchKernelGGL(k_colupd, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
     }
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
@@ -901,15 +924,14 @@ static int launch_convect(uvic_gpu *h) {
     mark(h, "convect");
   } else {
     const WetCols w = wet_range(h, h->ctx.js, h->ctx.je);
-    if (h->ts_ahead) {      // issued on the T,S side stream by launch_transport
-      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
-      h->ts_ahead = false;
-    } else {
+    const bool fused = h->ts_ahead;   // T,S walk on the side stream, replay inside pass B (launch_transport): all done
+    h->ts_ahead = false;
+    if (!fused) {
       if (w.count > 0)
         hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx, w);
       mark(h, "convect_ts");
     }
-    if (h->d.nt > 2) {
+    if (h->d.nt > 2 && !fused) {
       const long long n = (long long)w.count * (h->d.nt - 2);
       if (n > 0) hipLaunchKernelGGL(k_convect_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx, w);
       mark(h, "convect_apply");
@@ -1222,6 +1244,7 @@ extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
   HIPCHK(hipStreamSynchronize(h->side2));
+  HIPCHK(hipStreamSynchronize(h->side_ts));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1233,6 +1256,7 @@ static void profile_reset(uvic_gpu *h) {
 static int profile_collect(uvic_gpu *h, int max_kernels, const char **names, double *mean_ms, int *nkernels) {
   for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
   HIPCHK(hipStreamSynchronize(h->side2));
+  HIPCHK(hipStreamSynchronize(h->side_ts));
   HIPCHK(hipStreamSynchronize(h->stream));
   std::vector<KernelStat> st;
   for (int q = 0; q < 5; ++q)

@@ -274,17 +274,17 @@ class TimeLoop:
         mixing = self._mixing(self.itt)
         m.set_mixing(mixing)
         m.set_params(c2dtts=self.dtts if mixing else 2.0 * self.dtts)
-        # the look-ahead chains of the next step are queued first: they only wait for the end of the previous step,
-        # and the T,S side work of this step (queued by step_async on the isopyc stream) must come after them
-        if self.prefetch and not self._mixing(self.itt + 1):
-            if not m.params.diff_cbt_has_k33:
-                m.prefetch_isopyc()
-            if m.has_mobi:
-                m.prefetch_sources(2.0 * self.dtts)
         if self.shard is not None:
             self.shard.step(m)
         else:
             m.step_async()
+        # the look-ahead chains of the next step wait only for the end of the previous step; they are queued after
+        # this step so that its T,S passes (first on the isopyc stream) are not held up behind them
+        if self.prefetch and not self._mixing(self.itt + 1):
+            if m.has_mobi:
+                m.prefetch_sources(2.0 * self.dtts)
+            if not m.params.diff_cbt_has_k33:
+                m.prefetch_isopyc()
         m.rotate()
         if mixing:
             m.set_mixing(False)
