@@ -114,11 +114,16 @@ extern "C" int emu_filt(const uvic_ctx *cp, double pi, int jfrst, int jft0, int 
   return (int)fs.items.size();
 }
 
+// 0: the carbonate solve evaluates the reference's expression (bit-exact against the oracle); 1: the form the
+// device uses by default, with shared reciprocals (agrees to rounding)
+static int g_carb_shared = 0;
+extern "C" void emu_set_carb_shared(int on) { g_carb_shared = on; }
 // MOBI column kernel on the host: same source as the GPU kernel, libm instead of ocml
 extern "C" void emu_mobi(const uvic_ctx *cp, const uvic_mobi_params *P, const uvic_mobi_forcing *F) {
   const uvic_ctx &c = *cp;
   mobi_dev M;
   M.P = P;
+  M.carb_shared = g_carb_shared;
   M.tlat = F->tlat; M.dnswr = F->dnswr; M.aice = F->aice; M.hice = F->hice; M.hsno = F->hsno;
   M.sg_bathy = F->sg_bathy; M.fe_atmdep = F->fe_atmdep; M.fe_hydr = F->fe_hydr;
   M.pi = F->pi; M.radian = F->radian; M.relyr = F->relyr; M.co2ccn = F->co2ccn;
@@ -163,6 +168,7 @@ extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, con
   const uvic_ctx &c = *cp;
   mobi_dev M;
   M.P = P;
+  M.carb_shared = g_carb_shared;
   M.tlat = F->tlat; M.dnswr = F->dnswr; M.aice = F->aice; M.hice = F->hice; M.hsno = F->hsno;
   M.sg_bathy = F->sg_bathy; M.fe_atmdep = F->fe_atmdep; M.fe_hydr = F->fe_hydr;
   M.pi = F->pi; M.radian = F->radian; M.relyr = F->relyr; M.co2ccn = F->co2ccn;

@@ -98,6 +98,12 @@ def test_mobi_kernel_source_under_host_emulation_equals_oracle(dims):
     em.a["src"][...] = -1.0
     got = em.mobi(prm, team=True)
     assert np.array_equal(got[1:-1, :, 1:-1], src_o[1:-1, :, 1:-1])   # columns 2..imt-1, rows 2..jmt-1 are computed
+    # the carbonate solve with shared reciprocals (what the device runs by default): same Newton path, values to rounding
+    em.a["src"][...] = -1.0
+    got = em.mobi(prm, carb_shared=True)
+    for s in range(src_o.shape[-1]):
+        scale = np.abs(src_o[..., s]).max()
+        assert np.abs(got[1:-1, :, 1:-1, s] - src_o[1:-1, :, 1:-1, s]).max() <= 1e-13 * scale, s
 
 
 MOBI_RTOL = 1e-11  # per source slot, relative to the slot max; measured on MI355X: 4.7e-13 (102x102x19), 5.8e-15 (14x14x6)

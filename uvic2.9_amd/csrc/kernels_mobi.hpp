@@ -59,6 +59,9 @@ struct mobi_dev {
   //   col  2 x (imt,jmt)            calcite production of the column (prca, prca13)
   double *pre, *aux, *col;
   mobi_step S;
+  // 1: the alkalinity function of the carbonate solve shares reciprocals (ta_iter_shared); 0: the reference's
+  // expression, division by division (bit-exact on the host against the oracle)
+  int carb_shared;
 };
 enum { MP_BCT, MP_BCTZ, MP_NUD, MP_AOUT, MP_O2F, MP_AVEJ, MP_AVEJD, MP_AC13B, MP_COUNT };
 enum { MA_EXPO, MA_EXPOP, MA_RN15, MA_RC13, MA_CALPRO, MA_NFIX, MA_COUNT };
@@ -112,8 +115,52 @@ UVIC_DEV void ta_iter_SWS(const carb_t *q, double x, double *fn, double *df) {
         ft * (1.0 / sq(1.0 + q->kf / (x / c))) * (q->kf * c / x2) - pt * x2 * (3.0 * a - x * da) / a2;
 }
 
+// 1/y for y well inside the normal range: v_rcp_f64 and two Newton steps on the device (5 instructions; the IEEE
+// division sequence takes 12, four of them for range handling that cannot trigger here)
+UVIC_DEV double recip_nr(double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(y);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+#else
+  return 1.0 / y;
+#endif
+}
+// The same function and derivative as ta_iter_SWS with every denominator inverted once: 7 reciprocals per
+// evaluation instead of 27 divisions (the solve evaluates it ~13 times per cell; divisions were more than half of
+// mobi_pre's instructions).  x in [1e-10, 1e-6], every denominator between 1e-36 and 1e3: no range handling needed.
+// Terms keep the reference's order, so values differ from ta_iter_SWS by a few ulp of the largest term.
+typedef struct {
+  double rc, ckx_s, ckx_f, rkb, rksi;   // 1/c, ks*c, kf*c, 1/kb, 1/ksi: the same for every evaluation of a cell
+} carb_inv_t;
+UVIC_DEV void ta_iter_shared(const carb_t *q, const carb_inv_t *v, double x, double *fn, double *df) {
+  const double x2 = x * x, x3 = x2 * x;
+  const double k12 = q->k1 * q->k2, k12p = q->k1p * q->k2p, k123p = k12p * q->k3p;
+  const double a = x3 + q->k1p * x2 + k12p * x + k123p;
+  const double da = 3.0 * x2 + 2.0 * q->k1p * x + k12p;
+  const double b = x2 + q->k1 * x + k12;
+  const double db = 2.0 * x + q->k1;
+  const double dic = q->dic, pt = q->pt, bt = q->bt, st = q->st, ft = q->ft, sit = q->sit;
+  const double rx = recip_nr(x), rx2 = rx * rx;
+  const double ra = recip_nr(a), ra2 = ra * ra, rb = recip_nr(b), rb2 = rb * rb;
+  const double rub = recip_nr(1.0 + x * v->rkb), rus = recip_nr(1.0 + x * v->rksi);
+  const double rvs = recip_nr(1.0 + v->ckx_s * rx), rvf = recip_nr(1.0 + v->ckx_f * rx);
+  *fn = q->k1 * x * dic * rb + 2.0 * dic * k12 * rb + bt * rub + q->kw * rx + pt * k12p * x * ra + 2.0 * pt * k123p * ra +
+        sit * rus - x * v->rc - st * rvs - ft * rvf - pt * x3 * ra - q->ta;
+  *df = ((q->k1 * dic * b) - q->k1 * x * dic * db) * rb2 - 2.0 * dic * k12 * db * rb2 - bt * v->rkb * (rub * rub) - q->kw * rx2 +
+        (pt * k12p * (a - x * da)) * ra2 - 2.0 * pt * k123p * da * ra2 - sit * v->rksi * (rus * rus) - v->rc -
+        st * (rvs * rvs) * (v->ckx_s * rx2) - ft * (rvf * rvf) * (v->ckx_f * rx2) - pt * x2 * (3.0 * a - x * da) * ra2;
+}
+
 /* co2calc.F:401-453: bracketed Newton (Numerical Recipes rtsafe) */
-UVIC_DEV double drtsafe(const carb_t *q, double x1, double x2, double xacc) {
+template <bool SHARED>
+UVIC_DEV double drtsafe_t(const carb_t *q, double x1, double x2, double xacc) {
+  carb_inv_t v;
+  if (SHARED) {
+    const double c = 1.0 + q->st / q->ks + q->ft / q->kf;
+    v.rc = 1.0 / c; v.ckx_s = q->ks * c; v.ckx_f = q->kf * c; v.rkb = 1.0 / q->kb; v.rksi = 1.0 / q->ksi;
+  }
+#define ta_iter_SWS(q, x, f, d) do { if (SHARED) ta_iter_shared(q, &v, x, f, d); else (ta_iter_SWS)(q, x, f, d); } while (0)
   const int maxit = 100;
   double fl, fh, df, f, xl, xh, swap, r, dxold, dx, temp;
   ta_iter_SWS(q, x1, &fl, &df);
@@ -151,12 +198,16 @@ UVIC_DEV double drtsafe(const carb_t *q, double x1, double x2, double xacc) {
   }
   (void)fl; (void)fh;
   return r;
+#undef ta_iter_SWS
+}
+UVIC_DEV double drtsafe(const carb_t *q, double x1, double x2, double xacc, int shared) {
+  return shared ? drtsafe_t<true>(q, x1, x2, xacc) : drtsafe_t<false>(q, x1, x2, xacc);
 }
 
 /* co2calc.F:1-399; only the outputs mobi_driver uses are returned */
 UVIC_DEV void mobi_co2calc_SWS(double t, double s, double dic_in, double ta_in, double co2_in, double atmpres, double depth,
                      double *ph, double *co2star_o, double *dco2star_o, double *pCO2_o, double *dpco2_o, double *CO3_o,
-                     double *Omega_c, double *Omega_a) {
+                     double *Omega_c, double *Omega_a, int carb_shared = 0) {
   carb_t q;
   const double phhi = 6., phlo = 10.;
   const double sit_in = 7.6875e-03, pt_in = 0.5125e-3;
@@ -226,7 +277,7 @@ UVIC_DEV void mobi_co2calc_SWS(double t, double s, double dic_in, double ta_in, 
   const double x1 = pow(10.0, -phhi);
   const double x2 = pow(10.0, -phlo);
   const double xacc = 1.e-10;
-  const double hSWS = drtsafe(&q, x1, x2, xacc);
+  const double hSWS = drtsafe(&q, x1, x2, xacc, carb_shared);
   const double hSWS2 = hSWS * hSWS;
   double co2star = q.dic * hSWS2 / (hSWS2 + q.k1 * hSWS + q.k1 * q.k2);
   const double co2starair = co2 * ff * atmpres;
@@ -732,7 +783,7 @@ UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, 
     const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
     double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
     mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3,
-                     &Omega_c, &Omega_a);
+                     &Omega_c, &Omega_a, M.carb_shared);
     const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
     const double ac13_aq_POC = -0.017 * log10(dmin(dmax(co2star * 1000., 2.), 74.)) + 1.0034;
     PRE(MP_AC13B) = ac13_aq_POC / ac13_DIC_aq;
@@ -1036,6 +1087,8 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
   dev->sg_bathy = st->f[5]; dev->fe_atmdep = st->f[6]; dev->fe_hydr = st->f[7];
   mobi_set_work(dev, st->work, imt, jmt, km);
   dev->pi = hf->pi; dev->radian = hf->radian; dev->relyr = hf->relyr; dev->co2ccn = hf->co2ccn;
+  dev->carb_shared = 1;
+  if (const char *e = getenv("UVIC_CARB_SHARED")) dev->carb_shared = atoi(e) != 0;
   return 0;
 }
 #endif
