@@ -9,8 +9,9 @@ set has them, FCT advection, isopycnal diffusion, explicit update, implicit
 vertical solve, convection) and the time-level rotation, with every input
 already resident in HBM.  Metric (BASELINE.json): imt*jmt*km*nt cell updates
 per completed step / wall time, whole job.  N > 1 (launched by
-torch.distributed.run, one rank per GPU, RCCL) shards the tracer index across
-ranks and all-gathers t(tau+1) after the step.
+torch.distributed.run, one rank per GPU, RCCL): latitude slabs with a 2-row halo
+exchange of t(tau+1) per step when every rank gets at least 12 rows, else tracer-index
+shards with an all-gather (--decomp overrides).
 """
 from __future__ import annotations
 
@@ -240,10 +241,13 @@ def main():
         prof = live
         names = [k for k in prof if kernel_alg_bytes(k, nt, nsrc)]
         dom = max(names, key=lambda k: prof[k])
-        local_units = imt * jmt * km * shard.nt_local
+        # tracers of the dominant launch: when T and S take their passes first on the side stream (colfct_ts, colupd_ts:
+        # single rank and latitude slabs), the main-stream launch of colfct / colupd holds the other nt-2
+        nt_launch = shard.nt_local - 2 if "colfct_ts" in prof else shard.nt_local
+        local_units = imt * jmt * km * nt_launch
         if decomp == "slab":
-            local_units = imt * (shard.je - shard.js + 1 + 2) * km * nt     # pass A also does one row beyond each side
-        ach = kernel_alg_bytes(dom, nt, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
+            local_units = imt * (shard.je - shard.js + 1 + 2) * km * nt_launch     # pass A also does one row beyond each side
+        ach = kernel_alg_bytes(dom, nt_launch, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
         step_gbs = b_alg(nt, nsrc) * value / 1e9
         traffic, traffic_src = pmc_traffic(dom, world == 1 and a.cfg == "c30" and a.grid == "102x102x19")
         out = {
@@ -259,12 +263,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "dominant HBM-side (transport) kernel; kernel_ms are HIP-event means over a second, instrumented "
-                                 "pass of the same K steps (ms_per_step_instrumented), where the MOBI kernels of the next "
-                                 "step run beside the transport kernels on the side stream",
+                                 "pass of the same K steps (ms_per_step_instrumented), where the look-ahead chains (MOBI, isopyc) "
+                                 "and the T,S passes run beside the main-stream kernels on the side streams; "
+                                 "kernel_ms_isolated: the unfused kernels one after the other on one stream",
                          "kernel_ms": {k: round(v, 5) for k, v in prof.items()},
                          "kernel_ms_isolated": {k: round(v, 5) for k, v in iso.items()},
                          "next_rows_kernel_ms": nxt,
-                         "alg_bytes_per_cell_update": kernel_alg_bytes(dom, nt, nsrc)},
+                         "tracers_in_launch": nt_launch,
+                         "alg_bytes_per_cell_update": kernel_alg_bytes(dom, nt_launch, nsrc)},
             "step_hbm": {"alg_bytes_per_cell_update": b_alg(nt, nsrc), "achieved_GBs": step_gbs,
                          "frac_of_peak": step_gbs / HBM_PEAK_GBS},
         }

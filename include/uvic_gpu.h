@@ -214,6 +214,15 @@ int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);
+/* latitude-slab decomposition (uvic_gpu_set_shard js..je): the two outermost owned rows of t(tau+1) of every tracer
+ * go to the neighbour's halo after each step (reach of the FCT stencil, u09/mom/tracer_adv_flx.F:553-555).  The library
+ * packs them into contiguous staging buffers and unpacks what was received, both on its main stream; the caller moves
+ * the buffers between ranks (RCCL send/recv on that stream).  which: 0 send south, 1 send north, 2 receive south,
+ * 3 receive north; each holds uvic_gpu_halo_elems doubles, laid out (nt, 2, imt*km). */
+int64_t uvic_gpu_halo_elems(uvic_gpu *h);
+void *uvic_gpu_halo_buffer(uvic_gpu *h, int which);
+int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north);
+int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north);
 
 /* ---- producers of the step's shared inputs ------------------------------
  * replaces `call adv_vel (joff, js, je, is, ie)` (source/mom/mom.F:332; source/mom/adv_vel.F:63-131, the

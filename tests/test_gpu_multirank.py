@@ -94,3 +94,62 @@ def test_four_latitude_slabs_full_grid(tmp_path):
         js, je = slab_rows(102, 4, r)
         got = np.load(f"{out}.{r}.npy")
         assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
+
+
+def _rccl_worker(rank, port, out_path):
+    """The RCCL code paths themselves (the rehearsals above use gloo): one rank, backend "nccl"."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from uvic29_amd import OPTION_SETS, synthetic
+    from uvic29_amd.parallel import HALO, SlabShard, TracerShard
+    from uvic29_amd.tracer import TracerModel
+    cfg = OPTION_SETS["p2"]
+    ocean = synthetic.make_ocean(cfg, 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    m = TracerModel(14, 14, 6, cfg.nt, cfg.nsrc, cfg.ntnpzd, device=0)
+    m.load_ocean(ocean, to, so, c)
+    m.set_params(c2dtts=2.0 * ocean.params.dtts)
+    m.step_async()
+    m.sync()
+    before = m.download("t_taup1").copy()
+    # in-place all-gather on the library's stream through an ExternalStream: the identity for one rank
+    ts = TracerShard(cfg.nt, 1, 0)
+    ts.gather(m)
+    m.sync()
+    ok_gather = np.array_equal(m.download("t_taup1"), before)
+    # batched send/recv of the packed halo rows: the slab is rows 5..8 and the rank is its own southern and northern
+    # neighbour, so its southern rows 5,6 come back as "received from the south" into rows 3,4 and rows 7,8 into 9,10
+    sl = SlabShard(14, 1, 0)
+    sl.js, sl.je = 5, 8
+    sl.apply(m)
+    import torch as _t
+    sl._stream = _t.cuda.ExternalStream(m.lib.uvic_gpu_stream(m.h), device="cuda:0")
+    with _t.cuda.stream(sl._stream):
+        sl.exchange(m, "t_taup1", peers=(0, 0))
+    m.sync()
+    after = m.download("t_taup1")
+    want = before.copy()
+    # each rank sends [south block, north block] to (south, north) and receives in the same order from them; being both
+    # neighbours itself, what it sent south (rows 5,6) is what arrives "from the south" and likewise for the north
+    want[:, :, 2:4] = before[:, :, 4:6]
+    want[:, :, 8:10] = before[:, :, 6:8]
+    ok_p2p = np.array_equal(after, want)
+    np.save(out_path, np.array([ok_gather, ok_p2p]))
+    m.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_paths_single_rank(tmp_path):
+    """all_gather_into_tensor in place on the device buffer and batch_isend_irecv of row blocks through RCCL itself,
+    on the library's own stream (what bench.py --gpus N runs; N > 1 needs N GPUs, so one rank here)."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rccl.npy")
+    mp.spawn(_rccl_worker, args=(29551, out), nprocs=1, join=True)
+    ok = np.load(out)
+    assert ok[0], "in-place all-gather changed the buffer"
+    assert ok[1], "row blocks sent through RCCL did not arrive where expected"

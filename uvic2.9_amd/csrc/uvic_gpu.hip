@@ -265,6 +265,18 @@ __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m,
   mobi_column_kernel(c, m, i, j);
 }
 
+// latitude-slab halo: `nrow` rows j0.. of every tracer of `t` <-> a staging buffer laid out (nt, nrow, imt*km);
+// dir 0 packs (t -> staging), 1 unpacks (staging -> t).  One launch moves what the exchange sends or receives on a side.
+__global__ void __launch_bounds__(256) k_halo_rows(double *t, double *stage, int rowlen, int jmt, int nt, int j0, int nrow, int dir) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)nrow * rowlen;
+  if (gid >= per * nt) return;
+  const int n = (int)(gid / per);
+  const long long q = gid % per;   // (row - j0) * rowlen + offset within the row: rows are adjacent in t as well
+  double *cell = t + ((long long)n * jmt + (j0 - 1)) * rowlen + q;
+  if (dir == 0) stage[gid] = *cell; else *cell = stage[gid];
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -345,6 +357,8 @@ struct uvic_gpu {
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
   int *wet_dev;
   std::vector<int> wet_row_start;
+  // latitude-slab halo staging (uvic_gpu_halo_*): send south/north, receive south/north, each UVIC_HALO rows of every tracer
+  double *halo[4];
   // source buffers known to hold zeros on land (MOBI writes ocean columns only): see src_clean()
   std::vector<void *> src_zeroed;
   uvic_ctx ctx;
@@ -467,6 +481,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->have_vmix = false;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
   h->wet_dev = nullptr;
+  for (int q = 0; q < 4; ++q) h->halo[q] = nullptr;
   h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
@@ -589,6 +604,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->coef);
   (void)hipFree(h->rpm);
   (void)hipFree(h->wet_dev);
+  for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
@@ -1214,6 +1230,46 @@ extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
 extern "C" int uvic_gpu_convect_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   return launch_convect(h);
+}
+// -- latitude-slab halo rows of t(tau+1): staging buffers the exchange sends from and receives into
+#define UVIC_HALO 2
+extern "C" int64_t uvic_gpu_halo_elems(uvic_gpu *h) {
+  return h ? (int64_t)UVIC_HALO * h->d.imt * h->d.km * h->d.nt : -1;
+}
+extern "C" void *uvic_gpu_halo_buffer(uvic_gpu *h, int which) {   // 0 send south, 1 send north, 2 receive south, 3 receive north
+  if (!h || which < 0 || which > 3) return nullptr;
+  if (!h->halo[which]) {
+    if (hipSetDevice(h->device) != hipSuccess) return nullptr;
+    const size_t bytes = (size_t)uvic_gpu_halo_elems(h) * 8;
+    if (hipMalloc((void **)&h->halo[which], bytes) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(h->halo[which], 0, bytes, h->stream);
+  }
+  return h->halo[which];
+}
+static int halo_move(uvic_gpu *h, int which, int j0, int dir) {
+  double *stage = (double *)uvic_gpu_halo_buffer(h, which);
+  if (!stage) return fail_msg("uvic_gpu_halo: no staging buffer");
+  if (j0 < 1 || j0 + UVIC_HALO - 1 > h->d.jmt) return fail_msg("uvic_gpu_halo: rows outside 1..jmt");
+  const int rowlen = h->d.imt * h->d.km;
+  const long long n = (long long)UVIC_HALO * rowlen * h->d.nt;
+  hipLaunchKernelGGL(k_halo_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (double *)h->buf[UVIC_F_T_TAUP1], stage,
+                     rowlen, h->d.jmt, h->d.nt, j0, UVIC_HALO, dir);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// pack the outermost owned rows of t(tau+1) (the slab of uvic_gpu_set_shard) into the send buffers, on the main stream
+extern "C" int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north) {
+  if (!h) return fail_msg("null handle");
+  if (south) if (int rc = halo_move(h, 0, h->ctx.js, 0)) return rc;
+  if (north) if (int rc = halo_move(h, 1, h->ctx.je - UVIC_HALO + 1, 0)) return rc;
+  return 0;
+}
+// ... and the received rows into the halo rows beyond the slab
+extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
+  if (!h) return fail_msg("null handle");
+  if (south) if (int rc = halo_move(h, 2, h->ctx.js - UVIC_HALO, 1)) return rc;
+  if (north) if (int rc = halo_move(h, 3, h->ctx.je + 1, 1)) return rc;
+  return 0;
 }
 extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");

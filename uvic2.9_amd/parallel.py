@@ -80,6 +80,15 @@ class TracerShard:
         if self._stream is None:
             self._stream = torch.cuda.ExternalStream(model.lib.uvic_gpu_stream(model.h), device=f"cuda:{model.device}")
         check(model.lib.uvic_gpu_step_pre_async(model.h), "step_pre_async")
+        self.gather(model)
+        check(model.lib.uvic_gpu_convect_async(model.h), "convect_async")
+
+    def gather(self, model):
+        """All-gather of t(:,:,:,slice,tau+1), in place on the device buffer, on the library's stream."""
+        import torch
+        import torch.distributed as dist
+        if self._stream is None:
+            self._stream = torch.cuda.ExternalStream(model.lib.uvic_gpu_stream(model.h), device=f"cuda:{model.device}")
         full = self._tensor(model, "t_taup1")
         per = full.numel() // self.world
         mine = full[self.rank * per:(self.rank + 1) * per]
@@ -93,7 +102,6 @@ class TracerShard:
                 host = torch.empty(full.numel(), dtype=full.dtype)
                 dist.all_gather_into_tensor(host, mine.cpu())
                 full.copy_(host)
-        check(model.lib.uvic_gpu_convect_async(model.h), "convect_async")
 
 
 HALO = 2   # rows: FCT needs R+-Y of rows r+-1, each of which needs t of its own r+-1
@@ -133,44 +141,57 @@ class SlabShard:
             self._views[ptr] = flat.view(model.nt, model.jmt, model.imt * model.km)
         return self._views[ptr]
 
-    def exchange(self, model, name="t_taup1"):
-        """Send the outermost HALO owned rows to the neighbours, receive theirs into the halo rows."""
+    def _staging(self, model):
+        """The library's four staging buffers (send south/north, receive south/north) as torch views, made once."""
+        import torch
+        if not self._views.get("halo"):
+            n = int(model.lib.uvic_gpu_halo_elems(model.h))
+            bufs = []
+            for which in range(4):
+                ptr = model.lib.uvic_gpu_halo_buffer(model.h, which)
+                if not ptr:
+                    raise RuntimeError("uvic_gpu_halo_buffer: no staging buffer")
+                bufs.append(torch.as_tensor(_DevArray(ptr, n), device=f"cuda:{model.device}"))
+            self._views["halo"] = bufs
+        return self._views["halo"]
+
+    def exchange(self, model, name="t_taup1", peers=None):
+        """Send the outermost HALO owned rows of t(tau+1) to the neighbours, receive theirs into the halo rows.
+        The library packs and unpacks (one kernel per side, on its stream); only the transfer itself goes through
+        torch.distributed, so a step costs one batched send/recv and no allocation.  `peers` = (south, north) ranks
+        overrides the neighbour pattern (tests: a rank may name itself)."""
         import torch
         import torch.distributed as dist
-        t = self._rows(model, name)
-        js, je = self.js - 1, self.je - 1          # 0-based
-        south, north = self.rank - 1, self.rank + 1
-        jobs = []                                   # (peer, send rows slice, recv rows slice)
-        if south >= 0:
-            jobs.append((south, slice(js, js + HALO), slice(js - HALO, js)))
-        if north < self.world:
-            jobs.append((north, slice(je - HALO + 1, je + 1), slice(je + 1, je + 1 + HALO)))
-        if not jobs:
+        from .capi import check
+        assert name == "t_taup1"
+        south, north = (self.rank - 1, self.rank + 1) if peers is None else peers
+        has_s = south is not None and 0 <= south < max(self.world, 1)
+        has_n = north is not None and 0 <= north < max(self.world, 1)
+        if not (has_s or has_n):
             return
-        nccl = dist.get_backend() == "nccl"
-        sends = [t[:, s, :].contiguous() for _, s, _ in jobs]
-        recvs = [torch.empty_like(b) for b in sends]
-        if nccl:
+        send_s, send_n, recv_s, recv_n = self._staging(model)
+        check(model.lib.uvic_gpu_halo_pack(model.h, int(has_s), int(has_n)), "halo_pack")
+        pairs = ([(south, send_s, recv_s)] if has_s else []) + ([(north, send_n, recv_n)] if has_n else [])
+        if dist.get_backend() == "nccl":
             ops = []
-            for (peer, _, _), sb, rb in zip(jobs, sends, recvs):
+            for peer, sb, rb in pairs:
                 ops.append(dist.P2POp(dist.isend, sb, peer))
                 ops.append(dist.P2POp(dist.irecv, rb, peer))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         else:                                       # rehearsal backend: staged through the host
             torch.cuda.current_stream().synchronize()
-            hs = [b.cpu() for b in sends]
+            hs = [sb.cpu() for _, sb, _ in pairs]
             hr = [torch.empty_like(b) for b in hs]
             ws = []
-            for (peer, _, _), sb, rb in zip(jobs, hs, hr):
+            for (peer, _, _), sb, rb in zip(pairs, hs, hr):
                 ws.append(dist.isend(sb, peer))
                 ws.append(dist.irecv(rb, peer))
             for w in ws:
                 w.wait()
-            for rb, hb in zip(recvs, hr):
+            for (_, _, rb), hb in zip(pairs, hr):
                 rb.copy_(hb)
-        for (_, _, r), rb in zip(jobs, recvs):
-            t[:, r, :].copy_(rb)
+        check(model.lib.uvic_gpu_halo_unpack(model.h, int(has_s), int(has_n)), "halo_unpack")
 
     def step(self, model):
         """One device-resident step of the slab and the halo exchange (no host sync with RCCL)."""
