@@ -15,10 +15,18 @@ base = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof/pmc"
 
 def load(d):
     fs = glob.glob(f"{base}/{d}/*/*_counter_collection.csv")
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    # a kernel launched with several grids in one step (pass A and B run once for T,S on the side stream and once for
+    # the other tracers on the main stream) is listed per grid: the plain name is the largest grid, the others "name#<grid>"
+    rows = []
     for f in fs:
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows.append((r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+    biggest = {}
+    for name, grid, _, _ in rows:
+        biggest[name] = max(biggest.get(name, 0), grid)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name, grid, cname, val in rows:
+        agg[name if grid == biggest[name] else f"{name}#{grid}"][cname].append(val)
     return agg
 
 

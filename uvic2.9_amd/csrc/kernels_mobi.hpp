@@ -126,6 +126,25 @@ UVIC_DEV double recip_nr(double y) {
   return 1.0 / y;
 #endif
 }
+// Quotients of the ecosystem sub-step whose denominator is a clamped pool (>= trcmin), a pool plus a positive
+// half-saturation constant, or 1 + a positive ratio: finite, far from the ends of the exponent range, never zero.  On
+// the device they skip the range handling of the IEEE sequence (8 instructions instead of 12, on the dependent chain
+// of every sub-step); the host build divides, so that the emulation stays bit-identical to the oracle.  Quotients whose
+// denominator is a difference of pools (it may vanish: the reference relies on +-inf being clamped) keep `/`.
+UVIC_DEV double div_safe(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r = recip_nr(y);
+  const double q = x * r;
+  return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+#else
+  return x / y;
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UV_DIVC(x, cst) ((x) * (1.0 / (cst)))   /* division by a literal: its reciprocal is folded at compile time */
+#else
+#define UV_DIVC(x, cst) ((x) / (cst))
+#endif
 // The same function and derivative as ta_iter_SWS with every denominator inverted once: 7 reciprocals per
 // evaluation instead of 27 divisions (the solve evaluates it ~13 times per cell; divisions were more than half of
 // mobi_pre's instructions).  x in [1e-10, 1e-6], every denominator between 1e-36 and 1e3: no range handling needed.
@@ -312,7 +331,7 @@ typedef struct {
 } src_out_t;
 
 /* Rayleigh-type fractionation factor: r + eps*(1-u)/u*log(1-u)*r/1000 (e.g. mobi.F:2589-2600) */
-UVIC_DEV double rayleigh(double r, double eps, double u) { return r + eps * (1 - u) / u * log(1 - u) * r / 1000.; }
+UVIC_DEV double rayleigh(double r, double eps, double u) { return r + UV_DIVC(div_safe(eps * (1 - u), u) * log(1 - u) * r, 1000.); }   /* u in [trcmin, 0.999] */
 UVIC_DEV double clamp_ratio(double r, double hi, double lo) {
   r = dmin(r, hi);
   r = dmax(r, lo);
@@ -419,19 +438,19 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
     if (ROLE(0)) {  // ---- growth and nutrient limitation (mobi.F:2150-2236), 15N assimilation (:2589-2600)
       const double p1 = dmin(biophyt, P->pmax);
       const double p2 = dmax(0.0, biophyt - P->pmax);
-      const double k1n = (P->knmin * p1 + P->knmax * p2) / (p1 + p2);
+      const double k1n = div_safe(P->knmin * p1 + P->knmax * p2, p1 + p2);
       const double k1p_P = k1n * ptn_P;
-      const double kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
-      const double deffe = biodfe / (kfevar + biodfe);
+      const double kfevar = div_safe(P->kfemin * p1 + P->kfemax * p2, p1 + p2);
+      const double deffe = div_safe(biodfe, kfevar + biodfe);
       const double jmax = P->abio_P * bct * deffe;
-      const double deffe_D = biodfe / (P->kfe_D + biodfe);
+      const double deffe_D = div_safe(biodfe, P->kfe_D + biodfe);
       const double jmax_D = dmax(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
-      const double limP_dop = P->hdop * biodop / (k1p_P + biodop);
-      const double limP_po4 = biopo4 / (k1p_P + biopo4);
+      const double limP_dop = div_safe(P->hdop * biodop, k1p_P + biodop);
+      const double limP_po4 = div_safe(biopo4, k1p_P + biopo4);
       const double dopupt_flag = flag01(limP_dop - limP_po4);
       const double limP = limP_dop * dopupt_flag + limP_po4 * (1. - dopupt_flag);
       double u_P = dmin(avej, jmax * limP);
-      u_P = dmin(u_P, jmax * biono3 / (k1n + biono3));
+      u_P = dmin(u_P, div_safe(jmax * biono3, k1n + biono3));
       const double u_D = dmin(avej_D, jmax_D * limP);
       const double dopupt_D_flag = dopupt_flag;
       npp = u_P * biophyt;
@@ -442,17 +461,17 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
       npp = npp * no3flag * (dopupt_flag * dopflag + (1. - dopupt_flag) * po4flag) * din15flag;
       npp_D = npp_D * (dopupt_D_flag * dopflag + (1. - dopupt_D_flag) * po4flag) * din15flag;
       no3upt_D = no3upt_D * no3flag * din15flag;
-      double uno3 = npp * dtbio / biono3;
+      double uno3 = div_safe(npp * dtbio, biono3);
       uno3 = dmin(uno3, 0.999);
       uno3 = dmax(uno3, UV_TRCMIN);
       const double rno3 = clamp_ratio(biodin15 / (biono3 - biodin15), 2 * UV_RN15STD, UV_RN15STD / 2.);
       const double bassim = rayleigh(rno3, P->eps_assim, uno3);
-      fcassim = bassim / (1 + bassim);
+      fcassim = div_safe(bassim, 1 + bassim);
     }
     if (ROLE(1)) {  // ---- grazing, mortality, remineralisation, export (mobi.F:2223-2312), 15N recycling
       const double thetaZ = P->zprefP * biophyt + P->zprefDet * biodetr + P->zprefZ * biozoop + P->zprefDiaz * biodiaz + P->kzoo;
-      const double ing_P = P->zprefP / thetaZ, ing_Det = P->zprefDet / thetaZ, ing_Z = P->zprefZ / thetaZ;
-      const double ing_D = P->zprefDiaz / thetaZ;
+      const double ing_P = div_safe(P->zprefP, thetaZ), ing_Det = div_safe(P->zprefDet, thetaZ), ing_Z = div_safe(P->zprefZ, thetaZ);
+      const double ing_D = div_safe(P->zprefDiaz, thetaZ);   /* thetaZ >= kzoo > 0 */
       const double g_D = gmax * ing_D * biodiaz;
       graz_D = g_D * biozoop;
       morpt_D = nupt_D * biodiaz;
@@ -486,18 +505,18 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
       morpt_D = morpt_D * diazflag * diazn15flag;
       morp_D = morp_D * diazflag * diazn15flag;
       recy_don = recy_don * donflag * don15flag;
-      double udon = recy_don * dtbio / biodon;
+      double udon = div_safe(recy_don * dtbio, biodon);
       udon = dmin(udon, 0.999);
       udon = dmax(udon, UV_TRCMIN);
       const double rdon = clamp_ratio(biodon15 / (biodon - biodon15), 2 * UV_RN15STD, UV_RN15STD / 2.);
       const double brecy = rayleigh(rdon, P->eps_recy, udon);
-      fcrecy = brecy / (1 + brecy);
+      fcrecy = div_safe(brecy, 1 + brecy);
     }
     if (ROLE(2)) {  // ---- iron speciation and scavenging, mobi.F:2313-2342
       remife = nud * bct * biodetrfe;
-      const double ligand = dmax(aou_term + pow(biodon, 0.8) / 4.8, 0.5) / 1000.;
+      const double ligand = UV_DIVC(dmax(aou_term + UV_DIVC(pow(biodon, 0.8), 4.8), 0.5), 1000.);
       const double fepa = (1.0 + P->kfeleq * (ligand - biodfe)) * o2flag;
-      const double feprime = ((-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe)) / (2.0 * P->kfeleq)) * o2flag;
+      const double feprime = div_safe(-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe), 2.0 * P->kfeleq) * o2flag;
       feorgads = (P->kfeorg * (pow((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
       fecol = P->kfecol * (feprime * feprime) * o2flag;
       expofe = wwd * biodetrfe;
@@ -508,20 +527,20 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
     }
     if (ROLE(3)) {  // ---- isotope ratios, mobi.F:2601-2695
       const double rzoop = clamp_ratio(biozoopn15 / (biozoop - biozoopn15), 2. * UV_RN15STD, UV_RN15STD / 2.);
-      const double bexcr = rzoop - P->eps_excr * rzoop / 1000.;
-      fcexcr = bexcr / (1 + bexcr);
-      rtphytn15 = clamp_ratio(biophytn15 / biophyt, rn15hi, rn15lo);
-      rtzoopn15 = clamp_ratio(biozoopn15 / biozoop, rn15hi, rn15lo);
-      rtdetrn15 = clamp_ratio(biodetrn15 / biodetr, rn15hi, rn15lo);
-      rtdiazn15 = clamp_ratio(biodiazn15 / biodiaz, rn15hi, rn15lo);
+      const double bexcr = rzoop - UV_DIVC(P->eps_excr * rzoop, 1000.);
+      fcexcr = div_safe(bexcr, 1 + bexcr);
+      rtphytn15 = clamp_ratio(div_safe(biophytn15, biophyt), rn15hi, rn15lo);
+      rtzoopn15 = clamp_ratio(div_safe(biozoopn15, biozoop), rn15hi, rn15lo);
+      rtdetrn15 = clamp_ratio(div_safe(biodetrn15, biodetr), rn15hi, rn15lo);
+      rtdiazn15 = clamp_ratio(div_safe(biodiazn15, biodiaz), rn15hi, rn15lo);
       const double rdic13 = clamp_ratio(biodic13 / (biodic - biodic13), 2. * UV_RC13STD, 0.5 * UV_RC13STD);
       const double bc13npp = ac13b * rdic13;
-      fcnpp = bc13npp / (1 + bc13npp);
-      rtphytc13 = clamp_ratio(biophytc13 / (biophyt * redctn), rc13hi, rc13lo);
-      rtzoopc13 = clamp_ratio(biozoopc13 / (biozoop * redctn), rc13hi, rc13lo);
-      rtdetrc13 = clamp_ratio(biodetrc13 / (biodetr * redctn), rc13hi, rc13lo);
-      rtdoc13 = clamp_ratio(biodoc13 / (biodon * redctn), rc13hi, rc13lo);
-      rtdiazc13 = clamp_ratio(biodiazc13 / (biodiaz * redctn), rc13hi, rc13lo);
+      fcnpp = div_safe(bc13npp, 1 + bc13npp);
+      rtphytc13 = clamp_ratio(div_safe(biophytc13, biophyt * redctn), rc13hi, rc13lo);
+      rtzoopc13 = clamp_ratio(div_safe(biozoopc13, biozoop * redctn), rc13hi, rc13lo);
+      rtdetrc13 = clamp_ratio(div_safe(biodetrc13, biodetr * redctn), rc13hi, rc13lo);
+      rtdoc13 = clamp_ratio(div_safe(biodoc13, biodon * redctn), rc13hi, rc13lo);
+      rtdiazc13 = clamp_ratio(div_safe(biodiazc13, biodiaz * redctn), rc13hi, rc13lo);
     }
     TQ(0)
     if (Team::team) {  // publish own group, one barrier, fetch the other three

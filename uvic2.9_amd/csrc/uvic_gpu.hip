@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   coef_bv_cell(c, cf, i, k, j);
 }
-__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+__device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
@@ -134,8 +134,10 @@ __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
   colfct_wave(c, cf, S, r, n1, i0, i1);
 }
-__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body(c, cf, S, g); }
+// the same passes for T and S alone on the side stream: own names, so that a profile tells the two launches apart
+__global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body(c, cf, S, g); }
+__device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, const ColGrid &g, double *lds) {
   const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
   const int blk = xcd_remap(blockIdx.x, nblk);
   int r, n1, i0, i1;
@@ -143,6 +145,14 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, 
   if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, r, n1, i0, i1)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
   colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, r, n1, i0, i1, g.fuse_convect);
+}
+__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colupd_body(c, S, g, lds);
+}
+__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_ts(const uvic_ctx c, const double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colupd_body(c, S, g, lds);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -385,6 +395,7 @@ struct uvic_gpu {
   hipStream_t side2;
   // (T and S finish pass B and the convective T,S walk on side2 as well, beside pass B of the other tracers: the
   // device offers four hardware queues, and a fifth stream would share one with another and wait behind its barriers)
+  bool iso_waited;    // this step's T,S-derived fields came from the look-ahead chain (ev_iso_ready)
   bool step_begun;    // ev_step_begin of the current step is recorded (uvic_gpu_rotate ends the step)
   hipStream_t side_ts; // the T,S passes: side2, or a stream of its own when the runtime has more than four hardware queues
   hipEvent_t ev_fct_done, ev_ts_done;
@@ -506,7 +517,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   }
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
-  h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false;
+  h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next[q], hipEventDisableTiming));
   h->ev_iso_ready = h->ev_iso_pending = h->ev_iso_next[0];
   h->ev_flip = 0;
@@ -587,7 +598,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipFuncSetAttribute((const void *)k_update_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->upd_lds));
   {
     const size_t colupd_lds = (size_t)COLUPD_WAVES * 2 * (h->d.km + 1) * 64 * 8;
-    if (colupd_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_colupd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
+    if (colupd_lds > 64 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_colupd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
+      HIPCHK(hipFuncSetAttribute((const void *)k_colupd_ts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
+    }
   }
   HIPCHK(hipDeviceSynchronize());
   *out = h;
@@ -830,9 +844,11 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
   return 0;
 }
 static int launch_isopyc(uvic_gpu *h) {
+  h->iso_waited = false;
   if (h->iso_from_prefetch) {   // computed one step ahead on its side stream (uvic_gpu_prefetch_isopyc)
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_iso_ready, 0));
     h->iso_from_prefetch = false;
+    h->iso_waited = true;
     return 0;
   }
   return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
@@ -862,8 +878,15 @@ static int launch_transport(uvic_gpu *h) {
     const bool split = !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
                        h->ts_no_src;
     if (split) {
-      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));       // here: this step's T,S-derived fields are complete on the main stream
-      HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
+      // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
+      // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
+      if (h->iso_waited && h->step_begun) {
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_iso_ready, 0));
+      } else {
+        HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
+      }
       uvic_ctx cts = c;
       cts.nt_local = 2;
       cts.prio |= 2;
@@ -871,9 +894,9 @@ static int launch_transport(uvic_gpu *h) {
       ats.total = ats.nrows * 2 * ats.nseg;
       bts.total = bts.nrows * 2 * bts.nseg;
       mark_on(h, "begin", 3);
-      hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+      hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       mark_on(h, "colfct_ts", 3);
-      hipLaunchKernelGGL(k_colupd, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
+      hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
       mark_on(h, "colupd_ts", 3);
       const WetCols w = wet_range(h, c.js, c.je);
       if (w.count > 0)
