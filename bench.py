@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--decomp", default="auto", choices=["auto", "tracer", "slab"],
                     help="N>1: tracer-index shards + all-gather, or latitude slabs + 2-row halo exchange "
                          "(auto: slabs when every rank gets at least 12 rows, SURVEY.md §8e)")
+    ap.add_argument("--one-slab-of", type=int, default=0, metavar="N",
+                    help="diagnosis on one GPU: time only the work of a middle rank of an N-rank latitude-slab run "
+                         "(no exchange); the JSON line then describes that rank's share, not the metric")
     a = ap.parse_args()
 
     import torch
@@ -180,6 +183,10 @@ def main():
     if cfg.ntnpzd:
         m.set_mobi(ocean)
     shard.apply(m)
+    if a.one_slab_of > 1 and world == 1:
+        from uvic29_amd.parallel import slab_rows
+        js, je = slab_rows(jmt, a.one_slab_of, a.one_slab_of // 2)
+        m.set_shard(js=js, je=je)
 
     from uvic29_amd.tracer import TimeLoop
     loop = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, shard=shard if world > 1 else None)
@@ -224,6 +231,8 @@ def main():
         # restore a sane state (the timed loop may have drifted far) and profile per kernel
         m.load_ocean(ocean, to, so, c, src=src)
         shard.apply(m)
+        if a.one_slab_of > 1 and world == 1:
+            m.set_shard(js=js, je=je)
         iso = m.profile(nrep=10)   # the same kernels back to back on one stream, nothing overlapped
         # §8(f) rank-1 rows (producers of the shared inputs), timed on their own: not part of `value`
         nxt = {}
@@ -263,6 +272,7 @@ def main():
             "ms_per_step_instrumented": el_instr / a.steps * 1e3, "host_submit_ms_per_step": t_submit / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
+            **({"diagnosis": f"one middle slab of {a.one_slab_of}: rows {js}..{je} only, no exchange; not the metric"} if a.one_slab_of > 1 and world == 1 else {}),
             "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
                                    f"(FCT adv_flux, isoflux, explicit update, invtri, convct2"
                                    f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",

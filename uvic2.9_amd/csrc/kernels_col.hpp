@@ -167,7 +167,7 @@ struct ColGrid {
   int fuse_convect;            // pass B: replay the convective mixing found by the T,S walk before t(tau+1) is stored
 };
 #define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
-#define COLUPD_WAVES 2  // waves per workgroup of pass B: 2 x 2 x (km+1) x 512 B of LDS each, three workgroups per CU at km = 19
+#define COLUPD_WAVES 1  // waves per workgroup of pass B: 2 x (km+1) x 512 B of LDS each (20 KB at km = 19), so that workgroups still fit beside a MOBI team (90 KB) on a CU
 
 // Neighbour exchange by DPP whole-wave shifts (gfx9 `wave_shr:1` / `wave_shl:1`): one
 // v_mov_b32_dpp per dword at VALU latency instead of an LDS round trip (ds_bpermute) --
