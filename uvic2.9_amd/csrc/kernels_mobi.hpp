@@ -142,8 +142,12 @@ UVIC_DEV double div_safe(double x, double y) {
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 #define UV_DIVC(x, cst) ((x) * (1.0 / (cst)))   /* division by a literal: its reciprocal is folded at compile time */
+/* x**y for x > 0 on the sub-step's critical path: exp(y*log(x)) is about half the instructions of the correctly
+ * rounded pow and differs from it by |y log x| ulp at most (a few 1e-15 here) */
+#define UV_POWP(x, y) exp((y) * log(x))
 #else
 #define UV_DIVC(x, cst) ((x) / (cst))
+#define UV_POWP(x, y) pow(x, y)
 #endif
 // The same function and derivative as ta_iter_SWS with every denominator inverted once: 7 reciprocals per
 // evaluation instead of 27 divisions (the solve evaluates it ~13 times per cell; divisions were more than half of
@@ -353,7 +357,7 @@ UVIC_DEV double clamp_ratio(double r, double hi, double lo) {
 // the same expression as in the one-thread form (bit-identical results); only wave 0 stores.
 // `NoTeam` runs all roles in one thread (host oracle comparison, single-wave kernel).
 // ---------------------------------------------------------------------------
-#define UV_MOBI_XN 36  /* rates exchanged per column and sub-step */
+#define UV_MOBI_XN 37  /* rates exchanged per column and sub-step */
 #define UV_MOBI_YN 51  /* pools, flags and P:N ratios exchanged per column and sub-step */
 #define UV_MOBI_LDS_DOUBLES ((size_t)2 * (UV_MOBI_XN + UV_MOBI_YN) * 64)
 struct NoTeam {
@@ -422,14 +426,18 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
 
   for (int n = 1; n <= S.nbio; ++n) { /* mobi.F:2148-3252 */
 #ifdef UV_MOBI_TIMING
-    long long tq0 = clock64();
-#define TQ(q) { const long long tq1 = clock64(); T.tq[q] += tq1 - tq0; tq0 = tq1; }
+    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); long long tq0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#define TQ(q) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const long long tq1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); T.tq[q] += tq1 - tq0; tq0 = tq1; }
 #else
 #define TQ(q)
 #endif
 #define ROLE(r) (!Team::team || Team::role == (r))
     // outputs of the four roles
     double npp = 0., npp_D = 0., no3upt_D = 0., dopupt = 0., dopupt_D = 0., fcassim = 0.;
+    // th_no3, the nitrate switch of diazotroph uptake (a tanh, ~650 cycles), is formed by the isotope-ratio wave.
+    // Cycles of this phase per sub-step with fenced counters (-DUV_MOBI_TIMING): growth 2000, grazing 1050, iron 2300,
+    // ratios 870 before; growth 1350, grazing 1050, iron 1500 (its two pow() as exp(y*log(x))), ratios 1530 after.
+    double th_no3 = 0.;
     double graz = 0., graz_Z = 0., graz_Det = 0., graz_D = 0., morp = 0., morpt = 0., morz = 0., remi = 0., expo = 0.;
     double expo_phos = 0., recy_dop = 0., recy_don = 0., morp_D = 0., morpt_D = 0., fcrecy = 0.;
     double feorgads = 0., fecol = 0., expofe = 0., remife = 0.;
@@ -456,7 +464,7 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
       npp = u_P * biophyt;
       dopupt = npp * dopupt_flag; /* NB: from the unflagged npp, mobi.F:2236 */
       npp_D = dmax(0., u_D * biodiaz);
-      no3upt_D = (0.5 + 0.5 * tanh(biono3 - 5.)) * npp_D;
+      no3upt_D = npp_D;   /* times th_no3 = 0.5 + 0.5*tanh(biono3 - 5), applied after the exchange (mobi.F:2233) */
       dopupt_D = npp_D * dopupt_D_flag;
       npp = npp * no3flag * (dopupt_flag * dopflag + (1. - dopupt_flag) * po4flag) * din15flag;
       npp_D = npp_D * (dopupt_D_flag * dopflag + (1. - dopupt_D_flag) * po4flag) * din15flag;
@@ -514,10 +522,10 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
     }
     if (ROLE(2)) {  // ---- iron speciation and scavenging, mobi.F:2313-2342
       remife = nud * bct * biodetrfe;
-      const double ligand = UV_DIVC(dmax(aou_term + UV_DIVC(pow(biodon, 0.8), 4.8), 0.5), 1000.);
+      const double ligand = UV_DIVC(dmax(aou_term + UV_DIVC(UV_POWP(biodon, 0.8), 4.8), 0.5), 1000.);
       const double fepa = (1.0 + P->kfeleq * (ligand - biodfe)) * o2flag;
       const double feprime = div_safe(-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe), 2.0 * P->kfeleq) * o2flag;
-      feorgads = (P->kfeorg * (pow((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
+      feorgads = (P->kfeorg * (UV_POWP((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
       fecol = P->kfecol * (feprime * feprime) * o2flag;
       expofe = wwd * biodetrfe;
       remife = remife * detrfeflag;
@@ -525,7 +533,8 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
       expofe = expofe * detrfeflag;
       fecol = fecol * dfeflag;
     }
-    if (ROLE(3)) {  // ---- isotope ratios, mobi.F:2601-2695
+    if (ROLE(3)) {  // ---- isotope ratios, mobi.F:2601-2695; the nitrate switch (see above)
+      th_no3 = 0.5 + 0.5 * tanh(biono3 - 5.);
       const double rzoop = clamp_ratio(biozoopn15 / (biozoop - biozoopn15), 2. * UV_RN15STD, UV_RN15STD / 2.);
       const double bexcr = rzoop - UV_DIVC(P->eps_excr * rzoop, 1000.);
       fcexcr = div_safe(bexcr, 1 + bexcr);
@@ -551,7 +560,7 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
   X(14, expo) X(15, expo_phos) X(16, recy_dop) X(17, recy_don) X(18, morp_D) X(19, morpt_D) X(20, fcrecy)
 #define XC(X) X(21, feorgads) X(22, fecol) X(23, expofe) X(24, remife)
 #define XD(X) X(25, fcexcr) X(26, rtphytn15) X(27, rtzoopn15) X(28, rtdetrn15) X(29, rtdiazn15) X(30, fcnpp) \
-  X(31, rtphytc13) X(32, rtzoopc13) X(33, rtdetrc13) X(34, rtdoc13) X(35, rtdiazc13)
+  X(31, rtphytc13) X(32, rtzoopc13) X(33, rtdetrc13) X(34, rtdoc13) X(35, rtdiazc13) X(36, th_no3)
 #define XPUT(sl, v) xb[(size_t)(sl) * 64] = v;
 #define XGET(sl, v) v = xb[(size_t)(sl) * 64];
       if (Team::role == 0) { XA(XPUT) } else if (Team::role == 1) { XB(XPUT) } else if (Team::role == 2) { XC(XPUT) } else { XD(XPUT) }
@@ -571,6 +580,7 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
     }
 #undef ROLE
     TQ(3)
+    no3upt_D = th_no3 * no3upt_D;   /* mobi.F:2233; the flags (0 or 1) are already in, which leaves the product unchanged */
     /* zooplankton budget, mobi.F:2446-2530 */
     const double dig_P = gamma1 * graz, dig_Z = gamma1 * graz_Z, dig_Det = gamma1 * graz_Det;
     double dig = dig_Z + dig_P + dig_Det;
