@@ -90,6 +90,19 @@ namespace uvic {
 UVIC_DEV double flag01(double x) { return 0.5 + copysign(0.5, x); }
 UVIC_DEV double sq(double x) { return x * x; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UV_DIVC(x, cst) ((x) * (1.0 / (cst)))   /* division by a literal: its reciprocal is folded at compile time */
+/* x**y for x > 0 on the sub-step's critical path: exp(y*log(x)) is about half the instructions of the correctly
+ * rounded pow and differs from it by |y log x| ulp at most (a few 1e-15 here) */
+#define UV_POWP(x, y) exp((y) * log(x))
+#define UV_POW10(x) exp((x) * 2.302585092994045684)
+#define UV_POW15(x, sqrtx) ((x) * (sqrtx))   /* x**1.5 with sqrt(x) at hand */
+#else
+#define UV_DIVC(x, cst) ((x) / (cst))
+#define UV_POWP(x, y) pow(x, y)
+#define UV_POW10(x) pow(10., x)
+#define UV_POW15(x, sqrtx) pow(x, 1.5)
+#endif
 typedef struct {
   double k1, k2, k1p, k2p, k3p, ksi, kw, ks, kf, kb, bt, st, ft, pt, sit, ta, dic;
 } carb_t;
@@ -140,15 +153,6 @@ UVIC_DEV double div_safe(double x, double y) {
   return x / y;
 #endif
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-#define UV_DIVC(x, cst) ((x) * (1.0 / (cst)))   /* division by a literal: its reciprocal is folded at compile time */
-/* x**y for x > 0 on the sub-step's critical path: exp(y*log(x)) is about half the instructions of the correctly
- * rounded pow and differs from it by |y log x| ulp at most (a few 1e-15 here) */
-#define UV_POWP(x, y) exp((y) * log(x))
-#else
-#define UV_DIVC(x, cst) ((x) / (cst))
-#define UV_POWP(x, y) pow(x, y)
-#endif
 // The same function and derivative as ta_iter_SWS with every denominator inverted once: 7 reciprocals per
 // evaluation instead of 27 divisions (the solve evaluates it ~13 times per cell; divisions were more than half of
 // mobi_pre's instructions).  x in [1e-10, 1e-6], every denominator between 1e-36 and 1e3: no range handling needed.
@@ -254,7 +258,7 @@ UVIC_DEV void mobi_co2calc_SWS(double t, double s, double dic_in, double ta_in, 
   const double s2 = s * s;
   const double t2 = t * t;
   const double sqrts = sqrt(s);
-  const double s15 = pow(s, 1.5);
+  const double s15 = UV_POW15(s, sqrts);
   const double scl = s / 1.80655;
   const double pitkR = pres / tk / 83.15;
   const double p2itkR = pres * pitkR;
@@ -269,9 +273,9 @@ UVIC_DEV void mobi_co2calc_SWS(double t, double s, double dic_in, double ta_in, 
   double b_x = -1636.75 + 12.0408 * tk - 0.0327957 * tk * tk;
   b_x = b_x + 3.16528 * 1e-5 * tk * tk * tk;
   const double FugFac = exp((b_x + 2 * delta_x) * 1 / rt_x);
-  q.k1 = pow(10., -1. * (3670.7 * invtk - 62.008 + 9.7944 * dlogtk - 0.0118 * s + 0.000116 * s2)) *
+  q.k1 = UV_POW10(-1. * (3670.7 * invtk - 62.008 + 9.7944 * dlogtk - 0.0118 * s + 0.000116 * s2)) *
          exp((25.5 - 0.1271 * t) * pitkR + 0.5 * (-3.08e-3 + 8.77e-5 * t) * p2itkR);
-  q.k2 = pow(10., -1 * (1394.7 * invtk + 4.777 - 0.0184 * s + 0.000118 * s2)) *
+  q.k2 = UV_POW10(-1 * (1394.7 * invtk + 4.777 - 0.0184 * s + 0.000118 * s2)) *
          exp((15.82 + 0.0219 * t) * pitkR + 0.5 * (1.13e-3 - 1.475e-4 * t) * p2itkR);
   q.k1p = exp(-4576.752 * invtk + 115.540 - 18.453 * dlogtk + (-106.736 * invtk + 0.69171) * sqrts +
               (-0.65643 * invtk - 0.01844) * s) *
@@ -288,7 +292,7 @@ UVIC_DEV void mobi_co2calc_SWS(double t, double s, double dic_in, double ta_in, 
              0.01615 * s) *
          exp((20.02 - 0.1119 * t + 1.409e-3 * t2) * pitkR + 0.5 * (-5.13e-3 + 7.94e-5 * t) * p2itkR);
   q.ks = exp(-4276.1 * invtk + 141.328 - 23.093 * dlogtk + (-13856 * invtk + 324.57 - 47.986 * dlogtk) * sqrtis +
-             (35474 * invtk - 771.54 + 114.723 * dlogtk) * is - 2698 * invtk * pow(is, 1.5) + 1776 * invtk * is2 +
+             (35474 * invtk - 771.54 + 114.723 * dlogtk) * is - 2698 * invtk * UV_POW15(is, sqrtis) + 1776 * invtk * is2 +
              log(1.0 - 0.001005 * s)) *
          exp((18.03 - .0466 * t - 3.16e-4 * t2) * pitkR + 0.5 * (-4.53e-3 + 9.0e-5 * t) * p2itkR);
   q.kf = exp(1590.2 * invtk - 12.641 + 1.525 * sqrtis + log(1.0 - 0.001005 * s)) *
@@ -841,13 +845,13 @@ UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, 
     o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
     aou_in = o2sat - o2_in;
   }
-  const double bct = pow(P->bbio, P->cbio * t_in);
-  const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * pow(P->bbio, P->cbio * t_in);
+  const double bct = UV_POWP(P->bbio, P->cbio * t_in);
+  const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * UV_POWP(P->bbio, P->cbio * t_in);
   PRE(MP_BCT) = bct;
   PRE(MP_BCTZ) = bctz;
   PRE(MP_NUD) = P->nud0 * (0.6 + 0.4 * tanh(0.22 * dmax(o2_in, 0.)));
   PRE(MP_O2F) = tanh(dmax(o2_in, 0.));                 // o2flag, mobi.F:2313
-  PRE(MP_AOUT) = pow(dmax(aou_in, 40.), 0.8) / 66.;    // the AOU term of the ligand concentration, mobi.F:2316
+  PRE(MP_AOUT) = UV_DIVC(UV_POWP(dmax(aou_in, 40.), 0.8), 66.);    // the AOU term of the ligand concentration, mobi.F:2316
   /* light-limited growth, Evans & Parslow, with iron-dependent Chl:C, mobi.F:1984-2061 */
   const double biophyt = TNC(k, MI::phyt), biodiaz = TNC(k, MI::diaz), biodfe = TNC(k, MI::dfe), dzt = P->dzt[k - 1];
   const double p1 = dmin(biophyt, P->pmax);
