@@ -67,8 +67,8 @@ typedef struct uvic_ctx {
   const double *tlat;                                             /* (imt,jmt) */
   const double *edrm2, *edrs2, *edrk1, *edro1;                    /* (imt,km,jmt) */
   double kappa_h, zetar, ogamma, gravrho0r;
-  int no_landskip;   /* debug */
-  int prio;          /* experiment: bit0 MOBI team waves at normal issue priority, bit1 transport waves raised */
+  int no_landskip;   /* measurement: 1 = segments without ocean are marched like the others (UVIC_NO_LANDSKIP) */
+  int prio;          /* bit 0: MOBI team waves at normal issue priority (UVIC_TEAM_PRIO0); bit 1: this launch at raised priority (the T,S passes) */
 } uvic_ctx;
 
 #endif

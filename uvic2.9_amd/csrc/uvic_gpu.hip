@@ -397,7 +397,7 @@ struct uvic_gpu {
   // device offers four hardware queues, and a fifth stream would share one with another and wait behind its barriers)
   bool iso_waited;    // this step's T,S-derived fields came from the look-ahead chain (ev_iso_ready)
   bool step_begun;    // ev_step_begin of the current step is recorded (uvic_gpu_rotate ends the step)
-  hipStream_t side_ts; // the T,S passes: side2, or a stream of its own when the runtime has more than four hardware queues
+  hipStream_t side_ts; // the T,S passes: an alias of side2
   hipEvent_t ev_fct_done, ev_ts_done;
   bool ts_ahead;      // this step's convect_ts was already issued on side2
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
@@ -496,25 +496,15 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
-  const int prio_exp = getenv("UVIC_PRIO") ? atoi(getenv("UVIC_PRIO")) : 0;
-  int prio_lo = 0, prio_hi = 0;
-  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lower = higher priority
-  if (prio_exp & 4) HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
-  else HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->mobi_flip = 0;
   h->mobi_two_streams = true;
   if (const char *e = getenv("UVIC_MOBI_STREAMS")) h->mobi_two_streams = atoi(e) != 1;
-  if (prio_exp & 8) HIPCHK(hipStreamCreateWithPriority(&h->side_m[0], hipStreamNonBlocking, prio_lo));
-  else HIPCHK(hipStreamCreateWithFlags(&h->side_m[0], hipStreamNonBlocking));
-  if (h->mobi_two_streams && (prio_exp & 8)) HIPCHK(hipStreamCreateWithPriority(&h->side_m[1], hipStreamNonBlocking, prio_lo));
-  else if (h->mobi_two_streams) HIPCHK(hipStreamCreateWithFlags(&h->side_m[1], hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->side_m[0], hipStreamNonBlocking));
+  if (h->mobi_two_streams) HIPCHK(hipStreamCreateWithFlags(&h->side_m[1], hipStreamNonBlocking));
   else h->side_m[1] = h->side_m[0];
   HIPCHK(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-  h->side_ts = h->side2;
-  {
-    const char *q = getenv("GPU_MAX_HW_QUEUES");
-    if (q && atoi(q) >= 5) HIPCHK(hipStreamCreateWithFlags(&h->side_ts, hipStreamNonBlocking));
-  }
+  h->side_ts = h->side2;   // a stream of their own did not pay: the device has four hardware queues
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
   h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false;
@@ -571,7 +561,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->ctx.n0 = 0; h->ctx.nt_local = dims->nt; h->ctx.js = 2; h->ctx.je = dims->jmt - 1;
   h->ctx.c2dtts = 0.0; h->ctx.aidif = 0.5;
   h->ctx.no_landskip = getenv("UVIC_NO_LANDSKIP") ? 1 : 0;
-  h->ctx.prio = getenv("UVIC_PRIO") ? atoi(getenv("UVIC_PRIO")) : 0;
+  h->ctx.prio = getenv("UVIC_TEAM_PRIO0") ? 1 : 0;
   // tile geometry: keep the FCT tile within the LDS budget
   int budget_kb = 150;
   if (const char *e = getenv("UVIC_LDS_BUDGET_KB")) budget_kb = atoi(e);
