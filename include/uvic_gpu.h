@@ -189,7 +189,9 @@ int uvic_gpu_transport(uvic_gpu *h);
  * u09/mom/tracer.F:1198-1203 (source/mom/convect.F:99-311) */
 int uvic_gpu_convect(uvic_gpu *h);
 /* replaces `call tracer (joff, js, je, is, ie)`, source/mom/mom.F:389:
- * sources, transport, convection */
+ * sources, transport, convection.  Knowing that convct2 follows, it sends T and S through the
+ * transport first and replays their mixed segments inside the update of the other tracers; the
+ * result equals uvic_gpu_transport followed by uvic_gpu_convect bit for bit (tests/test_gpu_fast.py) */
 int uvic_gpu_tracer(uvic_gpu *h);
 /* time-level rotation done by putmw/getvar through the ramdrive
  * (u09/mom/loadmw.F:528-588,717-744): taum1 <- tau, tau <- taup1 */

@@ -113,3 +113,31 @@ def test_hundred_step_drift_full_size_vs_bit_exact_path():
         assert drift <= max(1e-12, 5.0 * sens), (name, drift, sens)
         assert drift <= 1e-11, (name, drift)
     print("100-step drift (production vs bit-exact, one-ulp sensitivity):", report)
+
+
+@pytest.mark.parametrize("dims", [(14, 14, 6), (102, 102, 19)])
+def test_whole_step_with_fused_convection_equals_the_separate_passes(dims):
+    """`uvic_gpu_tracer` sends T and S through both column passes and the convective walk first (side stream) and lets
+    pass B of the other tracers replay the mixed segments before t(tau+1) is stored; `transport` + `convect` run pass A
+    and B for all tracers together and convct2 as its own two passes.  Same bits, and convection does act on this ocean."""
+    from uvic29_amd.tracer import TracerModel
+    oc = synthetic.make_ocean("c30", *dims)
+    to, so, c = synthetic.load_eos(dims[2])
+    src = _rand_src(oc)
+    out = {}
+    for how in ("fused", "separate", "unmixed"):
+        m = TracerModel(*dims, oc.cfg.nt, oc.cfg.nsrc, 0)      # sources given: the comparison is about transport + convection
+        m.set_exact(False)
+        m.load_ocean(oc, to, so, c, src=src)
+        m.isopyc()
+        if how == "fused":
+            m.tracer()
+        else:
+            m.transport()
+            if how == "separate":
+                m.convect()
+        out[how] = m.download("t_taup1")
+        m.close()
+    assert np.array_equal(out["fused"], out["separate"])
+    changed = (out["separate"] != out["unmixed"]).any(axis=(0, 1, 2))
+    assert changed[:2].all() and changed[2:].any(), "convection left the step unchanged: the test ocean has no unstable column"

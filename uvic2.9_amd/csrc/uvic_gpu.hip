@@ -843,7 +843,8 @@ static int launch_isopyc(uvic_gpu *h) {
   }
   return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
 }
-static int launch_transport(uvic_gpu *h) {
+// `convect_follows`: the caller runs convct2 right after (the whole `tracer` step): T,S may go first and the replay be fused
+static int launch_transport(uvic_gpu *h, bool convect_follows) {
   const uvic_ctx &c = h->ctx;
   if (c.nt_local <= 0) return 0;
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
@@ -865,7 +866,7 @@ static int launch_transport(uvic_gpu *h) {
     // the walk run on the side stream while the main stream works on the other tracers, whose pass B then finds the
     // mixed segments ready and replays them itself (no separate convection pass over t(tau+1)).  Not under tracer
     // sharding, where convection follows the exchange.
-    const bool split = !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
+    const bool split = convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
                        h->ts_no_src;
     if (split) {
       // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
@@ -1109,7 +1110,7 @@ extern "C" int uvic_gpu_isopyc(uvic_gpu *h) {
 extern "C" int uvic_gpu_transport(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));
-  if (int rc = launch_transport(h)) return rc;
+  if (int rc = launch_transport(h, false)) return rc;   // transport alone: t(tau+1) before convct2
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1122,7 +1123,7 @@ extern "C" int uvic_gpu_convect(uvic_gpu *h) {
 }
 static int launch_tracer(uvic_gpu *h) {
   if (int rc = launch_mobi(h)) return rc;
-  if (int rc = launch_transport(h)) return rc;
+  if (int rc = launch_transport(h, true)) return rc;
   if (int rc = launch_convect(h)) return rc;
   return 0;
 }
@@ -1237,7 +1238,7 @@ extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
   if (int rc = step_begin(h)) return rc;
   if (int rc = launch_isopyc(h)) return rc;
   if (int rc = launch_mobi(h)) return rc;
-  return launch_transport(h);
+  return launch_transport(h, false);
 }
 // ... and convection (all tracers, needs T,S of every column) after it
 extern "C" int uvic_gpu_convect_async(uvic_gpu *h) {
