@@ -147,6 +147,13 @@ int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc, const int3
                            const double *fsc, const double *tlat, const double *dnswr, const double *aice,
                            const double *hice, const double *hsno, const double *sg_bathy, const double *fe_atmdep,
                            const double *fe_hydr);
+/* what of the MOBI forcing changes every step, after uvic_gpu_set_mobi[_flat] has set the rest once: the fields
+ * tracer.F:355-390 reads (downward shortwave, ice fraction and thickness, snow), relyr and the atmospheric CO2 */
+int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, const double *dnswr, const double *aice,
+                           const double *hice, const double *hsno);
+/* page-lock a host range that is uploaded from or downloaded into every step (the reference's COMMON blocks live as
+ * long as the process); the memory stays the caller's */
+int uvic_gpu_pin_host(uvic_gpu *h, void *ptr, int64_t bytes);
 /* the source-term kernel alone (for parity tests): fills UVIC_F_SRC */
 int uvic_gpu_mobi(uvic_gpu *h);
 
@@ -163,6 +170,10 @@ int uvic_gpu_download(uvic_gpu *h, int field, void *host, int64_t offset, int64_
 /* host array dimensioned (imt, kdim, jlo:jhi [, extra]) -> device rows jlo..jhi */
 int uvic_gpu_upload_rows(uvic_gpu *h, int field, const double *host, int jlo, int jhi);
 int uvic_gpu_download_rows(uvic_gpu *h, int field, double *host, int jlo, int jhi);
+/* level k (1-based) of tracer n (1-based; 1 for a plain cell field; 0 = every tracer, host (imt, jmt, nt)) of a cell field as contiguous (imt, jmt) planes.
+ * With the state resident on the device the host needs T,S whole but of the other tracers only the surface level:
+ * `set_sbc` reads t(i,1,j,n,taup1) (u09/mom/set_sbc.F:36-72) */
+int uvic_gpu_download_level(uvic_gpu *h, int field, int n, int k, double *host);
 /* number of elements and device address of a field (for zero-copy plumbing) */
 int64_t uvic_gpu_field_elems(uvic_gpu *h, int field);
 void *uvic_gpu_field_devptr(uvic_gpu *h, int field);

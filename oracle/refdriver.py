@@ -235,3 +235,17 @@ class RefOcean:
         t = self.v["t"]
         t[..., 0] = t[..., 1]
         t[..., 1] = t[..., 2]
+
+    def set_step_kind(self, forward: bool):
+        """A forward ("mixing") step: c2dtts = dtts and both MW slots hold the tau data
+        (updates/09/source/mom/loadmw.F:107-111); else leapfrog with c2dtts = 2 dtts."""
+        dtts = self.ocean.params.dtts
+        self.ref.set("forward", 1 if forward else 0)
+        self.ref.set("leapfrog", 0 if forward else 1)
+        self.ref.set("c2dtts", dtts if forward else 2.0 * dtts)
+        if forward:
+            self.v["t"][..., 0] = self.v["t"][..., 1]
+
+    def flush(self):
+        """Resident overlay only: the device's t(tau-1), t(tau) into the host's slots."""
+        self.ref.call("tracer_gpu_flush")

@@ -55,3 +55,41 @@ def test_overlay_tracer_with_polar_filter_matches_reference(monkeypatch):
     shim.set_filter(flt)
     got = shim.step().copy()
     assert np.array_equal(got[:, :, 1:-1], want[:, :, 1:-1])
+
+
+@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6))])
+def test_resident_overlay_over_several_steps(cfg, dims, monkeypatch):
+    """UVIC_RESIDENT=1: t stays on the device and rotates there (what loadmw/putmw and the
+    ramdrive do on the host); per step only T,S and the surface levels come back.  Six steps of the reference's own
+    call sequence -- leapfrog, a forward (mixing) step, and one step on which the overlay hands the work to the
+    reference routine (every tracer goes down, t(tau+1) comes up) -- against the unmodified reference."""
+    monkeypatch.setenv("UVIC_EXACT", "1")
+    monkeypatch.setenv("UVIC_RESIDENT", "1")
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    ref = refdriver.RefOcean(oc)
+    shim = refdriver.RefOcean(oc, shim=True)
+    if not hasattr(shim.ref.lib, "tracer_gpu_flush_"):
+        pytest.skip("oracle/_ref shim predates the resident mode")
+    jmt = dims[1]
+    for it in range(1, 7):
+        forward, on_host = it == 3, it == 5
+        for r in (ref, shim):
+            r.set_step_kind(forward)
+            r.ref.set("euler2", 1 if on_host else 0)       # the overlay's cue to call the reference routine
+        want = ref.step().copy()
+        got = shim.step().copy()
+        # what the host reads between two steps: T and S whole ...
+        assert np.array_equal(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2]), it
+        ref.rotate(); shim.rotate()
+    if oc.cfg.nt > 2:   # resident for real: below the surface the host copy of the other tracers is stale until the flush
+        assert not np.array_equal(shim.v["t"][:, 1:, 1:jmt - 1, 2:, 1], ref.v["t"][:, 1:, 1:jmt - 1, 2:, 1])
+    shim.flush()
+    for slot in (0, 1):                                      # t(tau-1), t(tau) of the coming step, every tracer
+        a, b = shim.v["t"][..., slot], ref.v["t"][..., slot]
+        assert np.array_equal(a[:, :, 1:jmt - 1, :2], b[:, :, 1:jmt - 1, :2])
+        for n, name in enumerate(oc.cfg.tracers):
+            x, y = a[:, :, 1:jmt - 1, n], b[:, :, 1:jmt - 1, n]
+            assert np.abs(x - y).max() <= 1e-11 * np.abs(y).max(), (slot, name, np.abs(x - y).max())

@@ -768,6 +768,26 @@ extern "C" int uvic_gpu_download_rows(uvic_gpu *h, int field, double *host, int 
   return rows_xfer(h, field, host, jlo, jhi, false);
 }
 
+// one level of one tracer (or of a plain cell field: n = 1) as an (imt, jmt) plane: what set_sbc wants of t(tau+1)
+// when the state stays on the device (u09/mom/set_sbc.F:36-72 reads t(i,1,j,n,taup1) only)
+extern "C" int uvic_gpu_download_level(uvic_gpu *h, int field, int n, int k, double *host) {
+  if (!h || !host) return fail_msg("uvic_gpu_download_level: null argument");
+  if (field < 0 || field >= UVIC_F_COUNT || FIELDS[field].is_int || FIELDS[field].kind != K_C)
+    return fail_msg("uvic_gpu_download_level: field is not a cell field (imt,km,jmt[,n])");
+  const int64_t ex = extra_of(h->d, FIELDS[field].extra);
+  if (n < 0 || n > ex || k < 1 || k > h->d.km) return fail_msg("uvic_gpu_download_level: n or k out of range");
+  HIPCHK(hipSetDevice(h->device));
+  // rows of one level lie imt*km apart, within a tracer and from the last row of one tracer to the first of the next:
+  // one strided copy serves one tracer (jmt rows) or all of them (n = 0: jmt*ex rows -> host (imt, jmt, ex))
+  const size_t N3 = (size_t)h->d.imt * h->d.km * h->d.jmt;
+  const char *src = (const char *)h->buf[field] + ((size_t)(n > 0 ? n - 1 : 0) * N3 + (size_t)(k - 1) * h->d.imt) * 8;
+  const size_t rows = (size_t)h->d.jmt * (n > 0 ? 1 : (size_t)ex);
+  HIPCHK(hipMemcpy2DAsync(host, (size_t)h->d.imt * 8, src, (size_t)h->d.imt * h->d.km * 8, (size_t)h->d.imt * 8, rows,
+                          hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 extern "C" int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p) {
   if (!h || !p) return fail_msg("uvic_gpu_set_params: null argument");
   h->ctx.c2dtts = p->c2dtts; h->ctx.aidif = p->aidif;
@@ -1420,6 +1440,32 @@ extern "C" int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc,
   F.tlat = tlat; F.dnswr = dnswr; F.aice = aice; F.hice = hice; F.hsno = hsno;
   F.sg_bathy = sg_bathy; F.fe_atmdep = fe_atmdep; F.fe_hydr = fe_hydr;
   return uvic_gpu_set_mobi(h, &P, &F);
+}
+// the part of the MOBI forcing that changes from step to step (tracer.F:355-390 reads dnswr, aice, hice, hsno of the
+// current step; relyr selects the month of the dust field and the declination; co2ccn the atmospheric CO2)
+extern "C" int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, const double *dnswr, const double *aice,
+                                      const double *hice, const double *hsno) {
+  if (!h || !dnswr || !aice || !hice || !hsno) return fail_msg("uvic_gpu_set_mobi_step: null argument");
+  if (!h->have_mobi) return fail_msg("uvic_gpu_set_mobi_step: call uvic_gpu_set_mobi first");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->d.imt * h->d.jmt * 8;
+  const double *src[4] = {dnswr, aice, hice, hsno};
+  for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->mobi.relyr = relyr;
+  h->mobi.co2ccn = co2ccn;
+  return 0;
+}
+// Page-lock a host range the caller will upload from or download into every step (COMMON blocks live as long as the
+// process): transfers then run at the link's rate instead of through the runtime's staging buffer.  Not owned: the
+// caller's memory stays the caller's; uvic_gpu_destroy does not unregister.
+extern "C" int uvic_gpu_pin_host(uvic_gpu *h, void *ptr, int64_t bytes) {
+  if (!h || !ptr || bytes <= 0) return fail_msg("uvic_gpu_pin_host: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return 0; }
+  if (e != hipSuccess) return fail("hipHostRegister", e, __LINE__);
+  return 0;
 }
 extern "C" int uvic_gpu_mobi(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");

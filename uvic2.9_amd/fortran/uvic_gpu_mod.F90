@@ -114,6 +114,39 @@
           type(c_ptr), value :: h
           integer(c_int) :: rc
         end function
+        function uvic_gpu_download_level(h, field, n, k, host) bind(C,name='uvic_gpu_download_level') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: field, n, k
+          real(c_double) :: host(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_mobi_step(h, relyr, co2ccn, dnswr, aice, hice, hsno)                             &
+     &      bind(C,name='uvic_gpu_set_mobi_step') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double), value :: relyr, co2ccn
+          real(c_double) :: dnswr(*), aice(*), hice(*), hsno(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_pin_host(h, host, bytes) bind(C,name='uvic_gpu_pin_host') result(rc)
+          import
+          type(c_ptr), value :: h
+          type(*) :: host(*)
+          integer(c_int64_t), value :: bytes
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_mixing(h, on) bind(C,name='uvic_gpu_set_mixing') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: on
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_rotate(h) bind(C,name='uvic_gpu_rotate') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_last_error() bind(C,name='uvic_gpu_last_error') result(msg)
           import
           type(c_ptr) :: msg
@@ -121,6 +154,10 @@
       end interface
 
       type(c_ptr), save :: uvic_handle = c_null_ptr
+!     resident mode (environment UVIC_RESIDENT=1, read at the first call of the overlay): every tracer stays on
+!     the device from step to step; uvic_dev_state says that the device holds t(tau-1), t(tau) of the coming step
+      logical, save :: uvic_resident = .false.
+      logical, save :: uvic_dev_state = .false.
 
       contains
 
