@@ -74,6 +74,17 @@ def load():
     if not path.exists():
         raise UvicGpuError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch ships its own copy of the HIP runtime.  A process that uses both must let torch bring its runtime up
+    # first (the library then binds to that one); the other way round torch finds "no HIP GPUs".  So if torch is
+    # already imported, initialise its device layer before the library is loaded.
+    import sys
+    if "torch" in sys.modules:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:   # torch without a usable GPU: the library will say so itself
+            pass
     lib = ctypes.CDLL(str(path))
     lib.uvic_gpu_last_error.restype = ctypes.c_char_p
     lib.uvic_gpu_field_elems.restype = ctypes.c_int64
