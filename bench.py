@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--decomp", default="auto", choices=["auto", "tracer", "slab"],
                     help="N>1: tracer-index shards + all-gather, or latitude slabs + 2-row halo exchange "
                          "(auto: slabs when every rank gets at least 12 rows, SURVEY.md §8e)")
+    ap.add_argument("--segment", type=int, default=0, metavar="NTSPOS",
+                    help="ocean steps per coupling segment: the first step of a segment gets new surface forcing, so its MOBI "
+                         "sources are not computed a step ahead (0 = the synthetic forcing is constant, the default)")
     ap.add_argument("--one-slab-of", type=int, default=0, metavar="N",
                     help="diagnosis on one GPU: time only the work of a middle rank of an N-rank latitude-slab run "
                          "(no exchange); the JSON line then describes that rank's share, not the metric")
@@ -189,7 +192,7 @@ def main():
         m.set_shard(js=js, je=je)
 
     from uvic29_amd.tracer import TimeLoop
-    loop = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, shard=shard if world > 1 else None)
+    loop = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, shard=shard if world > 1 else None, segment=a.segment)
 
     def one_step():
         loop.step()
@@ -276,7 +279,9 @@ def main():
             "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
                                    f"(FCT adv_flux, isoflux, explicit update, invtri, convct2"
                                    f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",
-                       "grid": a.grid, "nt": nt, "parallelism": (f"latitude-slab x{world}, 2-row halo exchange" if decomp == "slab" else f"tracer-shard x{world}")},
+                       "grid": a.grid, "nt": nt,
+                       "forcing": ("constant: every leapfrog step looks one step ahead" if a.segment == 0 else
+                                   f"renewed every {a.segment} steps: the first step of a segment computes its MOBI sources in line"), "parallelism": (f"latitude-slab x{world}, 2-row halo exchange" if decomp == "slab" else f"tracer-shard x{world}")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "dominant HBM-side (transport) kernel; kernel_ms are HIP-event means over a second, instrumented "

@@ -261,8 +261,12 @@ class TimeLoop:
     With MOBI, the source terms of the next leapfrog step are started one step ahead on a
     side stream (they depend only on t(tau-1) of that step = t(tau) of this one)."""
 
-    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True):
+    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True, segment=0):
+        """segment = ntspos, the ocean steps per coupling segment (u09/common/UVic_ESCM.F:177-189): the surface forcing
+        MOBI reads changes at a segment's first step, whose sources therefore cannot be computed one step ahead
+        (0: the forcing never changes during the loop)."""
         self.m, self.dtts, self.nmix, self.shard, self.prefetch = model, float(dtts), int(nmix), shard, prefetch
+        self.segment = int(segment)
         self.itt = 0
 
     def _mixing(self, itt):
@@ -281,7 +285,7 @@ class TimeLoop:
         # the look-ahead chains of the next step wait only for the end of the previous step; they are queued after
         # this step so that its T,S passes (first on the isopyc stream) are not held up behind them
         if self.prefetch and not self._mixing(self.itt + 1):
-            if m.has_mobi:
+            if m.has_mobi and not (self.segment > 0 and self.itt % self.segment == 0):   # next step opens a segment: new forcing
                 m.prefetch_sources(2.0 * self.dtts)
             if not m.params.diff_cbt_has_k33:
                 m.prefetch_isopyc()
