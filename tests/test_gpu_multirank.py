@@ -153,3 +153,24 @@ def test_rccl_paths_single_rank(tmp_path):
     ok = np.load(out)
     assert ok[0], "in-place all-gather changed the buffer"
     assert ok[1], "row blocks sent through RCCL did not arrive where expected"
+
+
+def test_bench_with_two_ranks_on_one_gpu_prints_one_json_line():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
+    the one GPU of this box and gloo standing in for RCCL (UVIC_BENCH_REHEARSAL=1): rank 0 prints exactly one JSON line
+    with the contract's keys, the whole-job value and the slab decomposition."""
+    import json
+    import subprocess
+    env = dict(os.environ, UVIC_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "latitude-slab x2" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d            # reported at N = 1 only
