@@ -997,7 +997,7 @@ UVIC_DEV void mobi_post_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k,
   const double din15flag = flag01(tn_din15 - UV_TRCMIN);
   const double lno3 = 0.5 * tanh(tn_no3 * 10 - 5.0);
   double sg_bdeni =
-      (0.06 + 0.19 * pow(0.99, dmax(o2_in, UV_TRCMIN) - dmax(tn_no3, UV_TRCMIN))) * dmax(expo * sgb, UV_TRCMIN) * redctn * 1.e3;
+      (0.06 + 0.19 * UV_POWP(0.99, dmax(o2_in, UV_TRCMIN) - dmax(tn_no3, UV_TRCMIN))) * dmax(expo * sgb, UV_TRCMIN) * redctn * 1.e3;
   sg_bdeni = dmin(sg_bdeni, sgb * expo);
   sg_bdeni = dmax(sg_bdeni, 0.);
   sg_bdeni = sg_bdeni * (0.5 + lno3) * no3flag * din15flag;
@@ -1012,7 +1012,7 @@ UVIC_DEV void mobi_post_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k,
   const double coxdepth = dmin(dmax(P->zt[k - 1], 50000.), 150000.);
   const double oblinc = -1.26e-6 * coxdepth + 0.203;
   const double obexpc = -6.e-7 * coxdepth + 1.14;
-  const double nburial = (oblinc * pow(expo * sgb * dztk / 100 * 86400. * 365. * redctn * 1000., obexpc)) /
+  const double nburial = (oblinc * UV_POWP(expo * sgb * dztk / 100 * 86400. * 365. * redctn * 1000., obexpc)) /   /* base >= 0, exponent > 0: exp(y log 0) = 0 as pow */
                          (86400. * 365. * dztk / 100 * redctn * 1000.);
   const double coxsed = expo * sgb - nburial;
   const double fesedmax = 85.;
