@@ -152,12 +152,6 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     imt, jmt, km = (int(x) for x in a.grid.split("x"))
     cfg = OPTION_SETS[a.cfg] if a.cfg in OPTION_SETS else performance_set(int(a.cfg.replace("perf", "")))
@@ -182,6 +176,14 @@ def main():
     if shard.nt_model != nt:          # pad the tracer dimension with inert tracers (see parallel.py)
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, nsrc, cfg.ntnpzd, device=local_rank)
+    # The communicator only now: the library's four streams must take the device's four hardware queues before RCCL's
+    # own streams exist (a 12-row slab steps in 0.21 ms this way and in 0.34 ms the other way round).
+    if world > 1:
+        import torch.distributed as dist
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     m.load_ocean(ocean, to, so, c, src=src)
     if cfg.ntnpzd:
         m.set_mobi(ocean)
