@@ -391,6 +391,8 @@ struct uvic_gpu {
   // before step n waits for the chain of step n: `_pending` = recorded during this step, `_ready` = what this step waits for
   int ev_flip;
   hipEvent_t ev_src_ready, ev_src_pending, ev_iso_ready, ev_iso_pending;
+  hipEvent_t ev_step_end[2], ev_end_ready, ev_end_pending;   // end of a step's own work (step_end)
+  bool end_ready, end_pending;
   // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
   hipStream_t side2;
   // (T and S finish pass B and the convective T,S walk on side2 as well, beside pass B of the other tracers: the
@@ -517,6 +519,9 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
   h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
+  for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_step_end[q], hipEventDisableTiming));
+  h->ev_end_ready = h->ev_end_pending = h->ev_step_end[0];
+  h->end_ready = h->end_pending = false;
   h->src_alt = nullptr;
   h->mobi_team = true;
   if (const char *e = getenv("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
@@ -630,7 +635,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
-  for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_src_next[q]);
+  for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(h->ev_src_next[q]); (void)hipEventDestroy(h->ev_step_end[q]); }
   (void)hipStreamDestroy(h->side_m[0]);
   if (h->side_m[1] != h->side_m[0]) (void)hipStreamDestroy(h->side_m[1]);
   if (h->side_ts != h->side2) (void)hipStreamDestroy(h->side_ts);
@@ -724,6 +729,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
   HIPCHK(hipStreamSynchronize(h->side_ts));
     h->prefetch_pending = h->src_from_prefetch = false;
     h->iso_prefetch_pending = h->iso_from_prefetch = false;
+    h->end_ready = h->end_pending = false;
   }
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1171,11 +1177,21 @@ static int step_begin(uvic_gpu *h) {
   return 0;
 }
 // asynchronous variants used by the time loop of bench.py: no host sync
+// The point on the main stream where this step's own rows of t(tau+1) are complete -- before a latitude-slab caller
+// queues the halo exchange.  The MOBI chain of the step after next is column-local and waits for this, not for the
+// exchange (on a 12-row slab the chain is the critical path and the exchange costs 0.06 ms).
+static int step_end(uvic_gpu *h) {
+  h->ev_end_pending = h->ev_step_end[h->ev_flip];
+  HIPCHK(hipEventRecord(h->ev_end_pending, h->stream));
+  h->end_pending = true;
+  return 0;
+}
 extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   if (int rc = step_begin(h)) return rc;
   if (int rc = launch_isopyc(h)) return rc;
-  return launch_tracer(h);
+  if (int rc = launch_tracer(h)) return rc;
+  return step_end(h);
 }
 // MOBI sources of the NEXT step from t(tau) (= next step's t(tau-1) on a leapfrog step) on
 // the side stream, overlapped with this step's transport.  Call before (preferred: its kernels are then queued ahead of this step's side-stream work) or after uvic_gpu_step_async
@@ -1200,7 +1216,8 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
   if (int rc = step_begin(h)) return rc;
   // src_alt was read last by pass B of the previous step (before ev_step_begin); the other chain writes the other buffer
-  HIPCHK(hipStreamWaitEvent(st, h->ev_step_begin, 0));
+  // (the end of the previous step's own work is enough: MOBI is column-local, the halo rows do not matter to it)
+  HIPCHK(hipStreamWaitEvent(st, h->end_ready ? h->ev_end_ready : h->ev_step_begin, 0));
   if (int rc = launch_mobi_on(h, c, m, st, sid)) return rc;
   h->ev_src_pending = h->ev_src_next[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_src_pending, st));
@@ -1271,7 +1288,8 @@ extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
 // ... and convection (all tracers, needs T,S of every column) after it
 extern "C" int uvic_gpu_convect_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
-  return launch_convect(h);
+  if (int rc = launch_convect(h)) return rc;
+  return step_end(h);
 }
 // -- latitude-slab halo rows of t(tau+1): staging buffers the exchange sends from and receives into
 #define UVIC_HALO 2
@@ -1317,6 +1335,9 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   h->step_begun = false;
   h->ev_flip ^= 1;
+  h->end_ready = h->end_pending;
+  h->ev_end_ready = h->ev_end_pending;
+  h->end_pending = false;
   void *m1 = h->buf[UVIC_F_T_TAUM1], *t0 = h->buf[UVIC_F_T_TAU], *p1 = h->buf[UVIC_F_T_TAUP1];
   h->buf[UVIC_F_T_TAUM1] = t0;
   h->buf[UVIC_F_T_TAU] = p1;
