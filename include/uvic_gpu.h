@@ -225,6 +225,10 @@ int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 /* the T,S-derived fields (isopyc products, folded coefficients) of the NEXT step on a second side stream; same calling
  * rule as uvic_gpu_prefetch_sources: before uvic_gpu_rotate of this step, next step leapfrog */
 int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
+/* one call per step of a device-resident loop: forward-step aliasing (mixing), c2dtts, the whole step, and the
+ * look-ahead chains of the next step (mobi_ahead with c2dtts_next, iso_ahead); then exchange halo rows if the
+ * decomposition has neighbours, then uvic_gpu_rotate (which ends a forward step's aliasing) */
+int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, int iso_ahead);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);
 /* latitude-slab decomposition (uvic_gpu_set_shard js..je): the two outermost owned rows of t(tau+1) of every tracer

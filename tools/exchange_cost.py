@@ -36,8 +36,7 @@ class SelfSlab(SlabShard):
         self.peers = (0, 0) if n > 2 else (None, 0)      # of two slabs the southern one: a northern neighbour only
         self.do_exchange = exchange
 
-    def step(self, model):
-        model.step_async()
+    def after_step(self, model):
         if not self.do_exchange:
             return
         if self._stream is None:

@@ -398,6 +398,7 @@ struct uvic_gpu {
   // (T and S finish pass B and the convective T,S walk on side2 as well, beside pass B of the other tracers: the
   // device offers four hardware queues, and a fifth stream would share one with another and wait behind its barriers)
   bool iso_waited;    // this step's T,S-derived fields came from the look-ahead chain (ev_iso_ready)
+  bool unmix_at_rotate;   // uvic_gpu_step_lookahead ran a forward step: uvic_gpu_rotate ends the aliasing
   bool step_begun;    // ev_step_begin of the current step is recorded (uvic_gpu_rotate ends the step)
   hipStream_t side_ts; // the T,S passes: an alias of side2
   hipEvent_t ev_fct_done, ev_ts_done;
@@ -509,7 +510,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->side_ts = h->side2;   // a stream of their own did not pay: the device has four hardware queues
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
-  h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false;
+  h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false; h->unmix_at_rotate = false;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next[q], hipEventDisableTiming));
   h->ev_iso_ready = h->ev_iso_pending = h->ev_iso_next[0];
   h->ev_flip = 0;
@@ -1193,6 +1194,26 @@ extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
   if (int rc = launch_tracer(h)) return rc;
   return step_end(h);
 }
+extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
+extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
+extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on);
+// One call per time step for a device-resident loop: what the Python TimeLoop does with six (at 0.2 ms per step of a
+// small slab the host's share counts).  mixing: forward step (t(tau-1) := t(tau), c2dtts = dtts); mobi_ahead, iso_ahead:
+// start the look-ahead chains of the NEXT step (only when that one is a leapfrog step with c2dtts_next and, for MOBI,
+// keeps this step's surface forcing).  The caller then exchanges halo rows if it has neighbours, and calls
+// uvic_gpu_rotate (which also ends a forward step's aliasing).
+extern "C" int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, int iso_ahead) {
+  if (!h) return fail_msg("null handle");
+  if (int rc = uvic_gpu_set_mixing(h, mixing)) return rc;
+  h->ctx.c2dtts = c2dtts;
+  if (int rc = uvic_gpu_step_async(h)) return rc;
+  if (mobi_ahead && h->have_mobi)
+    if (int rc = uvic_gpu_prefetch_sources(h, c2dtts_next)) return rc;
+  if (iso_ahead && !h->ctx.diff_cbt_given)
+    if (int rc = uvic_gpu_prefetch_isopyc(h)) return rc;
+  h->unmix_at_rotate = mixing != 0;
+  return 0;
+}
 // MOBI sources of the NEXT step from t(tau) (= next step's t(tau-1) on a leapfrog step) on
 // the side stream, overlapped with this step's transport.  Call before (preferred: its kernels are then queued ahead of this step's side-stream work) or after uvic_gpu_step_async
 // and before uvic_gpu_rotate; only valid when the next step is a leapfrog step.
@@ -1334,6 +1355,7 @@ extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
 extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   h->step_begun = false;
+  if (h->unmix_at_rotate) { h->mixing = false; h->unmix_at_rotate = false; }
   h->ev_flip ^= 1;
   h->end_ready = h->end_pending;
   h->ev_end_ready = h->ev_end_pending;

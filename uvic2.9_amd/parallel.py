@@ -173,10 +173,14 @@ class SlabShard:
         check(model.lib.uvic_gpu_halo_pack(model.h, int(has_s), int(has_n)), "halo_pack")
         pairs = ([(south, send_s, recv_s)] if has_s else []) + ([(north, send_n, recv_n)] if has_n else [])
         if dist.get_backend() == "nccl":
-            ops = []
-            for peer, sb, rb in pairs:
-                ops.append(dist.P2POp(dist.isend, sb, peer))
-                ops.append(dist.P2POp(dist.irecv, rb, peer))
+            key = ("ops", south if has_s else None, north if has_n else None)
+            ops = self._views.get(key)
+            if ops is None:                         # the same buffers and peers every step: built once
+                ops = []
+                for peer, sb, rb in pairs:
+                    ops.append(dist.P2POp(dist.isend, sb, peer))
+                    ops.append(dist.P2POp(dist.irecv, rb, peer))
+                self._views[key] = ops
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         else:                                       # rehearsal backend: staged through the host
@@ -196,6 +200,10 @@ class SlabShard:
     def step(self, model):
         """One device-resident step of the slab and the halo exchange (no host sync with RCCL)."""
         model.step_async()
+        self.after_step(model)
+
+    def after_step(self, model):
+        """The halo exchange of t(tau+1), queued behind the step on the library's stream."""
         if self.world == 1:
             return
         import torch

@@ -276,6 +276,19 @@ class TimeLoop:
         m = self.m
         self.itt += 1
         mixing = self._mixing(self.itt)
+        if self.shard is None or hasattr(self.shard, "after_step"):
+            # one C call per step (uvic_gpu_step_lookahead), then the halo exchange of a latitude slab, then the rotation
+            ahead = self.prefetch and not self._mixing(self.itt + 1)
+            mobi_ahead = ahead and m.has_mobi and not (self.segment > 0 and self.itt % self.segment == 0)
+            iso_ahead = ahead and not m.params.diff_cbt_has_k33
+            c2dtts = self.dtts if mixing else 2.0 * self.dtts
+            check(m.lib.uvic_gpu_step_lookahead(m.h, c2dtts, int(mixing), int(mobi_ahead), 2.0 * self.dtts, int(iso_ahead)),
+                  "step_lookahead")
+            m.params.c2dtts = c2dtts          # the mirror of uvic_params follows
+            if self.shard is not None:
+                self.shard.after_step(m)
+            m.rotate()
+            return
         m.set_mixing(mixing)
         m.set_params(c2dtts=self.dtts if mixing else 2.0 * self.dtts)
         if self.shard is not None:
