@@ -805,14 +805,17 @@ UVIC_DEV void mobi_src(Team &T, mobi_params_cp P, const mobi_step &S, double *bi
 // co2calc_SWS (called at mobi.F:772 for every level) needs T, S, DIC and alkalinity of the
 // cell only; of its outputs option set C uses CO2* through the 13C fractionation factor
 // ac13b = ac13_aq_POC / ac13_DIC_aq (mobi.F:775-789).  Light: tracer.F:381-390, mobi.F:735-760.
-UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
+// `part`: 0 = everything (host emulation, one thread per cell), 1 = the carbonate chemistry alone, 2 = the rest.  The
+// two halves share nothing but their inputs, so the device gives each cell two threads: on a small latitude slab,
+// where the pass is one round of waves, its latency (the head of the MOBI chain that bounds multi-GPU scaling) halves.
+UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j, int part = 0) {
   UV_MOBI_LOCALS(c, M);
   if (k > c.kmt[ij]) return;
   const double t_in = TM(k, P->itemp);
   const double s_in = 1.e3 * TM(k, P->isalt) + 35.0;
   const double dic_in = TM(k, P->idic), alk_in = TM(k, P->ialk);
   const double o2_in = TM(k, P->io2) * 1000.;
-  {
+  if (part != 2) {
     const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
     double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
     mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3,
@@ -821,6 +824,7 @@ UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, 
     const double ac13_aq_POC = -0.017 * log10(dmin(dmax(co2star * 1000., 2.), 74.)) + 1.0034;
     PRE(MP_AC13B) = ac13_aq_POC / ac13_DIC_aq;
   }
+  if (part == 1) return;
   // light geometry, tracer.F:381-390
   const double ai = M.aice[ij], hi = M.hice[ij], hs = M.hsno[ij];
   double rctheta = dmax(-1.5, dmin(1.5, M.tlat[ij] / M.radian - S.declin));

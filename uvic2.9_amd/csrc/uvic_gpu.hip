@@ -189,11 +189,14 @@ __global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c, const W
 }
 // cell-parallel MOBI passes: thread = (ocean column, level), columns fastest
 __global__ void __launch_bounds__(128) k_mobi_pre(const uvic_ctx c, const mobi_dev m, const WetCols w) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  // two threads per cell: the first half of the grid does the carbonate chemistry, the second the rest (whole waves each)
+  const int half = (int)((gridDim.x + 1) / 2);
+  const int part = blockIdx.x < half ? 1 : 2;
+  const int gid = (blockIdx.x - (part == 2 ? half : 0)) * blockDim.x + threadIdx.x;
   const int k = gid / w.count + 1;
   if (k > c.km) return;
   WET_DECODE(w, gid % w.count);
-  mobi_pre_cell(c, m, i, k, j);
+  mobi_pre_cell(c, m, i, k, j, part);
 }
 __global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1034,7 +1037,7 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
   if (int rc = src_clean(h, (void *)c.src, st)) return rc;
   mark_on(h, "begin", sid);
   const unsigned cells = (unsigned)(((long long)w.count * c.km + 127) / 128), cols = (unsigned)((w.count + 63) / 64);
-  if (w.count > 0) hipLaunchKernelGGL(k_mobi_pre, dim3(cells), dim3(128), 0, st, c, m, w);
+  if (w.count > 0) hipLaunchKernelGGL(k_mobi_pre, dim3(2 * cells), dim3(128), 0, st, c, m, w);   // two threads per cell
   mark_on(h, "mobi_pre", sid);
   if (w.count > 0) {
     if (h->mobi_team)
