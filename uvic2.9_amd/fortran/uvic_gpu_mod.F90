@@ -136,6 +136,14 @@
           integer(c_int64_t), value :: bytes
           integer(c_int) :: rc
         end function
+        function uvic_gpu_step_lookahead(h, c2dtts, mixing, mobi_ahead, c2dtts_next, iso_ahead)              &
+     &      bind(C,name='uvic_gpu_step_lookahead') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double), value :: c2dtts, c2dtts_next
+          integer(c_int), value :: mixing, mobi_ahead, iso_ahead
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_set_mixing(h, on) bind(C,name='uvic_gpu_set_mixing') result(rc)
           import
           type(c_ptr), value :: h
