@@ -931,6 +931,12 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (w.count > 0)
         hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side_ts, cts, w);
       mark_on(h, "convect_ts", 3);
+      // one barrier packet less on the main stream (~8 us each): the side stream waits for the sources as well before it
+      // signals, and the main stream waits for that one event
+      if (h->src_from_prefetch) {
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_src_ready, 0));
+        h->src_from_prefetch = false;
+      }
       HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
       h->ts_ahead = true;
       // the other tracers on the main stream: work arrays are indexed from the group's first tracer
