@@ -51,7 +51,13 @@ enum {
 // 16 Ai planes through memory).  Column-kernel path only; Ai_* are not stored.  i = 2..imt-1,
 // k = 1..km, j = 1..jmt-1.
 // ---------------------------------------------------------------------------
+#if defined(__HIPCC__) && !defined(UV_NO_CONTRACT)
+#define UV_FAST_FP _Pragma("clang fp contract(fast)")
+#else
+#define UV_FAST_FP
+#endif
 UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
+  UV_FAST_FP
   UV_DIMS(c);
   const size_t q = X3(i, k, j);
   const double sc = 1.0 / (c.slmxr * c.dtxsqr[k - 1]);
@@ -162,8 +168,19 @@ UVIC_DEV void coef_bv_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
 }
 
 #if defined(__HIPCC__)
+// The column kernels are tolerance-tested (1e-13 one step), not bit-exact: mul+add pairs may fuse here.  The
+// library is built -ffp-contract=off for the exact kernels (kernels_fct.hpp, kernels_isopyc.hpp); the pragma
+// holds until the matching contract(off) at the end of this block.  -DUV_NO_CONTRACT: measurement only.
+#ifndef UV_NO_CONTRACT
+#pragma clang fp contract(fast)
+#endif
+// The work list of a pass: `pairs` = (row, 60-column segment) codes (row | seg << 16) built on the host from kmt
+// (uvic_gpu.hip: build_col_pairs).  Pass A lists only segments that hold ocean, row-major, so that no wave is
+// launched for the polar caps and each XCD's contiguous share of the list is the same amount of work; pass B lists
+// every segment of the slab (land ones store zeros), ordered (segment, row).
 struct ColGrid {
-  int r0, nrows, nseg, total;  // total = nrows * nt_local * nseg work items (one wave each)
+  const int *pairs;
+  int npairs, total;           // total = npairs * nt_local work items (one wave each)
   int fuse_convect;            // pass B: replay the convective mixing found by the T,S walk before t(tau+1) is stored
 };
 #define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
@@ -235,15 +252,15 @@ __device__ __forceinline__ void bst2(brsrc r, unsigned voff, int soff, double a,
 __device__ __forceinline__ double fmx(double a, double b) { return __builtin_fmax(a, b); }
 __device__ __forceinline__ double fmn(double a, double b) { return __builtin_fmin(a, b); }
 __device__ __forceinline__ double upstream(double v, double a, double b) { return v * (a + b) + dabs(v) * (a - b); }
-__device__ __forceinline__ double limited(double cpos, double cneg, double f) {
-  return 0.5 * ((cpos + cneg) * f + (cpos - cneg) * dabs(f));
-}
+// 0.5*((cpos+cneg)*f + (cpos-cneg)*|f|) of adv_flx:703-705 is cpos*f for f >= 0 and cneg*f otherwise: compare,
+// select, one multiplication instead of six operations (equal to rounding, not bit for bit)
+__device__ __forceinline__ double limited(double cpos, double cneg, double f) { return ((f >= 0.0) ? cpos : cneg) * f; }
 // x / y for the limiter ratios.  x is finite, y = P + epsln lies in [1e-20, ~1e6]: the range handling of the IEEE
-// division sequence (two v_div_scale, v_div_fmas, v_div_fixup) is dead weight here.  v_rcp_f64, two Newton steps
-// and one correction of the quotient: 8 instructions instead of 12, result within 1 ulp of x / y.
+// division sequence (two v_div_scale, v_div_fmas, v_div_fixup) is dead weight here.  v_rcp_f64 (relative error
+// 2^-23), ONE Newton step (2^-46) and one correction of the quotient (error (2^-46)^2, below the final rounding):
+// 6 instructions instead of 12, result within 1 ulp of x / y.
 __device__ __forceinline__ double div_pos(double x, double y) {
   double r = __builtin_amdgcn_rcp(y);
-  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
   const double q = x * r;
   return __builtin_fma(__builtin_fma(-y, q, x), r, q);
@@ -258,29 +275,27 @@ __device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, do
   rm = fmn(1., div_pos(mask * (tlo - trmin), pminus + UV_EPSLN));
 }
 
+__device__ __forceinline__ void col_pair(const uvic_ctx &c, const ColGrid &g, int pair, int &r, int &i0, int &i1) {
+  const int code = ((const __attribute__((address_space(4))) int *)g.pairs)[pair];   // wave-uniform: a scalar load
+  r = code & 0xffff;
+  i0 = 2 + (code >> 16) * COL_OWN;
+  i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
+}
 __device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
   if (item >= g.total) return false;
   // tracer index fastest: the four waves of a workgroup work on four tracers of the same
   // row and longitude segment and share its coefficient lines in L1
   n1 = c.n0 + item % c.nt_local + 1;
-  const int rest = item / c.nt_local;
-  const int seg = rest % g.nseg;
-  r = g.r0 + rest / g.nseg;
-  i0 = 2 + seg * COL_OWN;
-  i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
+  col_pair(c, g, item / c.nt_local, r, i0, i1);
   return true;
 }
-// pass B order: latitude row fastest, so the four waves of a workgroup (and the workgroups next to it)
-// work on adjacent rows of ONE tracer: rows r-1, r, r+1 of t, R+-Y that a wave reads are the centre
-// rows of its neighbours and come from L1/L2 instead of being fetched three times
+// pass B order: latitude row fastest, so the workgroups next to each other work on adjacent rows of ONE tracer:
+// rows r-1, r, r+1 of t, R+-Y that a wave reads are the centre rows of its neighbours and come from L1/L2 instead
+// of being fetched three times
 __device__ __forceinline__ bool col_decode_rows(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
   if (item >= g.total) return false;
-  r = g.r0 + item % g.nrows;
-  const int rest = item / g.nrows;
-  const int seg = rest % g.nseg;
-  n1 = c.n0 + rest / g.nseg + 1;
-  i0 = 2 + seg * COL_OWN;
-  i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
+  n1 = c.n0 + item / g.npairs + 1;
+  col_pair(c, g, item % g.npairs, r, i0, i1);
   return true;
 }
 __device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..imt-1, cyclic
@@ -549,12 +564,12 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
     if (k == kb) f = z - botbc * tdt * t_dztr.at(k - 1) * aidif * mk;
     double znew;
     if (k == 1) {
-      bet = mk / (b + eps);
+      bet = div_pos(mk, b + eps);   // the pivots of this diagonally dominant system are >= 1 (a, c <= 0, b = 1 - a - c)
       znew = f * bet;
     } else {
       const double e = cprev * bet;
       ework[(size_t)k * 64 + lane] = e;
-      bet = mk / (b - a * e + eps);
+      bet = div_pos(mk, b - a * e + eps);
       znew = (f - a * zprev) * bet;
     }
     zwork[(size_t)k * 64 + lane] = znew;
@@ -595,6 +610,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
       zn = zk;
     }
     for (int sg = 1; sg <= ncv; ++sg) {
+#pragma clang fp contract(off)   /* the same bits as convect_apply_cell, whichever of the two runs (tests/test_gpu_fast.py) */
       const int kt = c.cv_kt[X3(i, sg, r)], kb = c.cv_kb[X3(i, sg, r)];
       const double zsm = c.cv_z[X3(i, sg, r)];
       double tsm3 = 0.0;
@@ -627,6 +643,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
 #undef AT
 #undef OC
 #undef RPM
+#pragma clang fp contract(off)
 #endif  // __HIPCC__
 
 }  // namespace uvic

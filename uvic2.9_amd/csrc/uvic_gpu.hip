@@ -6,6 +6,7 @@
 // reference does on its own errors (updates/09/source/mom/tracer.F:1250).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -370,6 +371,11 @@ struct uvic_gpu {
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
   int *wet_dev;
   std::vector<int> wet_row_start;
+  // work lists of the column passes (ColGrid): (row, segment) codes of the current slab, rebuilt when kmt or the slab changes
+  std::vector<int> kmt_host;
+  int *pairs_dev;            // pass A list (segments with ocean, row-major) followed by the pass B list (all, segment-major)
+  int npairs_a, npairs_b;
+  bool pairs_dirty;
   // latitude-slab halo staging (uvic_gpu_halo_*): send south/north, receive south/north, each UVIC_HALO rows of every tracer
   double *halo[4];
   // source buffers known to hold zeros on land (MOBI writes ocean columns only): see src_clean()
@@ -498,6 +504,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->have_vmix = false;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
   h->wet_dev = nullptr;
+  h->pairs_dev = nullptr; h->npairs_a = h->npairs_b = 0; h->pairs_dirty = true;
   for (int q = 0; q < 4; ++q) h->halo[q] = nullptr;
   h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
@@ -625,6 +632,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->coef);
   (void)hipFree(h->rpm);
   (void)hipFree(h->wet_dev);
+  (void)hipFree(h->pairs_dev);
   for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
@@ -683,6 +691,8 @@ static int make_tmask(uvic_gpu *h) {
   const int imt = h->d.imt, jmt = h->d.jmt;
   std::vector<int> kmt((size_t)imt * jmt), wet;
   HIPCHK(hipMemcpy(kmt.data(), h->buf[UVIC_F_KMT], kmt.size() * 4, hipMemcpyDeviceToHost));
+  h->kmt_host = kmt;
+  h->pairs_dirty = true;
   h->wet_row_start.assign((size_t)jmt + 2, 0);
   for (int j = 1; j <= jmt; ++j) {
     h->wet_row_start[j] = (int)wet.size();
@@ -699,6 +709,35 @@ static int make_tmask(uvic_gpu *h) {
   // all-land waves of pass A leave R+- alone
   HIPCHK(hipMemsetAsync(h->rpm, 0, (size_t)imt * h->d.km * jmt * 16 * (size_t)h->d.nt, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// Work lists of the column passes for the slab js..je (kernels_col.hpp: ColGrid).  Pass A covers one row beyond the slab
+// on each side and lists only the 60-column segments that hold ocean (the others leave R+- at zero); pass B lists every
+// segment of the slab, ocean or not (a land segment stores zeros).
+static int build_col_pairs(uvic_gpu *h) {
+  if (!h->pairs_dirty) return 0;
+  const int imt = h->d.imt, jmt = h->d.jmt;
+  const uvic_ctx &c = h->ctx;
+  const int nseg = (imt - 2 + COL_OWN - 1) / COL_OWN;
+  std::vector<int> pa, pb;
+  const bool have_kmt = h->kmt_host.size() == (size_t)imt * jmt;
+  const int ra0 = c.js - 1 < 2 ? 2 : c.js - 1, ra1 = c.je + 1 > jmt - 1 ? jmt - 1 : c.je + 1;
+  for (int r = ra0; r <= ra1; ++r)
+    for (int seg = 0; seg < nseg; ++seg) {
+      bool ocean = c.no_landskip || !have_kmt;
+      const int i0 = 2 + seg * COL_OWN, i1 = std::min(i0 + COL_OWN - 1, imt - 1);
+      for (int i = i0; i <= i1 && !ocean; ++i) ocean = h->kmt_host[(size_t)(i - 1) + (size_t)imt * (r - 1)] > 0;
+      if (ocean) pa.push_back(r | (seg << 16));
+    }
+  for (int seg = 0; seg < nseg; ++seg)
+    for (int r = c.js; r <= c.je; ++r) pb.push_back(r | (seg << 16));
+  (void)hipFree(h->pairs_dev);
+  h->pairs_dev = nullptr;
+  HIPCHK(hipMalloc((void **)&h->pairs_dev, (pa.size() + pb.size() + 1) * 4));
+  if (!pa.empty()) HIPCHK(hipMemcpy(h->pairs_dev, pa.data(), pa.size() * 4, hipMemcpyHostToDevice));
+  if (!pb.empty()) HIPCHK(hipMemcpy(h->pairs_dev + pa.size(), pb.data(), pb.size() * 4, hipMemcpyHostToDevice));
+  h->npairs_a = (int)pa.size(); h->npairs_b = (int)pb.size();
+  h->pairs_dirty = false;
   return 0;
 }
 // the ocean columns of rows js..je
@@ -823,6 +862,7 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
   if (!h) return fail_msg("uvic_gpu_set_shard: null handle");
   if (n0 < 0 || nt_local < 0 || n0 + nt_local > h->d.nt) return fail_msg("uvic_gpu_set_shard: tracer range outside 1..nt");
   if (js < 2 || je > h->d.jmt - 1 || js > je) return fail_msg("uvic_gpu_set_shard: row range outside 2..jmt-1");
+  if (js != h->ctx.js || je != h->ctx.je) h->pairs_dirty = true;
   h->ctx.n0 = n0; h->ctx.nt_local = nt_local; h->ctx.js = js; h->ctx.je = je;
   return 0;
 }
@@ -887,14 +927,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   if (c.nt_local <= 0) return 0;
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
   if (!h->exact) {  // lane-per-column path
+    if (int rc = build_col_pairs(h)) return rc;
     ColGrid a, b;
-    a.r0 = c.js - 1 < 2 ? 2 : c.js - 1;
-    const int ra = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
-    a.nrows = ra - a.r0 + 1;
-    a.nseg = (c.imt - 2 + COL_OWN - 1) / COL_OWN;
-    a.total = a.nrows * c.nt_local * a.nseg;
-    b = a;
-    b.r0 = c.js; b.nrows = c.je - c.js + 1; b.total = b.nrows * c.nt_local * b.nseg;
+    a.pairs = h->pairs_dev; a.npairs = h->npairs_a; a.total = a.npairs * c.nt_local;
+    b.pairs = h->pairs_dev + h->npairs_a; b.npairs = h->npairs_b; b.total = b.npairs * c.nt_local;
     double *S = h->work[3];
     a.fuse_convect = b.fuse_convect = 0;
     const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
@@ -920,10 +956,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       cts.nt_local = 2;
       cts.prio |= 2;
       ColGrid ats = a, bts = b;
-      ats.total = ats.nrows * 2 * ats.nseg;
-      bts.total = bts.nrows * 2 * bts.nseg;
+      ats.total = ats.npairs * 2;
+      bts.total = bts.npairs * 2;
       mark_on(h, "begin", 3);
-      hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+      if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       mark_on(h, "colfct_ts", 3);
       hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
       mark_on(h, "colupd_ts", 3);
@@ -945,11 +981,11 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       cr.n0 = 2; cr.nt_local = c.nt - 2;
       cr.Rpm = c.Rpm + 2 * N3 * 2;
       ColGrid ar = a, br = b;
-      ar.total = ar.nrows * cr.nt_local * ar.nseg;
-      br.total = br.nrows * cr.nt_local * br.nseg;
+      ar.total = ar.npairs * cr.nt_local;
+      br.total = br.npairs * cr.nt_local;
       br.fuse_convect = 1;
       mark(h, "begin");
-      hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ar)), dim3(64, 4), 0, h->stream, cr, (const double *)h->coef, S + 2 * N3, ar);
+      if (ar.total > 0) hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ar)), dim3(64, 4), 0, h->stream, cr, (const double *)h->coef, S + 2 * N3, ar);
       mark(h, "colfct");
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
@@ -959,7 +995,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
     } else {
       mark(h, "begin");
-      hipLaunchKernelGGL(k_colfct, dim3(blocks_a(a)), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+      if (a.total > 0) hipLaunchKernelGGL(k_colfct, dim3(blocks_a(a)), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
       mark(h, "colfct");
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
