@@ -3,13 +3,18 @@
 // Same physics as kernels_fct.hpp (FCT adv_flux, isoflux, explicit update,
 // invtri; reference lines cited there), laid out for the CDNA4 wavefront:
 //
-//   one wave  = one latitude row r of one tracer, 64 adjacent columns
-//   one lane  = one (i) column; the lane marches down k = 1..km keeping the
-//               k-1,k,k+1 window of both time levels in registers
-//   x-neighbours come from the adjacent lanes by DPP shuffles (`__shfl_up/down`),
-//   rows r-1, r+1 from the lane's own coalesced loads; no LDS, no barriers.
-//   The two edge lanes on each side are halo (60 owned columns per wave),
-//   longitude wraps cyclically.
+//   one lane  = one (i, r) ocean column of one tracer; the lane marches down k = 1..km keeping
+//               the k-1,k,k+1 window of both time levels in registers
+//   one wave  = 64 lanes taken from a host-built LANE MAP (uvic_gpu.hip: build_col_lanes): the
+//               ocean columns of the slab row by row, so that lanes are adjacent columns of a row
+//               wherever the sea is; land columns, the polar caps and the padding of a fixed
+//               60-column segmentation get no lanes at all
+//   pass A: x-neighbours come from the adjacent lanes by DPP whole-wave shifts, so every run of
+//               adjacent ocean columns carries two halo lanes on each side (not owned: they
+//               compute, their results are not stored); a wave may hold pieces of several runs
+//               and rows.  Rows r-1, r+1 come from the lane's own coalesced loads; no LDS, no
+//               barriers.  Longitude wraps cyclically.
+//   pass B: no neighbour exchange at all: the lanes are the ocean columns and nothing else.
 //
 // The isopycnal flux terms are linear in the tracer with coefficients that do not
 // depend on the tracer: `ai_coef_cell` folds Ai * slope (and metric factors, masks,
@@ -174,16 +179,17 @@ UVIC_DEV void coef_bv_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
 #ifndef UV_NO_CONTRACT
 #pragma clang fp contract(fast)
 #endif
-// The work list of a pass: `pairs` = (row, 60-column segment) codes (row | seg << 16) built on the host from kmt
-// (uvic_gpu.hip: build_col_pairs).  Pass A lists only segments that hold ocean, row-major, so that no wave is
-// launched for the polar caps and each XCD's contiguous share of the list is the same amount of work; pass B lists
-// every segment of the slab (land ones store zeros), ordered (segment, row).
+// The work list of a pass: `lanes` holds one code per lane, 64 per wave: column i (bits 0-11), row r (bits 12-23),
+// bit 24 = owned (the lane stores what it computes), built on the host from kmt (uvic_gpu.hip: build_col_lanes).
+// Lanes that are not owned hold a valid (i, r) all the same, so that every address stays inside its buffer.
 struct ColGrid {
-  const int *pairs;
-  int npairs, total;           // total = npairs * nt_local work items (one wave each)
+  const int *lanes;
+  int nwaves, total;           // total = nwaves * nt_local work items (one wave each)
   int fuse_convect;            // pass B: replay the convective mixing found by the T,S walk before t(tau+1) is stored
 };
-#define COL_OWN 60  // owned columns per wave (64 lanes - 2x2 halo)
+#define COL_LANE_I(code) ((code) & 0xfff)
+#define COL_LANE_R(code) (((code) >> 12) & 0xfff)
+#define COL_LANE_OWNED(code) (((code) >> 24) & 1)
 #define COLUPD_WAVES 1  // waves per workgroup of pass B: 2 x (km+1) x 512 B of LDS each (20 KB at km = 19), so that workgroups still fit beside a MOBI team (90 KB) on a CU
 
 // Neighbour exchange by DPP whole-wave shifts (gfx9 `wave_shr:1` / `wave_shl:1`): one
@@ -275,45 +281,30 @@ __device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, do
   rm = fmn(1., div_pos(mask * (tlo - trmin), pminus + UV_EPSLN));
 }
 
-__device__ __forceinline__ void col_pair(const uvic_ctx &c, const ColGrid &g, int pair, int &r, int &i0, int &i1) {
-  const int code = ((const __attribute__((address_space(4))) int *)g.pairs)[pair];   // wave-uniform: a scalar load
-  r = code & 0xffff;
-  i0 = 2 + (code >> 16) * COL_OWN;
-  i1 = imin(i0 + COL_OWN - 1, c.imt - 1);
-}
-__device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
+// pass A order: tracer index fastest, so the four waves of a workgroup work on four tracers of the same lanes
+// and share their coefficient lines in L1
+__device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &code, int &n1) {
   if (item >= g.total) return false;
-  // tracer index fastest: the four waves of a workgroup work on four tracers of the same
-  // row and longitude segment and share its coefficient lines in L1
   n1 = c.n0 + item % c.nt_local + 1;
-  col_pair(c, g, item / c.nt_local, r, i0, i1);
+  code = g.lanes[(size_t)(item / c.nt_local) * 64 + threadIdx.x];
   return true;
 }
-// pass B order: latitude row fastest, so the workgroups next to each other work on adjacent rows of ONE tracer:
-// rows r-1, r, r+1 of t, R+-Y that a wave reads are the centre rows of its neighbours and come from L1/L2 instead
-// of being fetched three times
-__device__ __forceinline__ bool col_decode_rows(const uvic_ctx &c, const ColGrid &g, int item, int &r, int &n1, int &i0, int &i1) {
+// pass B order: the waves of one tracer next to each other (rows ascending), so that rows r-1, r, r+1 of t, R+-Y
+// that a wave reads are the centre rows of its neighbours and come from L1/L2 instead of being fetched three times
+__device__ __forceinline__ bool col_decode_rows(const uvic_ctx &c, const ColGrid &g, int item, int &code, int &n1) {
   if (item >= g.total) return false;
-  n1 = c.n0 + item / g.npairs + 1;
-  col_pair(c, g, item % g.npairs, r, i0, i1);
+  n1 = c.n0 + item / g.nwaves + 1;
+  code = g.lanes[(size_t)(item % g.nwaves) * 64 + threadIdx.x];
   return true;
 }
-__device__ __forceinline__ int col_wrap(int x, int imt) {  // any integer -> 2..imt-1, cyclic
-  const int p = imt - 2;
-  int y = (x - 2) % p;
-  if (y < 0) y += p;
-  return y + 2;
-}
-
 // ===========================================================================
 // pass A: one sweep down the column
 // ===========================================================================
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
-                                            int r, int n1, int i0, int i1) {
+                                            int code, int n1) {
   UV_DIMS(c);
-  const int lane = threadIdx.x;
-  const int i = col_wrap(i0 - 2 + lane, imt);
-  const bool owned = lane >= 2 && lane <= 2 + (i1 - i0);
+  const int i = COL_LANE_I(code), r = COL_LANE_R(code);
+  const bool owned = COL_LANE_OWNED(code) != 0;
   const size_t nloc = (size_t)(n1 - 1 - c.n0);
   const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
@@ -323,34 +314,34 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   LaneTable t_dzt2r, t_dtxcel, t_dztr;
   t_dzt2r.load(c.dzt2r, km); t_dtxcel.load(c.dtxcel, km); t_dztr.load(c.dztr, km);
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)], kz_n = c.kmt[X2(i, r + 1)];
-  // no ocean among the owned columns: R+- of land is zero and stays zero (the buffer is cleared with kmt), and
-  // pass B does not read S of a segment it skips on the same test
-  if (!c.no_landskip && __builtin_amdgcn_ballot_w64(owned && kz > 0) == 0) return;
+  // across the seam between two runs of the lane map the neighbour is not the x-neighbour: only halo lanes look there
   const int kz_w = dpp_i<DPP_WAVE_SHR1>(kz), kz_e = dpp_i<DPP_WAVE_SHL1>(kz);
-  const double cstr_r = kload(c.cstr, r - 1);
+  const double cstr_r = c.cstr[r - 1];
   const double cstdxt2r = cstr_r * c.dxtr[i - 1] * 0.5, cstdxtr = cstr_r * c.dxtr[i - 1];
-  const double cstdyt2r = kload(c.cstdyt2r, r - 1), cstdytr = kload(c.cstdytr, r - 1);
+  const double cstdyt2r = c.cstdyt2r[r - 1], cstdytr = c.cstdytr[r - 1];
+  const bool south_wall = (r - 1 == 1);   // no antidiffusive flux through the face to row 1 (adv_flx: jstrt)
   const double c2dtts = c.c2dtts;
   const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
   const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
-  // addresses = buffer descriptor + wave-uniform byte offset (one scalar register) + the lane's 32-bit column offset
+  // addresses = buffer descriptor + wave-uniform byte offset (one scalar register: level and row shift) + the lane's
+  // 32-bit offset of its (i, r) column
   const int rowstride = imt * km;
-  const int rbase = (r - 1) * rowstride;        // level k of row r starts at element rbase + (k-1)*imt
-  const unsigned lb = (unsigned)(i - 1) * 8u;   // the lane's byte offset within a row of a level
-  const unsigned lb2 = (unsigned)(i - 1) * 16u;
+  // (the lane offset points at row r-1, so that the scalar offset is never negative: the hardware adds it unsigned)
+  const unsigned lb = (unsigned)((r - 2) * rowstride + (i - 1)) * 8u;   // level 1 of column i of row r-1, cell fields
+  const unsigned lb2 = lb * 2u;
+  const unsigned lbf = (unsigned)((r - 1) * imt * (km + 1) + (i - 1)) * 8u;   // face 0 of the lane's column, face fields
   const brsrc b_tm = mkbuf(tm, N3 * 8), b_tt = mkbuf(tt, N3 * 8), b_te = mkbuf(c.tot_e, N3 * 8), b_tn = mkbuf(c.tot_n, N3 * 8);
   const brsrc b_tb = mkbuf(c.tot_b, NF * 8), b_vb = mkbuf(c.adv_vbt, NF * 8);
   const brsrc b_cf = mkbuf(cf, N3 * 16 * CF_PAIRS), b_S = mkbuf(Sn, N3 * 8), b_R = mkbuf(Rpm, N3 * 16);
-#define OC(k, dj) ((rbase + ((k)-1) * imt + (dj) * rowstride) * 8)   /* byte offset of level k of row r+dj */
+#define OC(k, dj) (((((k)-1) * imt + ((dj) + 1) * rowstride)) * 8)   /* byte offset of level k of row r+dj from the lane's offset */
 #define LD(b, k, dj) bld(b_##b, lb, OC(k, dj))
-#define CFP(pair, k, dj) bld2(b_cf, lb2, ((int)(pair) * (int)N3 + rbase + ((k)-1) * imt + (dj) * rowstride) * 16)
-  const int fbase = (r - 1) * imt * (km + 1);  // face k of row r starts at element fbase + k*imt
-#define OF(kf) ((fbase + (kf) * imt) * 8)
+#define CFP(pair, k, dj) bld2(b_cf, lb2, ((int)(pair) * (int)N3 + ((k)-1) * imt + ((dj) + 1) * rowstride) * 16)
+#define OF(kf) (((kf) * imt) * 8)
   double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
   double tc0, tc1;                                                        // levels s-1 and s of t(tau)
   tc0 = tc1 = LD(tt, 1, 0);
   // surface faces
-  const double vb0 = bld(b_vb, lb, OF(0));
+  const double vb0 = bld(b_vb, lbf, OF(0));
   double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
   double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
   double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
@@ -367,7 +358,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1), tc2 = LD(tt, sp, 0);
     const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
     const double ve = LD(te, s, 0), vn = LD(tn, s, 0), vs = LD(tn, s, -1);
-    const double vb = (s < km) ? bld(b_tb, lb, OF(s)) : bld(b_vb, lb, OF(km));
+    const double vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
     double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
     _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
       const double2 v = CFP(p, s, 0);
@@ -405,7 +396,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     }
     {
       const double afn_n = vn * (tt_c + t_n) - fnlo_n;
-      const double afn_s = (r - 1 == 1) ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
+      const double afn_s = south_wall ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
       fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
                 ryp, rym);
     }
@@ -474,24 +465,15 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 // `ework` is the wave's LDS scratch: e(k) and z(k) of the Thomas recurrence, each (km+1) x 64 doubles laid out
 // [k][lane], so that the forward sweep writes t(tau+1) nowhere and the back substitution stores it once
 // ===========================================================================
-__device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int r, int n1,
-                                            int i0, int i1, int fuse_convect) {
+__device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int code, int n1,
+                                            int fuse_convect) {
   UV_DIMS(c);
   const int lane = threadIdx.x;
-  const int i = i0 + lane;
+  const int i = COL_LANE_I(code), r = COL_LANE_R(code);
   LaneTable t_dtxcel, t_dztur, t_dztlr, t_dztr;   // filled while every lane is still active
   t_dtxcel.load(c.dtxcel, c.km); t_dztur.load(c.dztur, c.km); t_dztlr.load(c.dztlr, c.km); t_dztr.load(c.dztr, c.km);
-  const bool any_ocean = __builtin_amdgcn_ballot_w64(i <= i1 && c.kmt[X2(imin(i, i1), r)] > 0) != 0;
-  if (i > i1) return;
-  if (!any_ocean && !c.no_landskip) {   // a segment of land: t(tau+1) = 0 there (the update is masked, tracer.F:1109-1130), nothing to read
-    double *tp0 = c.t_taup1 + (size_t)(n1 - 1) * N3;
-    const int ic0 = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
-    for (int k = 1; k <= km; ++k) {
-      tp0[X3(i, k, r)] = 0.0;
-      if (ic0) tp0[X3(ic0, k, r)] = 0.0;
-    }
-    return;
-  }
+  // the lanes are ocean columns; land keeps the zeros it was given once (uvic_gpu.hip: land_clean)
+  if (!COL_LANE_OWNED(code)) return;   // padding of the last wave
   const size_t nloc = (size_t)(n1 - 1 - c.n0);
   const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
   const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
@@ -503,11 +485,12 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   const double *source = 0;
   if (c.src && c.itrc[n1 - 1] != 0) source = c.src + (size_t)(c.itrc[n1 - 1] - 1) * N3;
   const int kz = c.kmt[X2(i, r)], kz_s = c.kmt[X2(i, r - 1)];
-  const double cstdyt2r = kload(c.cstdyt2r, r - 1);
+  const double cstdyt2r = c.cstdyt2r[r - 1];
+  const bool south_wall = (r - 1 == 1);
   const int rowstride = imt * km;
-  const int rbase = (r - 1) * rowstride;   // wave-uniform part of every address; the lane adds its 32-bit column offset
-  const unsigned lb = (unsigned)(i - 1) * 8u, lb2 = (unsigned)(i - 1) * 16u;
-#define OC(k, dj) ((rbase + ((k)-1) * imt + (dj) * rowstride) * 8)
+  // the lane's column in row r-1; the scalar offset shifts level and row and is never negative (the hardware adds it unsigned)
+  const unsigned lb = (unsigned)((r - 2) * rowstride + (i - 1)) * 8u, lb2 = lb * 2u;
+#define OC(k, dj) (((((k)-1) * imt + ((dj) + 1) * rowstride)) * 8)
 #define AT(b, k, dj) bld(b, lb, OC(k, dj))
 #define RPM(k, dj) bld2(b_R, lb2, OC(k, dj) * 2)
   const double topbc = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt], botbc = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt];
@@ -545,7 +528,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
     const double mk = (k <= kz) ? 1.0 : 0.0, mk_s = (k <= kz_s) ? 1.0 : 0.0;
     const double lo_n = upstream(L.vn, m_c, L.m_n), lo_s = upstream(L.vs, L.m_s, m_c);
     const double f_n = L.vn * (t_c + L.t_n) - lo_n;
-    const double f_s = (r - 1 == 1) ? 0.0 : L.vs * (L.t_s + t_c) - lo_s;
+    const double f_s = south_wall ? 0.0 : L.vs * (L.t_s + t_c) - lo_s;
     const double fn_n = (limited(fmn(L.rpn, L.rm0), fmn(L.rp0, L.rmn), f_n) + lo_n) * mk;
     const double fn_s = (limited(fmn(L.rp0, L.rms), fmn(L.rps, L.rm0), f_s) + lo_s) * mk_s;
     const double ADV_Ty = (fn_n - fn_s) * cstdyt2r;

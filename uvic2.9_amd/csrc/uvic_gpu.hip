@@ -129,11 +129,11 @@ __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
 __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
-  int r, n1, i0, i1;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: row, tracer and segment live in scalar registers
-  if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, r, n1, i0, i1)) return;
+  int code, n1;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: the tracer and the wave of the lane map live in scalar registers
+  if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, code, n1)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colfct_wave(c, cf, S, r, n1, i0, i1);
+  colfct_wave(c, cf, S, code, n1);
 }
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body(c, cf, S, g); }
 // the same passes for T and S alone on the side stream: own names, so that a profile tells the two launches apart
@@ -141,11 +141,11 @@ __global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const doubl
 __device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, const ColGrid &g, double *lds) {
   const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
   const int blk = xcd_remap(blockIdx.x, nblk);
-  int r, n1, i0, i1;
+  int code, n1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, r, n1, i0, i1)) return;
+  if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, code, n1)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, r, n1, i0, i1, g.fuse_convect);
+  colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, code, n1, g.fuse_convect);
 }
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -279,6 +279,22 @@ __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m,
   mobi_column_kernel(c, m, i, j);
 }
 
+// Pass B runs over the ocean columns only; t(tau+1) is zero on land (the update is masked, tracer.F:1109-1130).  This
+// kernel clears the land columns of rows js..je of every local tracer (and the cyclic images of land columns 2 and
+// imt-1) ONCE per buffer: nothing on the device writes there afterwards, see land_clean().
+__global__ void __launch_bounds__(256) k_land_zero(const uvic_ctx c, double *tp) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrows = c.je - c.js + 1;
+  const long long per = (long long)c.imt * c.km * nrows;
+  if (gid >= per * c.nt_local) return;
+  const int n = c.n0 + (int)(gid / per);
+  const long long q = gid % per;
+  const int i = (int)(q % c.imt) + 1, k = (int)((q / c.imt) % c.km) + 1, j = c.js + (int)(q / ((long long)c.imt * c.km));
+  const int isrc = (i == 1) ? c.imt - 1 : ((i == c.imt) ? 2 : i);
+  if (c.kmt[(size_t)(isrc - 1) + (size_t)c.imt * (j - 1)] > 0) return;
+  tp[(size_t)n * c.imt * c.km * c.jmt + (size_t)(i - 1) + (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1))] = 0.0;
+}
+
 // latitude-slab halo: `nrow` rows j0.. of every tracer of `t` <-> a staging buffer laid out (nt, nrow, imt*km);
 // dir 0 packs (t -> staging), 1 unpacks (staging -> t).  One launch moves what the exchange sends or receives on a side.
 __global__ void __launch_bounds__(256) k_halo_rows(double *t, double *stage, int rowlen, int jmt, int nt, int j0, int nrow, int dir) {
@@ -371,11 +387,13 @@ struct uvic_gpu {
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
   int *wet_dev;
   std::vector<int> wet_row_start;
-  // work lists of the column passes (ColGrid): (row, segment) codes of the current slab, rebuilt when kmt or the slab changes
+  // lane maps of the column passes (ColGrid) for the current slab, rebuilt when kmt or the slab changes
   std::vector<int> kmt_host;
-  int *pairs_dev;            // pass A list (segments with ocean, row-major) followed by the pass B list (all, segment-major)
-  int npairs_a, npairs_b;
-  bool pairs_dirty;
+  int *lanes_dev;            // pass A map (nwaves_a * 64 codes) followed by the pass B map
+  int nwaves_a, nwaves_b;
+  bool lanes_dirty;
+  // t buffers whose land columns (rows js..je) are known to hold zeros: pass B does not touch land, see land_clean()
+  std::vector<void *> land_zeroed;
   // latitude-slab halo staging (uvic_gpu_halo_*): send south/north, receive south/north, each UVIC_HALO rows of every tracer
   double *halo[4];
   // source buffers known to hold zeros on land (MOBI writes ocean columns only): see src_clean()
@@ -504,7 +522,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->have_vmix = false;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
   h->wet_dev = nullptr;
-  h->pairs_dev = nullptr; h->npairs_a = h->npairs_b = 0; h->pairs_dirty = true;
+  h->lanes_dev = nullptr; h->nwaves_a = h->nwaves_b = 0; h->lanes_dirty = true;
   for (int q = 0; q < 4; ++q) h->halo[q] = nullptr;
   h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
@@ -632,7 +650,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->coef);
   (void)hipFree(h->rpm);
   (void)hipFree(h->wet_dev);
-  (void)hipFree(h->pairs_dev);
+  (void)hipFree(h->lanes_dev);
   for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
@@ -692,7 +710,8 @@ static int make_tmask(uvic_gpu *h) {
   std::vector<int> kmt((size_t)imt * jmt), wet;
   HIPCHK(hipMemcpy(kmt.data(), h->buf[UVIC_F_KMT], kmt.size() * 4, hipMemcpyDeviceToHost));
   h->kmt_host = kmt;
-  h->pairs_dirty = true;
+  h->lanes_dirty = true;
+  h->land_zeroed.clear();
   h->wet_row_start.assign((size_t)jmt + 2, 0);
   for (int j = 1; j <= jmt; ++j) {
     h->wet_row_start[j] = (int)wet.size();
@@ -711,33 +730,99 @@ static int make_tmask(uvic_gpu *h) {
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
-// Work lists of the column passes for the slab js..je (kernels_col.hpp: ColGrid).  Pass A covers one row beyond the slab
-// on each side and lists only the 60-column segments that hold ocean (the others leave R+- at zero); pass B lists every
-// segment of the slab, ocean or not (a land segment stores zeros).
-static int build_col_pairs(uvic_gpu *h) {
-  if (!h->pairs_dirty) return 0;
-  const int imt = h->d.imt, jmt = h->d.jmt;
+// Lane maps of the column passes for the slab js..je (kernels_col.hpp: ColGrid).
+//   pass A covers one row beyond the slab on each side.  In every row the ocean columns form runs (cyclic in longitude;
+//   runs closer than five columns are joined, marching over the land between them costs less than the four halo lanes
+//   of a cut); a run is laid into the waves with two halo lanes on each side, and cut -- with halo lanes again -- where
+//   a wave ends.
+//   pass B: the ocean columns of the slab and nothing else, row by row.
+static int build_col_lanes(uvic_gpu *h) {
+  if (!h->lanes_dirty) return 0;
+  const int imt = h->d.imt, jmt = h->d.jmt, nx = imt - 2;
   const uvic_ctx &c = h->ctx;
-  const int nseg = (imt - 2 + COL_OWN - 1) / COL_OWN;
-  std::vector<int> pa, pb;
+  if (imt > 0xfff || jmt > 0xfff) return fail_msg("column kernels: imt, jmt <= 4095 (lane codes hold 12 bits each)");
   const bool have_kmt = h->kmt_host.size() == (size_t)imt * jmt;
+  auto wet = [&](int x, int r) {   // x = 0..nx-1 <-> column x+2
+    return c.no_landskip || !have_kmt || h->kmt_host[(size_t)(x + 1) + (size_t)imt * (r - 1)] > 0;
+  };
+  auto code_of = [&](int x, int r, int owned) { return (((x % nx + nx) % nx) + 2) | (r << 12) | (owned << 24); };
+  std::vector<int> la, lb;
   const int ra0 = c.js - 1 < 2 ? 2 : c.js - 1, ra1 = c.je + 1 > jmt - 1 ? jmt - 1 : c.je + 1;
-  for (int r = ra0; r <= ra1; ++r)
-    for (int seg = 0; seg < nseg; ++seg) {
-      bool ocean = c.no_landskip || !have_kmt;
-      const int i0 = 2 + seg * COL_OWN, i1 = std::min(i0 + COL_OWN - 1, imt - 1);
-      for (int i = i0; i <= i1 && !ocean; ++i) ocean = h->kmt_host[(size_t)(i - 1) + (size_t)imt * (r - 1)] > 0;
-      if (ocean) pa.push_back(r | (seg << 16));
+  for (int r = ra0; r <= ra1; ++r) {
+    // runs of this row as (start x, length), cyclic
+    std::vector<std::pair<int, int>> runs;
+    int nwet = 0;
+    for (int x = 0; x < nx; ++x) nwet += wet(x, r) ? 1 : 0;
+    if (nwet == 0) continue;
+    if (nwet == nx) runs.push_back({0, nx});
+    else {
+      int x0 = 0;
+      while (wet(x0, r)) ++x0;            // a land column to start the scan from
+      for (int t = 1; t < nx;) {          // t counts columns after x0; a run cannot pass x0 (land)
+        if (!wet((x0 + t) % nx, r)) { ++t; continue; }
+        int len = 0;
+        while (t + len < nx && wet((x0 + t + len) % nx, r)) ++len;
+        runs.push_back({(x0 + t) % nx, len});
+        t += len;
+      }
+      // join runs whose gap is at most 4 columns (the last with the first as well: cyclic), unless that closes the circle
+      bool joined = true;
+      while (joined && runs.size() > 1) {
+        joined = false;
+        for (size_t q = 0; q < runs.size(); ++q) {
+          const size_t qn = (q + 1) % runs.size();
+          const int end = runs[q].first + runs[q].second;                       // first column after run q
+          const int gap = ((runs[qn].first - end) % nx + nx) % nx;
+          if (gap <= 4 && runs[q].second + gap + runs[qn].second < nx) {
+            runs[q].second += gap + runs[qn].second;
+            runs.erase(runs.begin() + (long)qn);
+            joined = true;
+            break;
+          }
+        }
+      }
     }
-  for (int seg = 0; seg < nseg; ++seg)
-    for (int r = c.js; r <= c.je; ++r) pb.push_back(r | (seg << 16));
-  (void)hipFree(h->pairs_dev);
-  h->pairs_dev = nullptr;
-  HIPCHK(hipMalloc((void **)&h->pairs_dev, (pa.size() + pb.size() + 1) * 4));
-  if (!pa.empty()) HIPCHK(hipMemcpy(h->pairs_dev, pa.data(), pa.size() * 4, hipMemcpyHostToDevice));
-  if (!pb.empty()) HIPCHK(hipMemcpy(h->pairs_dev + pa.size(), pb.data(), pb.size() * 4, hipMemcpyHostToDevice));
-  h->npairs_a = (int)pa.size(); h->npairs_b = (int)pb.size();
-  h->pairs_dirty = false;
+    for (auto &run : runs) {
+      int x = run.first, left = run.second;
+      while (left > 0) {
+        int space = 64 - (int)(la.size() % 64);
+        if (space < 5) {                       // not even one owned lane fits: pad the wave
+          for (int q = 0; q < space; ++q) la.push_back(code_of(x, r, 0));
+          space = 64;
+        }
+        const int own = std::min(left, space - 4);
+        la.push_back(code_of(x - 2, r, 0)); la.push_back(code_of(x - 1, r, 0));
+        for (int q = 0; q < own; ++q) la.push_back(code_of(x + q, r, 1));
+        la.push_back(code_of(x + own, r, 0)); la.push_back(code_of(x + own + 1, r, 0));
+        x += own; left -= own;
+      }
+    }
+  }
+  while (la.size() % 64) la.push_back(la.empty() ? code_of(0, ra0, 0) : (la.back() & ~(1 << 24)));
+  for (int r = c.js; r <= c.je; ++r)
+    for (int x = 0; x < nx; ++x)
+      if (wet(x, r)) lb.push_back(code_of(x, r, 1));
+  while (lb.size() % 64) lb.push_back(lb.empty() ? code_of(0, c.js, 0) : (lb.back() & ~(1 << 24)));
+  (void)hipFree(h->lanes_dev);
+  h->lanes_dev = nullptr;
+  HIPCHK(hipMalloc((void **)&h->lanes_dev, (la.size() + lb.size() + 64) * 4));
+  if (!la.empty()) HIPCHK(hipMemcpy(h->lanes_dev, la.data(), la.size() * 4, hipMemcpyHostToDevice));
+  if (!lb.empty()) HIPCHK(hipMemcpy(h->lanes_dev + la.size(), lb.data(), lb.size() * 4, hipMemcpyHostToDevice));
+  h->nwaves_a = (int)(la.size() / 64); h->nwaves_b = (int)(lb.size() / 64);
+  h->lanes_dirty = false;
+  return 0;
+}
+// Pass B leaves land alone: a buffer about to receive t(tau+1) gets its land columns cleared once (first use, or first use
+// since kmt, the slab or the buffer's contents came from the host); the cleared buffers are remembered by address (the
+// three time levels rotate by pointer)
+static int land_clean(uvic_gpu *h, const uvic_ctx &c, hipStream_t st) {
+  void *tp = (void *)c.t_taup1;
+  for (void *q : h->land_zeroed)
+    if (q == tp) return 0;
+  const long long n = (long long)c.imt * c.km * (c.je - c.js + 1) * c.nt_local;
+  if (n > 0) hipLaunchKernelGGL(k_land_zero, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c, c.t_taup1);
+  HIPCHK(hipGetLastError());
+  if (c.n0 == 0 && c.nt_local == c.nt) h->land_zeroed.push_back(tp);   // a partial launch (T,S alone) does not vouch for the buffer
   return 0;
 }
 // the ocean columns of rows js..je
@@ -758,6 +843,12 @@ static int src_clean(uvic_gpu *h, void *src, hipStream_t st) {
   return 0;
 }
 
+// the host wrote into a time level of t: its land columns are the host's business again (land_clean)
+static void land_touched(uvic_gpu *h, int field) {
+  if (field != UVIC_F_T_TAUM1 && field != UVIC_F_T_TAU && field != UVIC_F_T_TAUP1) return;
+  auto &v = h->land_zeroed;
+  v.erase(std::remove(v.begin(), v.end(), h->buf[field]), v.end());
+}
 extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t offset, int64_t count) {
   if (!h || !host) return fail_msg("uvic_gpu_upload: null argument");
   if (field < 0 || field >= UVIC_F_COUNT) return fail_msg("uvic_gpu_upload: bad field id");
@@ -781,6 +872,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
     h->ts_no_src = it[0] == 0 && it[1] == 0;
   }
   if (field == UVIC_F_SRC) h->src_zeroed.clear();
+  land_touched(h, field);
   if (field == UVIC_F_KMT) return make_tmask(h);
   return 0;
 }
@@ -807,6 +899,7 @@ static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, boo
   const int64_t nrows = jhi - jlo + 1;
   HIPCHK(hipSetDevice(h->device));
   if (up && field == UVIC_F_SRC) h->src_zeroed.clear();
+  if (up) land_touched(h, field);
   for (int64_t e = 0; e < ex; ++e) {
     char *dev = (char *)h->buf[field] + (e * plane(h->d, kd) + (int64_t)(jlo - 1) * rowlen) * 8;
     char *hst = (char *)host + e * nrows * rowlen * 8;
@@ -862,7 +955,7 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
   if (!h) return fail_msg("uvic_gpu_set_shard: null handle");
   if (n0 < 0 || nt_local < 0 || n0 + nt_local > h->d.nt) return fail_msg("uvic_gpu_set_shard: tracer range outside 1..nt");
   if (js < 2 || je > h->d.jmt - 1 || js > je) return fail_msg("uvic_gpu_set_shard: row range outside 2..jmt-1");
-  if (js != h->ctx.js || je != h->ctx.je) h->pairs_dirty = true;
+  if (js != h->ctx.js || je != h->ctx.je) { h->lanes_dirty = true; h->land_zeroed.clear(); }
   h->ctx.n0 = n0; h->ctx.nt_local = nt_local; h->ctx.js = js; h->ctx.je = je;
   return 0;
 }
@@ -927,10 +1020,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   if (c.nt_local <= 0) return 0;
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
   if (!h->exact) {  // lane-per-column path
-    if (int rc = build_col_pairs(h)) return rc;
+    if (int rc = build_col_lanes(h)) return rc;
     ColGrid a, b;
-    a.pairs = h->pairs_dev; a.npairs = h->npairs_a; a.total = a.npairs * c.nt_local;
-    b.pairs = h->pairs_dev + h->npairs_a; b.npairs = h->npairs_b; b.total = b.npairs * c.nt_local;
+    a.lanes = h->lanes_dev; a.nwaves = h->nwaves_a; a.total = a.nwaves * c.nt_local;
+    b.lanes = h->lanes_dev + (size_t)h->nwaves_a * 64; b.nwaves = h->nwaves_b; b.total = b.nwaves * c.nt_local;
     double *S = h->work[3];
     a.fuse_convect = b.fuse_convect = 0;
     const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
@@ -956,12 +1049,12 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       cts.nt_local = 2;
       cts.prio |= 2;
       ColGrid ats = a, bts = b;
-      ats.total = ats.npairs * 2;
-      bts.total = bts.npairs * 2;
+      ats.total = ats.nwaves * 2;
+      bts.total = bts.nwaves * 2;
       mark_on(h, "begin", 3);
       if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       mark_on(h, "colfct_ts", 3);
-      hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
+      if (bts.total > 0) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
       mark_on(h, "colupd_ts", 3);
       const WetCols w = wet_range(h, c.js, c.je);
       if (w.count > 0)
@@ -981,9 +1074,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       cr.n0 = 2; cr.nt_local = c.nt - 2;
       cr.Rpm = c.Rpm + 2 * N3 * 2;
       ColGrid ar = a, br = b;
-      ar.total = ar.npairs * cr.nt_local;
-      br.total = br.npairs * cr.nt_local;
+      ar.total = ar.nwaves * cr.nt_local;
+      br.total = br.nwaves * cr.nt_local;
       br.fuse_convect = 1;
+      if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
       if (ar.total > 0) hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ar)), dim3(64, 4), 0, h->stream, cr, (const double *)h->coef, S + 2 * N3, ar);
       mark(h, "colfct");
@@ -992,8 +1086,9 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         h->src_from_prefetch = false;
       }
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
-      hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+      if (br.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
     } else {
+      if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
       if (a.total > 0) hipLaunchKernelGGL(k_colfct, dim3(blocks_a(a)), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
       mark(h, "colfct");
@@ -1001,7 +1096,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
-      hipLaunchKernelGGL(k_colupd, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
+      if (b.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
     }
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
