@@ -227,7 +227,10 @@ int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
 /* one call per step of a device-resident loop: forward-step aliasing (mixing), c2dtts, the whole step, and the
  * look-ahead chains of the next step (mobi_ahead with c2dtts_next, iso_ahead); then exchange halo rows if the
- * decomposition has neighbours, then uvic_gpu_rotate (which ends a forward step's aliasing) */
+ * decomposition has neighbours, then uvic_gpu_rotate (which ends a forward step's aliasing).
+ * iso_ahead: bit 0 = the T,S-derived fields of the next step (a leapfrog step) from this step's t(tau); bit 1 = those
+ * of the step after next (a leapfrog step) from this step's t(tau+1), as soon as T and S of it are final -- single
+ * rank only (a latitude slab receives the halo rows of t(tau+1) with the exchange that follows) */
 int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, int iso_ahead);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);

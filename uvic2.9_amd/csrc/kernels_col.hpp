@@ -176,6 +176,10 @@ UVIC_DEV void coef_bv_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
 // The column kernels are tolerance-tested (1e-13 one step), not bit-exact: mul+add pairs may fuse here.  The
 // library is built -ffp-contract=off for the exact kernels (kernels_fct.hpp, kernels_isopyc.hpp); the pragma
 // holds until the matching contract(off) at the end of this block.  -DUV_NO_CONTRACT: measurement only.
+// Sums that join the two halves of pass A (advective, diffusive) never fuse with the products they add up: the one-sweep
+// and the two-sweep form of the pass then give the same bits (the halves meet in registers in one, in memory in the other).
+__device__ __forceinline__ double add_nc(double a, double b) { return a + b; }
+__device__ __forceinline__ double sub_nc(double a, double b) { return a - b; }
 #ifndef UV_NO_CONTRACT
 #pragma clang fp contract(fast)
 #endif
@@ -281,12 +285,20 @@ __device__ __forceinline__ void fct_ratio(double fxa, double fxb, double tlo, do
   rm = fmn(1., div_pos(mask * (tlo - trmin), pminus + UV_EPSLN));
 }
 
-// pass A order: tracer index fastest, so the four waves of a workgroup work on four tracers of the same lanes
-// and share their coefficient lines in L1
-__device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &code, int &n1) {
+// pass A order: tracer (group) index fastest, so the four waves of a workgroup work on four tracer groups of the same
+// lanes and share their coefficient lines in L1.  Each wave takes NTR consecutive tracers of the launch; when nt_local
+// is not a multiple of NTR the last group repeats its first tracer as a stand-in (live = false).
+template <int NTR>
+__device__ __forceinline__ bool col_decode(const uvic_ctx &c, const ColGrid &g, int item, int &code, int (&n1)[NTR], bool (&live)[NTR]) {
   if (item >= g.total) return false;
-  n1 = c.n0 + item % c.nt_local + 1;
-  code = g.lanes[(size_t)(item / c.nt_local) * 64 + threadIdx.x];
+  const int ngroups = (c.nt_local + NTR - 1) / NTR;
+  const int grp = item % ngroups;
+  _Pragma("unroll") for (int q = 0; q < NTR; ++q) {
+    const int nl = grp * NTR + q;
+    live[q] = nl < c.nt_local;
+    n1[q] = c.n0 + (live[q] ? nl : grp * NTR) + 1;
+  }
+  code = g.lanes[(size_t)(item / ngroups) * 64 + threadIdx.x];
   return true;
 }
 // pass B order: the waves of one tracer next to each other (rows ascending), so that rows r-1, r, r+1 of t, R+-Y
@@ -298,18 +310,30 @@ __device__ __forceinline__ bool col_decode_rows(const uvic_ctx &c, const ColGrid
   return true;
 }
 // ===========================================================================
-// pass A: one sweep down the column
+// pass A: one sweep down the column, NTR tracers per lane
+//
+// NTR = 2 puts two tracers through the same lanes: the 13 coefficient pairs, four velocities, kmt, the masks and
+// every scalar of a level are fetched and formed once for both, the two tracers are two independent dependency
+// chains for the issue logic, and the launch needs half as many waves (at ~250 VGPRs two of them share a SIMD:
+// 2048 slots hold all 15 x 133 waves of the nt = 30 case at once, where the one-tracer form needs a second,
+// nearly empty round of its 160-VGPR waves).  live[q] = false: tracer q is a stand-in (odd tracer count), its
+// results are not stored.
 // ===========================================================================
+//
+// PART splits the pass into two sweeps with half the state each, so that four waves instead of three fit on a SIMD
+// (a wave alone issues one fp64 instruction per ~9 cycles, two READY waves are needed to saturate the VALU, and the
+// memory wait of every level takes one of three out of the race) and all waves of an nt = 30 launch are resident at once:
+//   PART_DIF (first):  the diffusive fluxes with the folded coefficients -> S = DIFF_Tx + DIFF_Ty + DIFF_Tz
+//   PART_ADV (second): low-order fluxes, t_lo, limiter ratios, limited x and z fluxes -> R+-Y and S -= ADV_Tx + ADV_Tz
+//   PART_ALL: both in one sweep
+enum { PART_ALL = 0, PART_ADV = 1, PART_DIF = 2 };
+template <int NTR, int PART>
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
-                                            int code, int n1) {
+                                            int code, const int (&n1)[NTR], const bool (&live)[NTR]) {
+  constexpr bool ADV = PART != PART_DIF, DIF = PART != PART_ADV;
   UV_DIMS(c);
   const int i = COL_LANE_I(code), r = COL_LANE_R(code);
   const bool owned = COL_LANE_OWNED(code) != 0;
-  const size_t nloc = (size_t)(n1 - 1 - c.n0);
-  const double *tm = c.t_taum1 + (size_t)(n1 - 1) * N3;
-  const double *tt = c.t_tau + (size_t)(n1 - 1) * N3;
-  double *Rpm = c.Rpm + nloc * N3 * 2;   // (R+, R-) of the y limiter, one 16-byte element per cell
-  double *Sn = S + nloc * N3;
   // per-level metrics, one entry per lane, broadcast by v_readlane (no memory latency in the march)
   LaneTable t_dzt2r, t_dtxcel, t_dztr;
   t_dzt2r.load(c.dzt2r, km); t_dtxcel.load(c.dtxcel, km); t_dztr.load(c.dztr, km);
@@ -321,8 +345,6 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const double cstdyt2r = c.cstdyt2r[r - 1], cstdytr = c.cstdytr[r - 1];
   const bool south_wall = (r - 1 == 1);   // no antidiffusive flux through the face to row 1 (adv_flx: jstrt)
   const double c2dtts = c.c2dtts;
-  const double stf = c.stf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
-  const double btf = c.btf[X2(i, r) + (size_t)(n1 - 1) * imt * jmt] * (1.0 - c.aidif);
   // addresses = buffer descriptor + wave-uniform byte offset (one scalar register: level and row shift) + the lane's
   // 32-bit offset of its (i, r) column
   const int rowstride = imt * km;
@@ -330,130 +352,192 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const unsigned lb = (unsigned)((r - 2) * rowstride + (i - 1)) * 8u;   // level 1 of column i of row r-1, cell fields
   const unsigned lb2 = lb * 2u;
   const unsigned lbf = (unsigned)((r - 1) * imt * (km + 1) + (i - 1)) * 8u;   // face 0 of the lane's column, face fields
-  const brsrc b_tm = mkbuf(tm, N3 * 8), b_tt = mkbuf(tt, N3 * 8), b_te = mkbuf(c.tot_e, N3 * 8), b_tn = mkbuf(c.tot_n, N3 * 8);
+  const brsrc b_te = mkbuf(c.tot_e, N3 * 8), b_tn = mkbuf(c.tot_n, N3 * 8);
   const brsrc b_tb = mkbuf(c.tot_b, NF * 8), b_vb = mkbuf(c.adv_vbt, NF * 8);
-  const brsrc b_cf = mkbuf(cf, N3 * 16 * CF_PAIRS), b_S = mkbuf(Sn, N3 * 8), b_R = mkbuf(Rpm, N3 * 16);
+  const brsrc b_cf = mkbuf(cf, N3 * 16 * CF_PAIRS);
+  brsrc b_tm[NTR], b_tt[NTR], b_S[NTR], b_R[NTR];
+  double stf[NTR], btf[NTR];
+  _Pragma("unroll") for (int q = 0; q < NTR; ++q) {
+    const size_t nloc = (size_t)(n1[q] - 1 - c.n0);
+    b_tm[q] = mkbuf(c.t_taum1 + (size_t)(n1[q] - 1) * N3, N3 * 8);
+    b_tt[q] = mkbuf(c.t_tau + (size_t)(n1[q] - 1) * N3, N3 * 8);
+    b_S[q] = mkbuf(S + nloc * N3, N3 * 8);
+    b_R[q] = mkbuf(c.Rpm + nloc * N3 * 2, N3 * 16);   // (R+, R-) of the y limiter, one 16-byte element per cell
+    stf[q] = c.stf[X2(i, r) + (size_t)(n1[q] - 1) * imt * jmt] * (1.0 - c.aidif);
+    btf[q] = c.btf[X2(i, r) + (size_t)(n1[q] - 1) * imt * jmt] * (1.0 - c.aidif);
+  }
 #define OC(k, dj) (((((k)-1) * imt + ((dj) + 1) * rowstride)) * 8)   /* byte offset of level k of row r+dj from the lane's offset */
+#define LDQ(b, k, dj) bld(b[q], lb, OC(k, dj))
 #define LD(b, k, dj) bld(b_##b, lb, OC(k, dj))
 #define CFP(pair, k, dj) bld2(b_cf, lb2, ((int)(pair) * (int)N3 + ((k)-1) * imt + ((dj) + 1) * rowstride) * 16)
 #define OF(kf) (((kf) * imt) * 8)
-  double mc1 = LD(tm, 1, 0), ms1 = LD(tm, 1, -1), mn1 = LD(tm, 1, 1);   // level s of t(tau-1) centre/south/north
-  double tc0, tc1;                                                        // levels s-1 and s of t(tau)
-  tc0 = tc1 = LD(tt, 1, 0);
+#define FORQ _Pragma("unroll") for (int q = 0; q < NTR; ++q)
   // surface faces
   const double vb0 = bld(b_vb, lbf, OF(0));
-  double fblo_up = vb0 * 2.0 * mc1;              // low-order flux through the face above level s
-  double afb_up = fblo_up;                       // raw antidiffusive flux through it (adv_flx:617)
-  double dfb_up = stf, dfbi_up = 0.0;            // diffusive fluxes through the face above level s
-  double rzp_prev = 0.0, rzm_prev = 0.0, fblo_prev = 0.0, afb_prev = 0.0, spart_prev = 0.0, mk_prev = 0.0;
+  // state carried from level to level, per tracer
+  double mc1[NTR], ms1[NTR], mn1[NTR];   // level s of t(tau-1) centre/south/north
+  double tc0[NTR], tc1[NTR];             // levels s-1 and s of t(tau)
+  double fblo_up[NTR], afb_up[NTR];      // low-order and raw antidiffusive flux through the face above level s (adv_flx:617)
+  double dfb_up[NTR], dfbi_up[NTR];      // diffusive fluxes through the face above level s
+  double rzp_prev[NTR], rzm_prev[NTR], spart_prev[NTR];
+  double sfin_prev[NTR], sfin_last[NTR], sdif_last[NTR];
   // differences that level s+1 needs again are handed down instead of being formed (and shuffled) twice:
   // T(s)-T(s+1) of the own, east, south and north columns; T(i+1)-T(i) and T(i)-T(i-1) at level s+1
-  double me_next = shfl_e(mc1);
-  double dz_c = 0.0, dz_e = 0.0, dz_s = 0.0, dz_n = 0.0;
-  double dx_next = me_next - mc1, dxw_next = shfl_w(dx_next);
-  double fbfin_up = vb0 * (tc1 + tc1);           // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
+  double me_next[NTR], dz_c[NTR], dz_e[NTR], dz_s[NTR], dz_n[NTR], dx_next[NTR], dxw_next[NTR];
+  double fbfin_up[NTR];                  // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
+  double mk_prev = 0.0;
+  FORQ {
+    mc1[q] = LDQ(b_tm, 1, 0); ms1[q] = LDQ(b_tm, 1, -1); mn1[q] = LDQ(b_tm, 1, 1);
+    tc0[q] = tc1[q] = LDQ(b_tt, 1, 0);
+    fblo_up[q] = vb0 * 2.0 * mc1[q];
+    afb_up[q] = fblo_up[q];
+    dfb_up[q] = stf[q]; dfbi_up[q] = 0.0;
+    rzp_prev[q] = rzm_prev[q] = spart_prev[q] = sfin_prev[q] = sfin_last[q] = sdif_last[q] = 0.0;
+    me_next[q] = shfl_e(mc1[q]);
+    dz_c[q] = dz_e[q] = dz_s[q] = dz_n[q] = 0.0;
+    dx_next[q] = me_next[q] - mc1[q]; dxw_next[q] = shfl_w(dx_next[q]);
+    fbfin_up[q] = vb0 * (tc1[q] + tc1[q]);
+  }
   for (int s = 1; s <= km; ++s) {
     const bool last = (s == km);
     const int sp = last ? km : s + 1;
-    const double mc2 = LD(tm, sp, 0), ms2 = LD(tm, sp, -1), mn2 = LD(tm, sp, 1), tc2 = LD(tt, sp, 0);
-    const double t_s = LD(tt, s, -1), t_n = LD(tt, s, 1);
-    const double ve = LD(te, s, 0), vn = LD(tn, s, 0), vs = LD(tn, s, -1);
-    const double vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
-    double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
-    _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
-      const double2 v = CFP(p, s, 0);
-      cfc[2 * p] = v.x; cfc[2 * p + 1] = v.y;
+    // ---- what the tracers share: velocities, folded coefficients, masks, metrics ------------------------
+    double ve = 0.0, vn = 0.0, vs = 0.0, vb = 0.0;
+    if (ADV) {
+      ve = LD(te, s, 0); vn = LD(tn, s, 0); vs = LD(tn, s, -1);
+      vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
     }
-    _Pragma("unroll") for (int p = 0; p < 3; ++p) {
-      const double2 v = CFP(p, s, -1);
-      cfs[2 * p] = v.x; cfs[2 * p + 1] = v.y;
+    double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
+    if (DIF) {
+      _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
+        const double2 v = CFP(p, s, 0);
+        cfc[2 * p] = v.x; cfc[2 * p + 1] = v.y;
+      }
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+        const double2 v = CFP(p, s, -1);
+        cfs[2 * p] = v.x; cfs[2 * p + 1] = v.y;
+      }
     }
     const double dzt2r_s = t_dzt2r.at(s - 1), ddztr = t_dztr.at(s - 1);
+    const double dzt2r_up = (s >= 2) ? t_dzt2r.at(s - 2) : 0.0;
+    const double twodt = c2dtts * t_dtxcel.at(s - 1);
     const double mk = (s <= kz) ? 1.0 : 0.0;
     // wet neighbour -> its face value, land -> t_lo (adv_flx:640-668 blends with the 0/1 mask: the same value)
     const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
     const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
-    const double m_c = mc1, tt_c = tc1;
-    const double m_e = me_next, tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
-    // ---- advection, low order and raw antidiffusive (adv_flx:500-619) ----------
-    const double felo = upstream(ve, m_c, m_e);
-    const double afe = ve * (tt_c + tt_e) - felo;
-    const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
-    const double fnlo_n = upstream(vn, m_c, mn1), fnlo_s = upstream(vs, ms1, m_c);
-    double fblo = 0.0, afb = 0.0;
-    if (!last) {
-      fblo = vb * (mc2 + m_c) + dabs(vb) * (mc2 - m_c);
-      afb = vb * (tt_c + tc2) - fblo * mk;
+    const double avb = dabs(vb);
+    FORQ {
+      const double mc2 = LDQ(b_tm, sp, 0), ms2 = LDQ(b_tm, sp, -1), mn2 = LDQ(b_tm, sp, 1);
+      const double m_c = mc1[q];
+      const double mc2_e = shfl_e(mc2);
+      double spart = 0.0;     // what this sweep adds to S of level s, but for the z advection (finalised one level later)
+      // =================== advective part (adv_flx) =====================================================
+      if (ADV) {
+        const double tc2 = LDQ(b_tt, sp, 0);
+        const double t_s = LDQ(b_tt, s, -1), t_n = LDQ(b_tt, s, 1);
+        // the diffusive sweep has stored its share of S already: fetched here, used when level s-1 is finalised
+        double sdif_prev = 0.0;
+        if (PART == PART_ADV) sdif_prev = bld(b_S[q], lb, OC(s >= 2 ? s - 1 : 1, 0));
+        if (PART == PART_ADV && last) sdif_last[q] = bld(b_S[q], lb, OC(km, 0));
+        const double tt_c = tc1[q];
+        const double m_e = me_next[q], tt_e = shfl_e(tt_c), tt_w = shfl_w(tt_c);
+        // ---- low order and raw antidiffusive fluxes (adv_flx:500-619) ----------
+        const double felo = upstream(ve, m_c, m_e);
+        const double afe = ve * (tt_c + tt_e) - felo;
+        const double felo_w = shfl_w(felo), afe_w = shfl_w(afe);
+        const double fnlo_n = upstream(vn, m_c, mn1[q]), fnlo_s = upstream(vs, ms1[q], m_c);
+        double fblo = 0.0, afb = 0.0;
+        if (!last) {
+          fblo = vb * (mc2 + m_c) + avb * (mc2 - m_c);
+          afb = vb * (tt_c + tc2) - fblo * mk;
+        }
+        const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
+        const double advz = (fblo_up[q] - fblo) * dzt2r_s;
+        const double tlo = m_c - twodt * (advx + advy + advz) * mk;
+        // ---- limiter ratios ---------------------------------------------------------
+        double rxp, rxm, ryp, rym, rzp, rzm;
+        {
+          const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
+          fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
+        }
+        {
+          const double afn_n = vn * (tt_c + t_n) - fnlo_n;
+          const double afn_s = south_wall ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
+          fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
+                    ryp, rym);
+        }
+        {
+          const double fxa = wet_up ? 0.5 * (tc0[q] + tt_c) : tlo;
+          const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
+          fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up[q], mk, rzp, rzm);
+        }
+        if (owned && live[q]) bst2(b_R[q], lb2, OC(s, 0) * 2, ryp, rym);
+        // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
+        const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
+        const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
+        const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
+        spart = -ADV_Tx;
+        // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
+        if (s >= 2) {
+          const double fbfin = (limited(fmn(rzp_prev[q], rzm), fmn(rzp, rzm_prev[q]), afb_up[q]) + fblo_up[q]) * mk_prev;
+          const double ADV_Tz = (fbfin_up[q] - fbfin) * dzt2r_up;
+          sfin_prev[q] = sub_nc(add_nc(spart_prev[q], sdif_prev), ADV_Tz);
+          fbfin_up[q] = fbfin;
+        }
+        if (last) {  // bottom face of the column (tracer.F:1065); vb holds adv_vbt there
+          const double fbfin = vb * tt_c;
+          sfin_last[q] = (fbfin_up[q] - fbfin) * dzt2r_s;   // ADV_Tz of the bottom level
+        }
+        rzp_prev[q] = rzp; rzm_prev[q] = rzm;
+        fblo_up[q] = fblo; afb_up[q] = afb;
+        me_next[q] = mc2_e;
+        tc0[q] = tc1[q]; tc1[q] = tc2;
+      }
+      // =================== diffusive part (coefficients folded by ai_coef_cell) ===========================
+      if (DIF) {
+        const double dz_up = dz_c[q], dz_dn = (!last) ? m_c - mc2 : 0.0;          // own column (dz_up = dz_dn of the level above, 0 at the top)
+        const double dze_up = dz_e[q], dze_dn = shfl_e(dz_dn);                      // east column
+        const double dzs_up = dz_s[q], dzs_dn = (!last) ? ms1[q] - ms2 : 0.0;      // south row
+        const double dzn_up = dz_n[q], dzn_dn = (!last) ? mn1[q] - mn2 : 0.0;      // north row
+        const double dx_c = dx_next[q], dx_d = mc2_e - mc2;                         // T(i+1)-T(i) at levels s, s+1
+        const double dxw_c = dxw_next[q], dxw_d = shfl_w(dx_d);                     // T(i)-T(i-1)
+        const double dfe = cfc[CF_AE] * dx_c + cfc[CF_CE + 0] * dz_up + cfc[CF_CE + 1] * dze_up + cfc[CF_CE + 2] * dz_dn +
+                           cfc[CF_CE + 3] * dze_dn;
+        const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
+        const double dfn_n = cfc[CF_AN] * (mn1[q] - m_c) + cfc[CF_CN + 0] * dz_up + cfc[CF_CN + 1] * dzn_up + cfc[CF_CN + 2] * dz_dn +
+                             cfc[CF_CN + 3] * dzn_dn;
+        const double dfn_s = cfs[0] * (m_c - ms1[q]) + cfs[1] * dzs_up + cfs[2] * dz_up + cfs[3] * dzs_dn + cfs[4] * dz_dn;
+        const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
+        double dfb = 0.0, dfbi = 0.0;  // through the face below level s
+        if (!last) {
+          dfb = cfc[CF_BV] * (m_c - mc2);
+          dfbi = cfc[CF_CBX + 0] * dxw_c + cfc[CF_CBX + 1] * dx_c + cfc[CF_CBX + 2] * dxw_d + cfc[CF_CBX + 3] * dx_d +
+                 cfc[CF_CBY + 0] * (m_c - ms1[q]) + cfc[CF_CBY + 1] * (mn1[q] - m_c) + cfc[CF_CBY + 2] * (mc2 - ms2) +
+                 cfc[CF_CBY + 3] * (mn2 - mc2);
+        }
+        if (s == kz) dfb = btf[q];  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
+        if (kz == 0 && s == 1) dfb_up[q] = btf[q];
+        const double DIFF_Tz = (dfb_up[q] - dfb) * ddztr + (dfbi_up[q] - dfbi) * ddztr;
+        const double dsum = DIFF_Tx + DIFF_Ty + DIFF_Tz;
+        spart = (PART == PART_DIF) ? dsum : add_nc(spart, dsum);
+        dfb_up[q] = dfb; dfbi_up[q] = dfbi;
+        dx_next[q] = dx_d; dxw_next[q] = dxw_d;
+        dz_c[q] = dz_dn; dz_e[q] = dze_dn; dz_s[q] = dzs_dn; dz_n[q] = dzn_dn;
+      }
+      // ---- stores of S -----------------------------------------------------------------------
+      if (PART == PART_DIF) {
+        if (owned && live[q]) bst(b_S[q], lb, OC(s, 0), spart);
+      } else {
+        if (s >= 2 && owned && live[q]) bst(b_S[q], lb, OC(s - 1, 0), sfin_prev[q]);
+        if (last && owned && live[q]) bst(b_S[q], lb, OC(km, 0), sub_nc(add_nc(spart, sdif_last[q]), sfin_last[q]));
+        spart_prev[q] = spart;
+      }
+      mc1[q] = mc2; ms1[q] = ms2; mn1[q] = mn2;
     }
-    const double advx = (felo - felo_w) * cstdxt2r, advy = (fnlo_n - fnlo_s) * cstdyt2r;
-    const double advz = (fblo_up - fblo) * dzt2r_s;
-    const double tlo = m_c - (c2dtts * t_dtxcel.at(s - 1)) * (advx + advy + advz) * mk;
-    // ---- limiter ratios ---------------------------------------------------------
-    double rxp, rxm, ryp, rym, rzp, rzm;
-    {
-      const double mw = 0.5 * (tt_w + tt_c), me = 0.5 * (tt_c + tt_e);
-      fct_ratio(wet_w ? mw : tlo, wet_e ? me : tlo, tlo, c2dtts * cstdxt2r, afe_w, afe, mk, rxp, rxm);
-    }
-    {
-      const double afn_n = vn * (tt_c + t_n) - fnlo_n;
-      const double afn_s = south_wall ? 0.0 : vs * (t_s + tt_c) - fnlo_s;
-      fct_ratio(wet_s ? 0.5 * (t_s + tt_c) : tlo, wet_n ? 0.5 * (tt_c + t_n) : tlo, tlo, c2dtts * cstdyt2r, afn_s, afn_n, mk,
-                ryp, rym);
-    }
-    {
-      const double fxa = wet_up ? 0.5 * (tc0 + tt_c) : tlo;
-      const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
-      fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up, mk, rzp, rzm);
-    }
-    if (owned) bst2(b_R, lb2, OC(s, 0) * 2, ryp, rym);
-    // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
-    const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
-    const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
-    const double ADV_Tx = (fefin - shfl_w(fefin)) * cstdxt2r;
-    // ---- diffusive fluxes (coefficients folded by ai_coef_cell) ------------------------
-    const double dz_up = dz_c, dz_dn = (!last) ? m_c - mc2 : 0.0;       // own column (dz_up = dz_dn of the level above, 0 at the top)
-    const double dze_up = dz_e, dze_dn = shfl_e(dz_dn);                   // east column
-    const double dzs_up = dz_s, dzs_dn = (!last) ? ms1 - ms2 : 0.0;      // south row
-    const double dzn_up = dz_n, dzn_dn = (!last) ? mn1 - mn2 : 0.0;      // north row
-    const double mc2_e = shfl_e(mc2);
-    const double dx_c = dx_next, dx_d = mc2_e - mc2;                      // T(i+1)-T(i) at levels s, s+1
-    const double dxw_c = dxw_next, dxw_d = shfl_w(dx_d);                  // T(i)-T(i-1)
-    const double dfe = cfc[CF_AE] * dx_c + cfc[CF_CE + 0] * dz_up + cfc[CF_CE + 1] * dze_up + cfc[CF_CE + 2] * dz_dn +
-                       cfc[CF_CE + 3] * dze_dn;
-    const double DIFF_Tx = (dfe - shfl_w(dfe)) * cstdxtr;
-    const double dfn_n = cfc[CF_AN] * (mn1 - m_c) + cfc[CF_CN + 0] * dz_up + cfc[CF_CN + 1] * dzn_up + cfc[CF_CN + 2] * dz_dn +
-                         cfc[CF_CN + 3] * dzn_dn;
-    const double dfn_s = cfs[0] * (m_c - ms1) + cfs[1] * dzs_up + cfs[2] * dz_up + cfs[3] * dzs_dn + cfs[4] * dz_dn;
-    const double DIFF_Ty = (dfn_n - dfn_s) * cstdytr;
-    double dfb = 0.0, dfbi = 0.0;  // through the face below level s
-    if (!last) {
-      dfb = cfc[CF_BV] * (m_c - mc2);
-      dfbi = cfc[CF_CBX + 0] * dxw_c + cfc[CF_CBX + 1] * dx_c + cfc[CF_CBX + 2] * dxw_d + cfc[CF_CBX + 3] * dx_d +
-             cfc[CF_CBY + 0] * (m_c - ms1) + cfc[CF_CBY + 1] * (mn1 - m_c) + cfc[CF_CBY + 2] * (mc2 - ms2) +
-             cfc[CF_CBY + 3] * (mn2 - mc2);
-    }
-    if (s == kz) dfb = btf;  // bottom boundary condition of the explicit vertical flux (tracer.F:1060-1062)
-    if (kz == 0 && s == 1) dfb_up = btf;
-    const double DIFF_Tz = (dfb_up - dfb) * ddztr + (dfbi_up - dfbi) * ddztr;
-    const double spart = DIFF_Tx + DIFF_Ty + DIFF_Tz - ADV_Tx;
-    // ---- finalise level s-1: limited z flux through the face between s-1 and s (adv_flx:857-887, 994-999)
-    if (s >= 2) {
-      const double fbfin = (limited(fmn(rzp_prev, rzm), fmn(rzp, rzm_prev), afb_prev) + fblo_prev) * mk_prev;
-      const double ADV_Tz = (fbfin_up - fbfin) * t_dzt2r.at(s - 2);
-      if (owned) bst(b_S, lb, OC(s - 1, 0), spart_prev - ADV_Tz);
-      fbfin_up = fbfin;
-    }
-    if (last) {  // bottom face of the column (tracer.F:1065); vb holds adv_vbt there
-      const double fbfin = vb * tt_c;
-      const double ADV_Tz = (fbfin_up - fbfin) * dzt2r_s;
-      if (owned) bst(b_S, lb, OC(km, 0), spart - ADV_Tz);
-    }
-    // ---- roll ---------------------------------------------------------------------------
-    rzp_prev = rzp; rzm_prev = rzm; fblo_prev = fblo; afb_prev = afb; spart_prev = spart; mk_prev = mk;
-    fblo_up = fblo; afb_up = afb; dfb_up = dfb; dfbi_up = dfbi;
-    me_next = mc2_e; dx_next = dx_d; dxw_next = dxw_d; dz_c = dz_dn; dz_e = dze_dn; dz_s = dzs_dn; dz_n = dzn_dn;
-    mc1 = mc2; ms1 = ms2; mn1 = mn2; tc0 = tc1; tc1 = tc2;
+    mk_prev = mk;
   }
+#undef FORQ
+#undef LDQ
 #undef LD
 #undef CFP
 #undef OC

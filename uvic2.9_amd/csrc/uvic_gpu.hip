@@ -26,6 +26,8 @@
 #include "uvic_ctx.h"
 
 using namespace uvic;
+#define UV_STR_(x) #x
+#define UV_STR(x) UV_STR_(x)
 
 // ---------------------------------------------------------------------------
 // kernels
@@ -51,6 +53,7 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 // (SURVEY.md §8e); rows further out are left alone
 #define SLAB_OUT(c, j) ((j) < (c).js - 2 || (j) > (c).je + 2)
 __global__ void __launch_bounds__(256) k_isopyc_elements(const uvic_ctx c) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   CELL_DECODE(c);
   if (j > c.jmt || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   isopyc_elements_cell(c, i, k, j);
@@ -61,11 +64,13 @@ __global__ void __launch_bounds__(256) k_isopyc_ai(const uvic_ctx c) {
   isopyc_ai_cell(c, i, k, j);
 }
 __global__ void __launch_bounds__(256) k_isopyc_adv(const uvic_ctx c) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   CELL_DECODE(c);
   if (j > c.jmt - 1 || SLAB_OUT(c, j)) return;
   isopyc_adv_cell(c, i, k, j);
 }
 __global__ void __launch_bounds__(128) k_isopyc_column(const uvic_ctx c) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
   if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
@@ -117,6 +122,7 @@ __global__ void __launch_bounds__(256) k_vmixc(const uvic_ctx c) {
   vmixc_cell(c, i, k, j);
 }
 __global__ void __launch_bounds__(256) k_ai_coef(const uvic_ctx c, double *cf) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   CELL_DECODE(c);
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   ai_coef_cell(c, cf, i, k, j);
@@ -126,18 +132,26 @@ __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   coef_bv_cell(c, cf, i, k, j);
 }
+// NTR tracers per lane (kernels_col.hpp); g.total counts waves = (waves of the lane map) x ceil(nt_local / NTR)
+template <int NTR, int PART>
 __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
-  int code, n1;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: the tracer and the wave of the lane map live in scalar registers
-  if (blk >= nblk || !col_decode(c, g, blk * 4 + wv, code, n1)) return;
+  int code, n1[NTR];
+  bool live[NTR];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: the tracers and the wave of the lane map live in scalar registers
+  if (blk >= nblk || !col_decode<NTR>(c, g, blk * 4 + wv, code, n1, live)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colfct_wave(c, cf, S, code, n1);
+  colfct_wave<NTR, PART>(c, cf, S, code, n1, live);
 }
-__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body(c, cf, S, g); }
-// the same passes for T and S alone on the side stream: own names, so that a profile tells the two launches apart
-__global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body(c, cf, S, g); }
+__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
+// the pass as two sweeps, four waves per SIMD each: diffusive fluxes first (S), then the FCT advection (R+-Y, S)
+__global__ void __launch_bounds__(256) k_colfct_dif(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_DIF>(c, cf, S, g); }
+__global__ void __launch_bounds__(256) k_colfct_adv(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ADV>(c, cf, S, g); }
+// two tracers per lane: half the waves, shared coefficient and velocity loads, two dependency chains per wave
+__global__ void __launch_bounds__(256) k_colfct2(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<2, PART_ALL>(c, cf, S, g); }
+// the same pass for T and S alone on the side stream: own name, so that a profile tells the two launches apart
+__global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
 __device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, const ColGrid &g, double *lds) {
   const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
   const int blk = xcd_remap(blockIdx.x, nblk);
@@ -154,6 +168,42 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, 
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_ts(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   colupd_body(c, S, g, lds);
+}
+// ---- the T,S chain of step n and the isopyc chain of step n+1 share three launches -------------------------------
+// Both are chains of three short kernels on the same side stream (pass A, pass B, convective walk of T,S; elements,
+// mixing tensor + GM velocities, column sums of isopyc), neither reads what the other writes, and one after the other
+// they are the longest queue of a step.  Launched side by side (the first blocks of a launch do the T,S stage, the
+// rest the isopyc stage) the stream holds three kernels per step instead of seven.  `ci` is the context of the isopyc
+// part: it reads this step's t(tau) as t(tau-1) and writes the set of the next step.
+#define CELL_DECODE_ID(c, id)                               \
+  const long long gid = (id);                               \
+  const int i = (int)(gid % (c).imt) + 1;                   \
+  const int k = (int)((gid / (c).imt) % (c).km) + 1;        \
+  const int j = (int)(gid / ((long long)(c).imt * (c).km)) + 1
+__global__ void __launch_bounds__(256) k_ts_iso1(const uvic_ctx c, const double *cf, double *S, const ColGrid g, int nts, const uvic_ctx ci) {
+  if ((int)blockIdx.x < nts) { colfct_body<1, PART_ALL>(c, cf, S, g); return; }
+  if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
+  CELL_DECODE_ID(ci, (long long)(blockIdx.x - nts) * 256 + threadIdx.y * 64 + threadIdx.x);
+  if (j > ci.jmt || i < 2 || i > ci.imt - 1 || SLAB_OUT(ci, j)) return;
+  isopyc_elements_cell(ci, i, k, j);
+}
+// (blocks of 256 threads: the T,S stage, one wave per workgroup with its 20 KB of LDS, uses the first wave of its blocks;
+// eight such blocks fit on a CU, so the isopyc blocks beside them still fill every wave slot)
+__global__ void __launch_bounds__(256) k_ts_iso2(const uvic_ctx c, const double *S, const ColGrid g, int nts, const uvic_ctx ci,
+                                                 double *cfi, int ncell) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x < nts) {
+    if (threadIdx.y == 0) colupd_body(c, S, g, lds);
+    return;
+  }
+  if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
+  const int b = blockIdx.x - nts;
+  const bool second = b >= ncell;   // first the mixing tensor and the folded coefficients, then the GM velocities
+  CELL_DECODE_ID(ci, (long long)(second ? b - ncell : b) * 256 + threadIdx.y * 64 + threadIdx.x);
+  if (j > ci.jmt - 1 || SLAB_OUT(ci, j)) return;
+  if (second) { isopyc_adv_cell(ci, i, k, j); return; }
+  if (i < 2 || i > ci.imt - 1) return;
+  ai_coef_cell(ci, cfi, i, k, j);
 }
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,13 +223,43 @@ struct WetCols {
 #define WET_DECODE(w, cc)                          \
   const int wid_ = (w).ij[(w).first + (cc)];       \
   const int i = wid_ % c.imt + 1, j = wid_ / c.imt + 1
-__global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCols w) {
+__global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCols w, int *cvl) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= w.count) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
   WET_DECODE(w, gid);
   convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
+  if (cvl && c.cv_nseg[wid_] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid_;
+}
+// third shared launch: the convective T,S walk beside the column sums of isopyc
+__global__ void __launch_bounds__(256) k_ts_iso3(const uvic_ctx c, const WetCols w, int nts, const uvic_ctx ci, int *cvl) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x < nts) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.y != 0 || gid >= w.count) return;
+    if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
+    WET_DECODE(w, gid);
+    convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
+    if (cvl && c.cv_nseg[wid_] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid_;
+    return;
+  }
+  if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
+  const int gid = (blockIdx.x - nts) * 256 + threadIdx.y * 64 + threadIdx.x;
+  const int i = gid % ci.imt + 1, j = gid / ci.imt + 1;
+  if (j < 2 || j > ci.jmt - 1 || i < 2 || i > ci.imt - 1 || SLAB_OUT(ci, j)) return;
+  isopyc_column(ci, i, j);
+}
+// The columns in which the walk mixed something, as a list: cvl[0] counts them, cvl[1..] holds their ids ((i-1) + imt*(j-1)).
+// Few columns convect in a step, and convect_apply over the list is a handful of waves instead of one thread per
+// (ocean column, tracer) that finds nothing to do.
+__global__ void __launch_bounds__(256) k_convect_apply_list(const uvic_ctx c, const int *cvl) {
+  const int ncol = cvl[0];
+  const long long total = (long long)ncol * (c.nt - 2);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int wid = cvl[1 + (int)(q % ncol)];   // columns fastest
+    convect_apply_cell(c, wid % c.imt + 1, wid / c.imt + 1, (int)(q / ncol) + 3);
+  }
 }
 __global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,6 +270,7 @@ __global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c, const W
 }
 // cell-parallel MOBI passes: thread = (ocean column, level), columns fastest
 __global__ void __launch_bounds__(128) k_mobi_pre(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   // two threads per cell: the first half of the grid does the carbonate chemistry, the second the rest (whole waves each)
   const int half = (int)((gridDim.x + 1) / 2);
   const int part = blockIdx.x < half ? 1 : 2;
@@ -200,6 +281,7 @@ __global__ void __launch_bounds__(128) k_mobi_pre(const uvic_ctx c, const mobi_d
   mobi_pre_cell(c, m, i, k, j, part);
 }
 __global__ void __launch_bounds__(128) k_mobi_post(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = gid / w.count + 1;
   if (k > c.km) return;
@@ -246,7 +328,9 @@ __device__ __forceinline__ void mobi_team_role(const uvic_ctx &c, const mobi_dev
 #ifndef UV_TEAM_WAVES_PER_EU
 #define UV_TEAM_WAVES_PER_EU 3
 #endif
-#if UV_TEAM_WAVES_PER_EU > 0
+#if defined(UV_TEAM_NUM_VGPR)
+#define UV_TEAM_OCC __attribute__((amdgpu_num_vgpr(UV_TEAM_NUM_VGPR)))
+#elif UV_TEAM_WAVES_PER_EU > 0
 #define UV_TEAM_OCC __attribute__((amdgpu_waves_per_eu(UV_TEAM_WAVES_PER_EU, UV_TEAM_WAVES_PER_EU)))
 #else
 #define UV_TEAM_OCC
@@ -379,11 +463,13 @@ struct uvic_gpu {
   void *buf[UVIC_F_COUNT];
   double *work[8];  // tot_e, tot_n, tot_b, adv_x (also S of the column path), adv_z, RpY, RmY
   int *cv_int[3];   // convection segments: nseg, kt, kb
+  int *cv_list;     // [0] number of columns the T,S walk of this step mixed, [1..] their ids (k_convect_list)
   double *cv_z;
   bool exact_convect;  // single-kernel convct2 (debug: UVIC_CONVECT_ONEPASS=1)
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
   double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
+  int a_mode;       // pass A of the bulk launch: 1 = one sweep, 2 = one sweep with two tracers per lane, 3 = two sweeps (UVIC_A_MODE)
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
   int *wet_dev;
   std::vector<int> wet_row_start;
@@ -417,25 +503,42 @@ struct uvic_gpu {
   // events of the look-ahead chains alternate, because the chain of step n+1 is queued (and records its event)
   // before step n waits for the chain of step n: `_pending` = recorded during this step, `_ready` = what this step waits for
   int ev_flip;
-  hipEvent_t ev_src_ready, ev_src_pending, ev_iso_ready, ev_iso_pending;
+  hipEvent_t ev_src_ready, ev_src_pending;
   hipEvent_t ev_step_end[2], ev_end_ready, ev_end_pending;   // end of a step's own work (step_end)
   bool end_ready, end_pending;
   // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
   hipStream_t side2;
   // (T and S finish pass B and the convective T,S walk on side2 as well, beside pass B of the other tracers: the
   // device offers four hardware queues, and a fifth stream would share one with another and wait behind its barriers)
-  bool iso_waited;    // this step's T,S-derived fields came from the look-ahead chain (ev_iso_ready)
+  bool iso_waited;    // this step's T,S-derived fields came from a look-ahead chain (iso_set[iso_cur].ev)
   bool unmix_at_rotate;   // uvic_gpu_step_lookahead ran a forward step: uvic_gpu_rotate ends the aliasing
   bool step_begun;    // ev_step_begin of the current step is recorded (uvic_gpu_rotate ends the step)
   hipStream_t side_ts; // the T,S passes: an alias of side2
   hipEvent_t ev_fct_done, ev_ts_done;
   bool ts_ahead;      // this step's convect_ts was already issued on side2
+  // isopyc of the next step fused into the T,S launches of this one (k_ts_iso*): armed by uvic_gpu_step_lookahead
+  bool iso_fuse_armed, iso_fuse;
+  uvic_ctx iso_fuse_ctx;
+  double *iso_fuse_coef;
+  int iso_fuse_set;
+  bool ts_apply;      // ... and pass B of the other tracers did not replay the mixing: convect_apply follows it (conv_decoupled)
+  bool conv_decoupled;   // pass B of the other tracers does not wait for the T,S chain (UVIC_CONV_DECOUPLED, default 1)
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
   bool ts_no_src;     // itrc(1) = itrc(2) = 0: T and S have no source term (known from the upload of itrc)
-  hipEvent_t ev_iso_next[2];
-  void *iso_alt[UVIC_F_COUNT];
-  double *work_alt[3], *coef_alt;
-  bool iso_prefetch_pending, iso_from_prefetch;
+  // The T,S-derived fields (mixing tensor, GM velocities, folded coefficients, diff_cbt) exist in three sets: step m
+  // uses set m % 3, so the chain of step m+1 or m+2 can be written while step m still reads its own.  h->buf[], work[0..2]
+  // and coef are views of the set in use (use_iso_set).
+  struct IsoSet {
+    void *f[16];
+    double *work[3], *coef;
+    hipEvent_t ev;          // recorded behind the chain that filled the set
+    long long for_step;     // the step whose fields a look-ahead chain put there, -1: none
+    bool allocated;
+  } iso_set[3];
+  int iso_cur;
+  long long step_no;        // counts uvic_gpu_rotate
+  hipEvent_t ev_ts_final;   // T and S of this step's t(tau+1) are final (after convection and the polar filter)
+  bool ts_final_valid;
   hipEvent_t ev_step_begin, ev_src_next[2];
   void *src_alt;
   bool prefetch_pending, src_from_prefetch, mixing;
@@ -507,6 +610,9 @@ static void bind_ctx(uvic_gpu *h) {
 
 // the t(:,:,:,:,-1:1) slots rotate by pointer; tmask is derived from kmt on upload
 static int make_tmask(uvic_gpu *h);
+static void iso_set_adopt(uvic_gpu *h);
+static void iso_set_release(uvic_gpu *h);
+static int use_iso_set(uvic_gpu *h, int s);
 
 extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device) {
   if (!out || !dims) return fail_msg("uvic_gpu_create: null argument");
@@ -527,7 +633,21 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
   memset(&h->mobi, 0, sizeof h->mobi);
-  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  // The main stream carries the bulk passes (pass A and B of the nt-2 tracers): their waves fill every SIMD for most of
+  // a step, and the short kernels of the latency chains on the side streams (isopyc, MOBI pre/post, the T,S passes) then
+  // wait a whole wave lifetime for a free slot.  UVIC_MAIN_CUS=N (a multiple of 8, < 256) keeps the bulk passes off
+  // 256-N compute units (the mask bits go round the 8 XCDs), which stay free for the side streams.
+  {
+    int main_cus = 0;
+    if (const char *e = getenv("UVIC_MAIN_CUS")) main_cus = atoi(e);
+    if (main_cus >= 8 && main_cus < 256) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int b = 0; b < main_cus; ++b) mask[b / 32] |= 1u << (b % 32);
+      HIPCHK(hipExtStreamCreateWithCUMask(&h->stream, 8, mask));
+    } else {
+      HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    }
+  }
   h->mobi_flip = 0;
   h->mobi_two_streams = true;
   if (const char *e = getenv("UVIC_MOBI_STREAMS")) h->mobi_two_streams = atoi(e) != 1;
@@ -538,13 +658,20 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->side_ts = h->side2;   // a stream of their own did not pay: the device has four hardware queues
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
+  h->ts_apply = false;
+  h->iso_fuse_armed = false;
+  h->iso_fuse = false;   // measured: the shared launches take as long as the seven separate ones (the chip is saturated)
+  if (const char *e = getenv("UVIC_ISO_FUSE")) h->iso_fuse = atoi(e) != 0;
+  h->conv_decoupled = true;
+  if (const char *e = getenv("UVIC_CONV_DECOUPLED")) h->conv_decoupled = atoi(e) != 0;
   h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false; h->unmix_at_rotate = false;
-  for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_iso_next[q], hipEventDisableTiming));
-  h->ev_iso_ready = h->ev_iso_pending = h->ev_iso_next[0];
+  for (int q = 0; q < 3; ++q) {
+    memset(&h->iso_set[q], 0, sizeof h->iso_set[q]);
+    HIPCHK(hipEventCreateWithFlags(&h->iso_set[q].ev, hipEventDisableTiming));
+    h->iso_set[q].for_step = -1;
+  }
+  h->iso_cur = 0; h->step_no = 0; h->ts_final_valid = false;
   h->ev_flip = 0;
-  for (int f = 0; f < UVIC_F_COUNT; ++f) h->iso_alt[f] = nullptr;
-  h->work_alt[0] = h->work_alt[1] = h->work_alt[2] = nullptr; h->coef_alt = nullptr;
-  h->iso_prefetch_pending = h->iso_from_prefetch = false;
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
   h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
@@ -573,6 +700,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
       HIPCHK(hipMalloc((void **)&h->cv_int[q], isz[q] * 4));
       HIPCHK(hipMemset(h->cv_int[q], 0, isz[q] * 4));
     }
+    HIPCHK(hipMalloc((void **)&h->cv_list, (NS + 1) * 4));
+    HIPCHK(hipMemset(h->cv_list, 0, (NS + 1) * 4));
     HIPCHK(hipMalloc((void **)&h->cv_z, N3 * 8));
     HIPCHK(hipMemset(h->cv_z, 0, N3 * 8));
     h->exact_convect = false;
@@ -582,8 +711,12 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipMemset(h->rpm, 0, N3 * 16 * (size_t)dims->nt));
   HIPCHK(hipMalloc((void **)&h->coef, N3 * 16 * CF_PAIRS));
   HIPCHK(hipMemset(h->coef, 0, N3 * 16 * CF_PAIRS));
+  iso_set_adopt(h);   // what was just allocated is set 0
   h->exact = false;
   if (const char *e = getenv("UVIC_EXACT")) h->exact = atoi(e) != 0;
+  h->a_mode = 1;   // measured (102x102x19, nt = 30, alone): one sweep 131 us, two tracers per lane 116, two sweeps 63 + 79; in the loop all three tie
+  if (const char *e = getenv("UVIC_A_MODE")) h->a_mode = atoi(e);
+  if (h->a_mode < 1 || h->a_mode > 3) h->a_mode = 1;
   // tmask lives in its own buffer (derived data)
   double *tmask;
   HIPCHK(hipMalloc((void **)&tmask, N3 * 8));
@@ -596,6 +729,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->ctx.c2dtts = 0.0; h->ctx.aidif = 0.5;
   h->ctx.no_landskip = getenv("UVIC_NO_LANDSKIP") ? 1 : 0;
   h->ctx.prio = getenv("UVIC_TEAM_PRIO0") ? 1 : 0;
+  if (const char *e = getenv("UVIC_SMALL_PRIO")) h->ctx.prio |= atoi(e) ? 4 : 0;
   // tile geometry: keep the FCT tile within the LDS budget
   int budget_kb = 150;
   if (const char *e = getenv("UVIC_LDS_BUDGET_KB")) budget_kb = atoi(e);
@@ -644,10 +778,10 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  iso_set_release(h);   // the three sets of T,S-derived fields; clears their views in buf[], work[0..2], coef
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
-  (void)hipFree(h->coef);
   (void)hipFree(h->rpm);
   (void)hipFree(h->wet_dev);
   (void)hipFree(h->lanes_dev);
@@ -656,6 +790,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->flt_mats);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
   (void)hipFree(h->cv_z);
+  (void)hipFree(h->cv_list);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
     (void)hipFree(h->mobi_st.work);
@@ -672,10 +807,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipStreamDestroy(h->side2);
   (void)hipEventDestroy(h->ev_fct_done);
   (void)hipEventDestroy(h->ev_ts_done);
-  for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_iso_next[q]);
-  for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->iso_alt[f]);
-  for (int q = 0; q < 3; ++q) (void)hipFree(h->work_alt[q]);
-  (void)hipFree(h->coef_alt);
+  for (int q = 0; q < 3; ++q) (void)hipEventDestroy(h->iso_set[q].ev);
   (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -862,7 +994,8 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
     HIPCHK(hipStreamSynchronize(h->side2));
   HIPCHK(hipStreamSynchronize(h->side_ts));
     h->prefetch_pending = h->src_from_prefetch = false;
-    h->iso_prefetch_pending = h->iso_from_prefetch = false;
+    for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;
+    h->ts_final_valid = false;
     h->end_ready = h->end_pending = false;
   }
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
@@ -960,6 +1093,65 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
   return 0;
 }
 
+// -- the three sets of T,S-derived fields ---------------------------------------------
+static const int ISO_FIELDS[16] = {UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT, UVIC_F_AI_EZ, UVIC_F_AI_NZ,
+                                   UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33, UVIC_F_ADV_VETISO,
+                                   UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO, UVIC_F_DIFF_CBT};
+static void iso_set_adopt(uvic_gpu *h) {   // uvic_gpu_create: the buffers just allocated are set 0
+  uvic_gpu::IsoSet &S = h->iso_set[0];
+  for (int q = 0; q < 16; ++q) S.f[q] = h->buf[ISO_FIELDS[q]];
+  for (int q = 0; q < 3; ++q) S.work[q] = h->work[q];
+  S.coef = h->coef;
+  S.allocated = true;
+  h->iso_cur = 0;
+}
+static void iso_set_release(uvic_gpu *h) {
+  for (int s = 0; s < 3; ++s) {
+    uvic_gpu::IsoSet &S = h->iso_set[s];
+    if (!S.allocated) continue;
+    for (int q = 0; q < 16; ++q) (void)hipFree(S.f[q]);
+    for (int q = 0; q < 3; ++q) (void)hipFree(S.work[q]);
+    (void)hipFree(S.coef);
+    S.allocated = false;
+  }
+  for (int q = 0; q < 16; ++q) h->buf[ISO_FIELDS[q]] = nullptr;
+  for (int q = 0; q < 3; ++q) h->work[q] = nullptr;
+  h->coef = nullptr;
+}
+static int iso_set_alloc(uvic_gpu *h, int s, hipStream_t st) {   // zero-filled like the first one
+  uvic_gpu::IsoSet &S = h->iso_set[s];
+  if (S.allocated) return 0;
+  const uvic_dims &d = h->d;
+  for (int q = 0; q < 16; ++q) {
+    const size_t bytes = (size_t)field_elems(d, ISO_FIELDS[q]) * 8;
+    HIPCHK(hipMalloc(&S.f[q], bytes));
+    HIPCHK(hipMemsetAsync(S.f[q], 0, bytes, st));
+  }
+  const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt;
+  const size_t wsz[3] = {N3, N3, NF};
+  for (int q = 0; q < 3; ++q) {
+    HIPCHK(hipMalloc((void **)&S.work[q], wsz[q] * 8));
+    HIPCHK(hipMemsetAsync(S.work[q], 0, wsz[q] * 8, st));
+  }
+  HIPCHK(hipMalloc((void **)&S.coef, N3 * 16 * CF_PAIRS));
+  HIPCHK(hipMemsetAsync(S.coef, 0, N3 * 16 * CF_PAIRS, st));
+  HIPCHK(hipStreamSynchronize(st));   // once per set: whichever stream writes or reads it first finds the zeros
+  S.allocated = true;
+  return 0;
+}
+// point buf[], work[0..2], coef and the context at set s
+static int use_iso_set(uvic_gpu *h, int s) {
+  if (h->iso_cur == s) return 0;
+  if (int rc = iso_set_alloc(h, s, h->stream)) return rc;
+  const uvic_gpu::IsoSet &S = h->iso_set[s];
+  for (int q = 0; q < 16; ++q) h->buf[ISO_FIELDS[q]] = S.f[q];
+  for (int q = 0; q < 3; ++q) h->work[q] = S.work[q];
+  h->coef = S.coef;
+  h->iso_cur = s;
+  bind_ctx(h);
+  return 0;
+}
+
 // -- launch helpers ------------------------------------------------------------
 static void mark_on(uvic_gpu *h, const char *name, int sid) {
   if (!h->profiling) return;
@@ -989,6 +1181,8 @@ static unsigned col_blocks(const uvic_gpu *h, int bs) {
 // the T,S-derived fields of a step (mixing tensor, GM velocities, folded coefficients): ctx `c` says what is read
 // (t_taum1) and where the products go; `sid` 0 = main stream, 2 = the isopyc side stream
 static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStream_t st, int sid) {
+  static const bool dbg_skip = getenv("UVIC_DBG_SKIP_ISO") != nullptr;   // timing experiment only: results are wrong
+  if (dbg_skip && sid != 0) return 0;
   mark_on(h, "begin", sid);
   hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
   mark_on(h, "isopyc_elements", sid);
@@ -1006,9 +1200,11 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
 }
 static int launch_isopyc(uvic_gpu *h) {
   h->iso_waited = false;
-  if (h->iso_from_prefetch) {   // computed one step ahead on its side stream (uvic_gpu_prefetch_isopyc)
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_iso_ready, 0));
-    h->iso_from_prefetch = false;
+  const int set = (int)(h->step_no % 3);
+  if (int rc = use_iso_set(h, set)) return rc;
+  if (h->iso_set[set].for_step == h->step_no) {   // computed ahead on a side stream (uvic_gpu_prefetch_isopyc)
+    HIPCHK(hipStreamWaitEvent(h->stream, h->iso_set[set].ev, 0));
+    h->iso_set[set].for_step = -1;
     h->iso_waited = true;
     return 0;
   }
@@ -1028,7 +1224,20 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     a.fuse_convect = b.fuse_convect = 0;
     const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
     auto blocks_a = [](const ColGrid &g) { return (unsigned)((((g.total + 3) / 4 + 7) / 8) * 8); };
+    // the bulk launch of pass A: a_ntr tracers per lane (g.total counts waves)
     auto blocks_b = [](const ColGrid &g) { return (unsigned)((((g.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8); };
+    auto launch_a = [&](const uvic_ctx &cc, ColGrid g, const double *Sg, hipStream_t st) {
+      const int ntr = h->a_mode == 2 ? 2 : 1;
+      g.total = g.nwaves * ((cc.nt_local + ntr - 1) / ntr);
+      if (g.total <= 0) return;
+      const double *cf = (const double *)h->coef;
+      if (h->a_mode == 2) hipLaunchKernelGGL(k_colfct2, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
+      else if (h->a_mode == 3) {
+        hipLaunchKernelGGL(k_colfct_dif, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
+        mark(h, "colfct_dif");
+        hipLaunchKernelGGL(k_colfct_adv, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
+      } else hipLaunchKernelGGL(k_colfct, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
+    };
     // T and S first: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both passes and
     // the walk run on the side stream while the main stream works on the other tracers, whose pass B then finds the
     // mixed segments ready and replays them itself (no separate convection pass over t(tau+1)).  Not under tracer
@@ -1040,7 +1249,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
       if (h->iso_waited && h->step_begun) {
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_iso_ready, 0));
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
       } else {
         HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
@@ -1052,22 +1261,44 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       ats.total = ats.nwaves * 2;
       bts.total = bts.nwaves * 2;
       mark_on(h, "begin", 3);
-      if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
-      mark_on(h, "colfct_ts", 3);
-      if (bts.total > 0) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
-      mark_on(h, "colupd_ts", 3);
       const WetCols w = wet_range(h, c.js, c.je);
-      if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side_ts, cts, w);
-      mark_on(h, "convect_ts", 3);
+      const size_t cv_lds = (size_t)2 * h->d.km * 64 * 8;
+      if (h->iso_fuse_armed && ats.total > 0 && bts.total > 0 && w.count > 0) {
+        // the isopyc chain of the next step rides in the same three launches (k_ts_iso*)
+        h->iso_fuse_armed = false;
+        const uvic_ctx &ci = h->iso_fuse_ctx;
+        const int n1 = (int)blocks_a(ats), n2 = (int)blocks_b(bts), n3 = (w.count + 63) / 64;
+        const int ncell256 = (int)cell_blocks(h, 256), ncol256 = (int)col_blocks(h, 256);
+        hipLaunchKernelGGL(k_ts_iso1, dim3((unsigned)(n1 + ncell256)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats, n1, ci);
+        mark_on(h, "colfct_ts", 3);
+        hipLaunchKernelGGL(k_ts_iso2, dim3((unsigned)(n2 + 2 * ncell256)), dim3(64, 4), upd_lds, h->side_ts, cts, (const double *)S, bts, n2,
+                           ci, h->iso_fuse_coef, ncell256);
+        mark_on(h, "colupd_ts", 3);
+        HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+        hipLaunchKernelGGL(k_ts_iso3, dim3((unsigned)(n3 + ncol256)), dim3(64, 4), cv_lds, h->side_ts, cts, w, n3, ci, h->cv_list);
+        mark_on(h, "convect_ts", 3);
+        HIPCHK(hipEventRecord(h->iso_set[h->iso_fuse_set].ev, h->side_ts));
+        h->iso_set[h->iso_fuse_set].for_step = h->step_no + 1;
+      } else {
+        if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+        mark_on(h, "colfct_ts", 3);
+        if (bts.total > 0) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
+        mark_on(h, "colupd_ts", 3);
+        HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+        if (w.count > 0)
+          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds, h->side_ts, cts, w, h->cv_list);
+        mark_on(h, "convect_ts", 3);
+      }
       // one barrier packet less on the main stream (~8 us each): the side stream waits for the sources as well before it
       // signals, and the main stream waits for that one event
-      if (h->src_from_prefetch) {
+      if (h->src_from_prefetch && !h->conv_decoupled) {
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
       HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
       h->ts_ahead = true;
+      h->ts_apply = h->conv_decoupled;
+      if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
       // the other tracers on the main stream: work arrays are indexed from the group's first tracer
       const size_t N3 = (size_t)c.imt * c.km * c.jmt;
       uvic_ctx cr = c;
@@ -1076,21 +1307,24 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       ColGrid ar = a, br = b;
       ar.total = ar.nwaves * cr.nt_local;
       br.total = br.nwaves * cr.nt_local;
-      br.fuse_convect = 1;
+      br.fuse_convect = h->conv_decoupled ? 0 : 1;
       if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
-      if (ar.total > 0) hipLaunchKernelGGL(k_colfct, dim3(blocks_a(ar)), dim3(64, 4), 0, h->stream, cr, (const double *)h->coef, S + 2 * N3, ar);
+      launch_a(cr, ar, S + 2 * N3, h->stream);
       mark(h, "colfct");
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
-      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
+      static const bool dbg_nowait = getenv("UVIC_DBG_NOWAIT_TS") != nullptr;   // timing experiment only: results are wrong
+      // decoupled: the mixed segments are replayed by convect_apply after this pass (launch_convect), so that the main
+      // stream does not stand still between its two passes while the T,S chain (three short kernels) finishes
+      if (!dbg_nowait && !h->conv_decoupled) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
       if (br.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
     } else {
       if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
-      if (a.total > 0) hipLaunchKernelGGL(k_colfct, dim3(blocks_a(a)), dim3(64, 4), 0, h->stream, c, (const double *)h->coef, S, a);
+      launch_a(c, a, S, h->stream);
       mark(h, "colfct");
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
@@ -1131,9 +1365,16 @@ static int launch_convect(uvic_gpu *h) {
     const WetCols w = wet_range(h, h->ctx.js, h->ctx.je);
     const bool fused = h->ts_ahead;   // T,S walk on the side stream, replay inside pass B (launch_transport): all done
     h->ts_ahead = false;
+    if (fused && h->ts_apply) {       // ... or left to convect_apply here, once the walk has finished
+      h->ts_apply = false;
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
+      if (w.count > 0 && h->d.nt > 2)   // over the list of columns the walk mixed (few): 64 workgroups stride over it
+        hipLaunchKernelGGL(k_convect_apply_list, dim3(64), dim3(256), 0, h->stream, h->ctx, (const int *)h->cv_list);
+      mark(h, "convect_apply");
+    }
     if (!fused) {
       if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx, w);
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx, w, (int *)nullptr);
       mark(h, "convect_ts");
     }
     if (h->d.nt > 2 && !fused) {
@@ -1325,6 +1566,7 @@ static int step_end(uvic_gpu *h) {
   h->ev_end_pending = h->ev_step_end[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_end_pending, h->stream));
   h->end_pending = true;
+  if (!h->ts_final_valid) { h->ev_ts_final = h->ev_end_pending; h->ts_final_valid = true; }
   return 0;
 }
 extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
@@ -1336,6 +1578,7 @@ extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
 }
 extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
 extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
+static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead);
 extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on);
 // One call per time step for a device-resident loop: what the Python TimeLoop does with six (at 0.2 ms per step of a
 // small slab the host's share counts).  mixing: forward step (t(tau-1) := t(tau), c2dtts = dtts); mobi_ahead, iso_ahead:
@@ -1346,11 +1589,32 @@ extern "C" int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, i
   if (!h) return fail_msg("null handle");
   if (int rc = uvic_gpu_set_mixing(h, mixing)) return rc;
   h->ctx.c2dtts = c2dtts;
+  // isopyc of the next step inside the T,S launches of this one: the context that writes the next step's set from this
+  // step's t(tau), made now (the set in use is not this step's yet: launch_isopyc switches to it)
+  h->iso_fuse_armed = false;
+  if ((iso_ahead & 1) && h->iso_fuse && !h->ctx.diff_cbt_given && !h->exact) {
+    const long long target = h->step_no + 1;
+    const int set = (int)(target % 3), cur = h->iso_cur;
+    if (h->iso_set[set].for_step != target) {
+      if (int rc = use_iso_set(h, set)) return rc;
+      h->iso_fuse_ctx = h->ctx;
+      h->iso_fuse_coef = h->coef;
+      if (int rc = use_iso_set(h, cur)) return rc;
+      h->iso_fuse_ctx.t_taum1 = h->ctx.t_tau;
+      h->iso_fuse_set = set;
+      h->iso_fuse_armed = true;
+    }
+  }
   if (int rc = uvic_gpu_step_async(h)) return rc;
+  h->iso_fuse_armed = false;   // not taken (no T,S launches of their own in this configuration): the chain below does it
   if (mobi_ahead && h->have_mobi)
     if (int rc = uvic_gpu_prefetch_sources(h, c2dtts_next)) return rc;
-  if (iso_ahead && !h->ctx.diff_cbt_given)
-    if (int rc = uvic_gpu_prefetch_isopyc(h)) return rc;
+  if (!h->ctx.diff_cbt_given) {   // bit 0: the next step is a leapfrog step, bit 1: the step after next is (and no halo exchange follows)
+    if (iso_ahead & 1)
+      if (int rc = prefetch_isopyc_ahead(h, 1)) return rc;
+    if (iso_ahead & 2)
+      if (int rc = prefetch_isopyc_ahead(h, 2)) return rc;
+  }
   h->unmix_at_rotate = mixing != 0;
   return 0;
 }
@@ -1385,51 +1649,46 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   h->prefetch_pending = true;
   return 0;
 }
-// The T,S-derived fields of the NEXT step (isopyc reads T,S at tau-1 of that step = tau of this one) on a second
-// side stream, overlapped with this step.  Same calling rule as uvic_gpu_prefetch_sources.
-static const int ISO_FIELDS[] = {UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT, UVIC_F_AI_EZ, UVIC_F_AI_NZ,
-                                 UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33, UVIC_F_ADV_VETISO,
-                                 UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO, UVIC_F_DIFF_CBT};
-static void swap_iso_buffers(uvic_gpu *h) {
-  for (int f : ISO_FIELDS) std::swap(h->buf[f], h->iso_alt[f]);
-  for (int q = 0; q < 3; ++q) std::swap(h->work[q], h->work_alt[q]);
-  std::swap(h->coef, h->coef_alt);
+// The T,S-derived fields of a LATER step on a side stream, overlapped with this step.  isopyc of step m reads T,S at tau-1 of
+// that step, on a leapfrog step m the result of step m-2:
+//   ahead = 1: for the next step, from this step's t(tau); on the T,S stream, behind this step's T,S passes;
+//   ahead = 2: for the step after next, from this step's t(tau+1) as soon as T and S of it are final (ev_ts_final: after the
+//              convective walk on the T,S stream, or -- with the polar filter on -- at the end of the step); on the MOBI stream
+//              whose chain (the sources of THIS step) has ended by then, so that neither the T,S passes of the next step nor
+//              anything else the main stream waits for queues up behind it.  Not for a latitude slab (t(tau+1) of the halo
+//              rows arrives with the exchange).
+// Call after uvic_gpu_step_async and before uvic_gpu_rotate; only valid when the target step is a leapfrog step.
+static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead) {
+  if (h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_prefetch_isopyc: not with an uploaded diff_cbt (diff_cbt_has_k33 = 1)");
+  HIPCHK(hipSetDevice(h->device));
+  const long long target = h->step_no + ahead;
+  const int set = (int)(target % 3), cur = h->iso_cur;
+  if (h->iso_set[set].for_step == target) return 0;   // there already
+  hipStream_t st = h->side2;
+  int sid = 2;
+  if (ahead == 2) {
+    if (!h->ts_final_valid) return 0;                  // nothing says when T,S are final: leave it to ahead = 1 of the next step
+    st = h->side_m[h->mobi_flip];
+    sid = h->mobi_flip ? 4 : 1;
+  }
+  if (int rc = iso_set_alloc(h, set, st)) return rc;
+  // a context that writes set `set` and reads T,S of the level that will be tau-1 then
+  if (int rc = use_iso_set(h, set)) return rc;
+  uvic_ctx c = h->ctx;
+  double *coef = h->coef;
+  if (int rc = use_iso_set(h, cur)) return rc;
+  c.t_taum1 = (ahead == 2) ? (const double *)h->ctx.t_taup1 : h->ctx.t_tau;
+  if (int rc = step_begin(h)) return rc;
+  // the set was last read by step target-3; whatever this step still does with t does not touch what the chain reads
+  HIPCHK(hipStreamWaitEvent(st, ahead == 2 ? h->ev_ts_final : h->ev_step_begin, 0));
+  if (int rc = launch_isopyc_on(h, c, coef, st, sid)) return rc;
+  HIPCHK(hipEventRecord(h->iso_set[set].ev, st));
+  h->iso_set[set].for_step = target;
+  return 0;
 }
 extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
-  if (h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_prefetch_isopyc: not with an uploaded diff_cbt (diff_cbt_has_k33 = 1)");
-  HIPCHK(hipSetDevice(h->device));
-  const uvic_dims &d = h->d;
-  if (!h->coef_alt) {   // the alternate set, zero-filled like the primary one
-    for (int f : ISO_FIELDS) {
-      const size_t bytes = (size_t)field_elems(d, f) * 8;
-      HIPCHK(hipMalloc(&h->iso_alt[f], bytes));
-      HIPCHK(hipMemsetAsync(h->iso_alt[f], 0, bytes, h->side2));
-    }
-    const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt;
-    const size_t wsz[3] = {N3, N3, NF};
-    for (int q = 0; q < 3; ++q) {
-      HIPCHK(hipMalloc((void **)&h->work_alt[q], wsz[q] * 8));
-      HIPCHK(hipMemsetAsync(h->work_alt[q], 0, wsz[q] * 8, h->side2));
-    }
-    HIPCHK(hipMalloc((void **)&h->coef_alt, N3 * 16 * CF_PAIRS));
-    HIPCHK(hipMemsetAsync(h->coef_alt, 0, N3 * 16 * CF_PAIRS, h->side2));
-  }
-  // a context that reads this step's t(tau) as t(tau-1) and writes the alternate set
-  swap_iso_buffers(h);
-  bind_ctx(h);
-  uvic_ctx c = h->ctx;
-  double *coef = h->coef;
-  swap_iso_buffers(h);
-  bind_ctx(h);
-  c.t_taum1 = h->ctx.t_tau;
-  if (int rc = step_begin(h)) return rc;
-  HIPCHK(hipStreamWaitEvent(h->side2, h->ev_step_begin, 0));
-  if (int rc = launch_isopyc_on(h, c, coef, h->side2, 2)) return rc;
-  h->ev_iso_pending = h->ev_iso_next[h->ev_flip];
-  HIPCHK(hipEventRecord(h->ev_iso_pending, h->side2));
-  h->iso_prefetch_pending = true;
-  return 0;
+  return prefetch_isopyc_ahead(h, 1);
 }
 // forward (mixing) step: t(tau-1) aliases t(tau) until switched off again
 extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on) {
@@ -1512,12 +1771,8 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->src_from_prefetch = true;
     h->ev_src_ready = h->ev_src_pending;
   }
-  if (h->iso_prefetch_pending) {   // likewise the T,S-derived fields
-    swap_iso_buffers(h);
-    h->iso_prefetch_pending = false;
-    h->iso_from_prefetch = true;
-    h->ev_iso_ready = h->ev_iso_pending;
-  }
+  h->step_no += 1;      // the T,S-derived fields of the new step: launch_isopyc takes set step_no % 3
+  h->ts_final_valid = false;
   bind_ctx(h);
   return 0;
 }

@@ -15,6 +15,7 @@ include/uvic_gpu.h.  Everything computes on the GPU through libuvic_gpu.so.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -267,6 +268,7 @@ class TimeLoop:
         (0: the forcing never changes during the loop)."""
         self.m, self.dtts, self.nmix, self.shard, self.prefetch = model, float(dtts), int(nmix), shard, prefetch
         self.segment = int(segment)
+        self.iso2 = os.environ.get("UVIC_ISO2", "0") != "0"      # 1: isopyc two steps ahead on the idle MOBI stream (measured: no gain)
         self.itt = 0
 
     def _mixing(self, itt):
@@ -280,7 +282,11 @@ class TimeLoop:
             # one C call per step (uvic_gpu_step_lookahead), then the halo exchange of a latitude slab, then the rotation
             ahead = self.prefetch and not self._mixing(self.itt + 1)
             mobi_ahead = ahead and m.has_mobi and not (self.segment > 0 and self.itt % self.segment == 0)
-            iso_ahead = ahead and not m.params.diff_cbt_has_k33
+            # bit 0: T,S-derived fields of the next step from t(tau); bit 1: those of the step after next from this step's
+            # t(tau+1) (single rank only: a latitude slab gets the halo rows of t(tau+1) with the exchange that follows)
+            iso_ahead = 0
+            if self.prefetch and not m.params.diff_cbt_has_k33:
+                iso_ahead = (1 if ahead else 0) | (2 if self.shard is None and self.iso2 and not self._mixing(self.itt + 2) else 0)
             c2dtts = self.dtts if mixing else 2.0 * self.dtts
             check(m.lib.uvic_gpu_step_lookahead(m.h, c2dtts, int(mixing), int(mobi_ahead), 2.0 * self.dtts, int(iso_ahead)),
                   "step_lookahead")
