@@ -116,6 +116,52 @@ def cpu_baseline(ocean, to, so, c, src, budget_s=20.0):
                       f"oracle (gcc -O2 -ffp-contract=off), {cfg.name} {g.imt}x{g.jmt}x{g.km}"}
 
 
+def overlay_baseline(ocean, steps=40, segment=4):
+    """The path the north star names: the reference's own call sequence with `tracer` replaced by the Fortran overlay
+    (uvic2.9_amd/fortran/tracer_gpu.F -> ISO_C_BINDING -> libuvic_gpu.so), resident mode, driven through the compiled
+    reference's COMMON blocks (oracle/_ref/libuvicshim_*; a second model instance on the same GPU).  PCIe included:
+    velocities, diff_cbt, stf, btf up and T,S down every step; ocean segments of `segment` steps (run/control.in:
+    segtim 5 d / dtts 1.25 d), whose first step computes its MOBI sources in line.
+      call_ms      median wall time of one `tracer` call when the host does its own work between calls (here: the host
+                   isopyc of the tracer-only integration), i.e. what the Fortran driver waits for per step
+      loop_ms      wall time per step of the calls alone, back to back (the device never idles)"""
+    import refmodel
+    g, cfg = ocean.grid, ocean.cfg
+    if cfg.name not in ("p2", "c30") or not refmodel.available(cfg.name, g.imt, g.jmt, g.km, shim=True):
+        return None
+    os.environ["UVIC_RESIDENT"] = "1"
+    import refdriver
+    shim = refdriver.RefOcean(ocean, shim=True)
+    shim.set_step_kind(False)
+    shim.ref.set("nmix", 0)
+    shim.ref.set("ntspos", segment)
+    shim.ref.set("prelyr", float(shim.v["relyr"][0]))
+
+    def switches(it):
+        shim.ref.set("itt", it)
+        shim.ref.set("osegs", 1 if (it - 1) % segment == 0 else 0)
+        shim.ref.set("osege", 1 if it % segment == 0 else 0)
+
+    it, calls = 0, []
+    for _ in range(steps + 4):
+        it += 1
+        switches(it)
+        shim.isopyc(); shim.add_k33()
+        t0 = time.perf_counter()
+        shim.tracer()
+        calls.append(time.perf_counter() - t0)
+        shim.rotate()
+    calls = sorted(calls[4:])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        it += 1
+        switches(it)
+        shim.tracer()           # (no host rotation: the harness rotates by copying 2 x 47 MB, the model by permuting indices;
+    shim.ref.call("tracer_gpu_sync") if hasattr(shim.ref.lib, "tracer_gpu_sync_") else shim.flush()   # the state is on the device)
+    loop = (time.perf_counter() - t0) / steps
+    return {"call_ms": calls[len(calls) // 2] * 1e3, "loop_ms": loop * 1e3, "segment": segment, "steps": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +170,7 @@ def main():
     ap.add_argument("--cfg", default="c30")
     ap.add_argument("--grid", default="102x102x19")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlay", action="store_true", help="skip the Fortran-overlay measurement (oracle/_ref/libuvicshim_*)")
     ap.add_argument("--decomp", default="auto", choices=["auto", "tracer", "slab"],
                     help="N>1: tracer-index shards + all-gather, or latitude slabs + 2-row halo exchange "
                          "(auto: slabs when every rank gets at least 12 rows, SURVEY.md §8e)")
@@ -224,6 +271,19 @@ def main():
     barrier()
     el_instr = time.perf_counter() - t1
     live = m.profile_read()
+    # the same loop with the reference's coupling rhythm: ocean segments of 4 steps (run/control.in: segtim 5 d, dtts
+    # 1.25 d), whose first step gets new surface forcing and computes its MOBI sources in line
+    seg4_ms = None
+    if world == 1 and a.segment == 0 and cfg.ntnpzd and a.one_slab_of <= 1:
+        loop4 = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, segment=4)
+        for _ in range(4):
+            loop4.step()
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(a.steps):
+            loop4.step()
+        barrier()
+        seg4_ms = (time.perf_counter() - t4) / a.steps * 1e3
     if world > 1:
         tt = torch.tensor([el], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -298,6 +358,17 @@ def main():
             "step_hbm": {"alg_bytes_per_cell_update": b_alg(nt, nsrc), "achieved_GBs": step_gbs,
                          "frac_of_peak": step_gbs / HBM_PEAK_GBS},
         }
+        if seg4_ms is not None:
+            out["segment4_ms_per_step"] = seg4_ms
+        if world == 1 and not a.no_overlay and a.one_slab_of <= 1:
+            try:
+                ov = overlay_baseline(ocean)
+            except Exception as e:      # never let the side measurement break the bench line
+                ov = {"error": str(e)}
+            if ov is not None:
+                out["overlay"] = ov
+                if "loop_ms" in ov:
+                    out["overlay_ms_per_step"] = ov["loop_ms"]
         if not a.no_cpu_baseline and world == 1:      # the CPU baseline is reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(ocean, to, so, c, src)
         print(json.dumps(out), flush=True)

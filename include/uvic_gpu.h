@@ -148,7 +148,9 @@ int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc, const int3
                            const double *hice, const double *hsno, const double *sg_bathy, const double *fe_atmdep,
                            const double *fe_hydr);
 /* what of the MOBI forcing changes every step, after uvic_gpu_set_mobi[_flat] has set the rest once: the fields
- * tracer.F:355-390 reads (downward shortwave, ice fraction and thickness, snow), relyr and the atmospheric CO2 */
+ * tracer.F:355-390 reads (downward shortwave, ice fraction and thickness, snow), relyr and the atmospheric CO2.
+ * All four fields null: they stay (they change once per ocean segment), only relyr and co2ccn move on.  New fields
+ * void what a look-ahead chain computed from the old ones. */
 int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, const double *dnswr, const double *aice,
                            const double *hice, const double *hsno);
 /* page-lock a host range that is uploaded from or downloaded into every step (the reference's COMMON blocks live as
@@ -232,8 +234,34 @@ int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
  * of the step after next (a leapfrog step) from this step's t(tau+1), as soon as T and S of it are final -- single
  * rank only (a latitude slab receives the halo rows of t(tau+1) with the exchange that follows) */
 int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, int iso_ahead);
+/* the same with relyr and co2ccn of the NEXT step named (the reference's clock advances every ocean step and tracer.F:311-338
+ * takes the month of the dust field and the declination from it): the look-ahead MOBI chain computes with them; should the
+ * next step then be given other values (uvic_gpu_set_mobi_step), it discards the chain's sources and computes its own */
+int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, double relyr_next,
+                               double co2ccn_next, int iso_ahead);
+int uvic_gpu_prefetch_sources_at(uvic_gpu *h, double c2dtts_next, double relyr_next, double co2ccn_next);
 int uvic_gpu_step_pre_async(uvic_gpu *h);
 int uvic_gpu_convect_async(uvic_gpu *h);
+
+/* ---- the resident Fortran overlay (uvic2.9_amd/fortran/tracer_gpu.F, UVIC_RESIDENT=1) -----------------------------
+ * 0: uvic_gpu_upload, _upload_rows and _set_mobi_step queue their copies on the main stream and return; the host
+ * buffers (COMMON blocks, page-locked with uvic_gpu_pin_host) must stay unchanged until the next call that waits
+ * (any download, uvic_gpu_overlay_step, uvic_gpu_sync).  Default 1. */
+int uvic_gpu_set_host_sync(uvic_gpu *h, int on);
+/* `set_sbc` (u09/mom/set_sbc.F:36-72, called at tracer.F:1273-1286) sums t(i,1,j,n,taup1) over the steps of an ocean
+ * segment for the atmosphere.  With the state on the device the sums of the listed tracers (1-based) are kept there --
+ * same additions, same order -- and fetched once per segment: count planes (imt, jmt), tracer order as listed */
+int uvic_gpu_sbc_config(uvic_gpu *h, int count, const int32_t *tracers);
+int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload);
+/* one resident step: forward-step aliasing, the step, its look-ahead chains (see uvic_gpu_step_lookahead_at), the
+ * surface sums (sbc_zero: a segment's first step, set_sbc.F:40-48; sbc_accumulate), T,S of t(tau+1) to `ts_host`
+ * (imt, km, jmt, 2; what clinic and the next loadmw read) and the rotation of the time levels.  Returns as soon as T,S
+ * are on the host; pass B of the other tracers may still be running, the next call queues behind it. */
+typedef struct uvic_overlay_step {
+  double c2dtts, c2dtts_next, relyr_next, co2ccn_next;
+  int32_t mixing, mobi_ahead, iso_ahead, sbc_zero, sbc_accumulate, pad;
+} uvic_overlay_step;
+int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_host);
 /* latitude-slab decomposition (uvic_gpu_set_shard js..je): the two outermost owned rows of t(tau+1) of every tracer
  * go to the neighbour's halo after each step (reach of the FCT stencil, u09/mom/tracer_adv_flx.F:553-555).  The library
  * packs them into contiguous staging buffers and unpacks what was received, both on its main stream; the caller moves

@@ -45,6 +45,8 @@ EXPORTS = [
     "uvic_gpu_profile", "uvic_gpu_profile_live", "uvic_gpu_profile_read", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_set_mobi_flat", "uvic_gpu_mobi", "uvic_gpu_prefetch_sources",
     "uvic_gpu_set_mixing", "uvic_gpu_set_exact", "uvic_gpu_adv_vel", "uvic_gpu_set_vmix_params", "uvic_gpu_vmixc", "uvic_gpu_set_filter", "uvic_gpu_prefetch_isopyc",
     "uvic_gpu_step_lookahead", "uvic_gpu_download_level", "uvic_gpu_set_mobi_step", "uvic_gpu_pin_host", "uvic_gpu_halo_elems", "uvic_gpu_halo_buffer", "uvic_gpu_halo_pack", "uvic_gpu_halo_unpack",
+    "uvic_gpu_step_lookahead_at", "uvic_gpu_prefetch_sources_at", "uvic_gpu_set_host_sync", "uvic_gpu_sbc_config",
+    "uvic_gpu_sbc_transfer", "uvic_gpu_overlay_step",
 ]
 
 
@@ -117,6 +119,13 @@ def load():
     lib.uvic_gpu_set_mobi_step.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 4
     lib.uvic_gpu_pin_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
     lib.uvic_gpu_step_lookahead.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+    lib.uvic_gpu_step_lookahead_at.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                               ctypes.c_double, ctypes.c_double, ctypes.c_int]
+    lib.uvic_gpu_prefetch_sources_at.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    lib.uvic_gpu_set_host_sync.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.uvic_gpu_sbc_config.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.uvic_gpu_sbc_transfer.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.uvic_gpu_overlay_step.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_halo_elems.restype = ctypes.c_int64
     lib.uvic_gpu_halo_elems.argtypes = [ctypes.c_void_p]
     lib.uvic_gpu_halo_buffer.restype = ctypes.c_void_p

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -133,6 +134,18 @@ __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
   coef_bv_cell(c, cf, i, k, j);
 }
 // NTR tracers per lane (kernels_col.hpp); g.total counts waves = (waves of the lane map) x ceil(nt_local / NTR)
+// The total advective velocities adv_v?t + adv_v?tiso are formed by the isopyc kernels.  When those ran a step ahead and the
+// host has since uploaded this step's adv_vet/vnt/vbt (the Fortran overlay does, every step), the sums are formed again
+// from the new velocities and the GM velocities computed ahead: the same additions, element by element.
+__global__ void __launch_bounds__(256) k_tot_vel(const uvic_ctx c) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long N3 = (long long)c.imt * c.km * c.jmt, NF = (long long)c.imt * (c.km + 1) * c.jmt;
+  if (gid < N3) {
+    c.tot_e[gid] = c.adv_vet[gid] + c.adv_vetiso[gid];
+    c.tot_n[gid] = c.adv_vnt[gid] + c.adv_vntiso[gid];
+  }
+  if (gid < NF) c.tot_b[gid] = c.adv_vbt[gid] + c.adv_vbtiso[gid];
+}
 template <int NTR, int PART>
 __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
   const int nblk = (g.total + 3) / 4;
@@ -346,12 +359,23 @@ __global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c,
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
   if (!(c.prio & 1)) __builtin_amdgcn_s_setprio(2);
+#ifdef UV_CLOCK_PROBE
+  // diagnostic build: shader clock held during this (long) kernel = d(s_memtime) / d(s_memrealtime) x 100 MHz
+  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   switch (threadIdx.y) {   // wave-uniform: every wave runs the code specialised for its role
     case 0: mobi_team_role<0>(c, m, lds, i, j, live, kmax); break;
     case 1: mobi_team_role<1>(c, m, lds, i, j, live, kmax); break;
     case 2: mobi_team_role<2>(c, m, lds, i, j, live, kmax); break;
     default: mobi_team_role<3>(c, m, lds, i, j, live, kmax); break;
   }
+#ifdef UV_CLOCK_PROBE
+  if (threadIdx.x == 0 && threadIdx.y == 0 && (blockIdx.x == 7 || blockIdx.x == 70)) {
+    const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+    printf("clock probe blk %d: %llu shader cycles in %llu ticks of 10 ns = %.0f MHz\n", blockIdx.x, ck1 - ck0, rt1 - rt0,
+           (double)(ck1 - ck0) / (double)(rt1 - rt0) * 100.0);
+  }
+#endif
 }
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,6 +545,17 @@ struct uvic_gpu {
   uvic_ctx iso_fuse_ctx;
   double *iso_fuse_coef;
   int iso_fuse_set;
+  // resident overlay (uvic_gpu_overlay_step): uploads without host synchronisation, T,S of t(tau+1) sent to the host as soon
+  // as they are final, the surface boundary condition sums of set_sbc kept on the device
+  bool host_sync;               // 0: uploads are queued on the main stream and not waited for
+  double *ts_host;              // where T,S of this step's t(tau+1) go (null: nowhere); set for one step by overlay_step
+  hipEvent_t ev_ts_host;
+  bool ts_host_queued;
+  int sbc_count;                // tracers whose surface level is accumulated
+  int *sbc_tracer;              // device: their 1-based tracer numbers
+  double *sbc_acc;              // device (imt, jmt, sbc_count)
+  // what the look-ahead MOBI chain assumed about the step it computed for (checked when that step starts)
+  double src_relyr, src_co2ccn, src_c2dtts;
   bool ts_apply;      // ... and pass B of the other tracers did not replay the mixing: convect_apply follows it (conv_decoupled)
   bool conv_decoupled;   // pass B of the other tracers does not wait for the T,S chain (UVIC_CONV_DECOUPLED, default 1)
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
@@ -533,6 +568,7 @@ struct uvic_gpu {
     double *work[3], *coef;
     hipEvent_t ev;          // recorded behind the chain that filled the set
     long long for_step;     // the step whose fields a look-ahead chain put there, -1: none
+    bool vel_stale;         // adv_vet/vnt/vbt were uploaded after the chain had formed the total velocities from them
     bool allocated;
   } iso_set[3];
   int iso_cur;
@@ -575,7 +611,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 2; }
+extern "C" int uvic_gpu_abi_version(void) { return 3; }
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -659,6 +695,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
   h->ts_apply = false;
+  h->host_sync = true; h->ts_host = nullptr; h->ts_host_queued = false;
+  HIPCHK(hipEventCreateWithFlags(&h->ev_ts_host, hipEventDisableTiming));
+  h->sbc_count = 0; h->sbc_tracer = nullptr; h->sbc_acc = nullptr;
+  h->src_relyr = h->src_co2ccn = 0.0;
   h->iso_fuse_armed = false;
   h->iso_fuse = false;   // measured: the shared launches take as long as the seven separate ones (the chip is saturated)
   if (const char *e = getenv("UVIC_ISO_FUSE")) h->iso_fuse = atoi(e) != 0;
@@ -791,6 +831,9 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
   (void)hipFree(h->cv_z);
   (void)hipFree(h->cv_list);
+  (void)hipFree(h->sbc_tracer);
+  (void)hipFree(h->sbc_acc);
+  (void)hipEventDestroy(h->ev_ts_host);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
     (void)hipFree(h->mobi_st.work);
@@ -976,6 +1019,11 @@ static int src_clean(uvic_gpu *h, void *src, hipStream_t st) {
 }
 
 // the host wrote into a time level of t: its land columns are the host's business again (land_clean)
+static void velocity_touched(uvic_gpu *h, int field) {
+  if (field != UVIC_F_ADV_VET && field != UVIC_F_ADV_VNT && field != UVIC_F_ADV_VBT) return;
+  for (int q = 0; q < 3; ++q)
+    if (h->iso_set[q].for_step >= 0) h->iso_set[q].vel_stale = true;
+}
 static void land_touched(uvic_gpu *h, int field) {
   if (field != UVIC_F_T_TAUM1 && field != UVIC_F_T_TAU && field != UVIC_F_T_TAUP1) return;
   auto &v = h->land_zeroed;
@@ -999,13 +1047,16 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
     h->end_ready = h->end_pending = false;
   }
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  // (the time levels of t are not among what the resident overlay re-fills every step: always waited for)
+  const bool t_field = field == UVIC_F_T_TAUM1 || field == UVIC_F_T_TAU || field == UVIC_F_T_TAUP1;
+  if (h->host_sync || field == UVIC_F_KMT || t_field) HIPCHK(hipStreamSynchronize(h->stream));
   if (field == UVIC_F_ITRC && offset == 0 && count >= 2) {
     const int32_t *it = (const int32_t *)host;
     h->ts_no_src = it[0] == 0 && it[1] == 0;
   }
   if (field == UVIC_F_SRC) h->src_zeroed.clear();
   land_touched(h, field);
+  velocity_touched(h, field);
   if (field == UVIC_F_KMT) return make_tmask(h);
   return 0;
 }
@@ -1021,7 +1072,13 @@ extern "C" int uvic_gpu_download(uvic_gpu *h, int field, void *host, int64_t off
   return 0;
 }
 
+static double g_xfer_ms = 0.0;   // UVIC_OVL_TIMING: host time spent inside the transfer entry points since the last report
+struct XferTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ~XferTimer() { g_xfer_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, bool up) {
+  XferTimer tm_;
   if (!h || !host) return fail_msg("uvic_gpu_*_rows: null argument");
   if (field < 0 || field >= UVIC_F_COUNT || FIELDS[field].is_int) return fail_msg("uvic_gpu_*_rows: bad field id");
   const Kind kd = FIELDS[field].kind;
@@ -1032,7 +1089,13 @@ static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, boo
   const int64_t nrows = jhi - jlo + 1;
   HIPCHK(hipSetDevice(h->device));
   if (up && field == UVIC_F_SRC) h->src_zeroed.clear();
-  if (up) land_touched(h, field);
+  if (up) { land_touched(h, field); velocity_touched(h, field); }
+  if (jlo == 1 && jhi == h->d.jmt && ex > 1) {   // every row: the planes of all `extra` entries are one contiguous range
+    if (up)                                       // (one copy instead of nt of them: each costs ~10 us of stream time)
+      HIPCHK(hipMemcpyAsync(h->buf[field], host, (size_t)ex * plane(h->d, kd) * 8, hipMemcpyHostToDevice, h->stream));
+    else
+      HIPCHK(hipMemcpyAsync(host, h->buf[field], (size_t)ex * plane(h->d, kd) * 8, hipMemcpyDeviceToHost, h->stream));
+  } else
   for (int64_t e = 0; e < ex; ++e) {
     char *dev = (char *)h->buf[field] + (e * plane(h->d, kd) + (int64_t)(jlo - 1) * rowlen) * 8;
     char *hst = (char *)host + e * nrows * rowlen * 8;
@@ -1041,7 +1104,8 @@ static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, boo
     else
       HIPCHK(hipMemcpyAsync(hst, dev, nrows * rowlen * 8, hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHK(hipStreamSynchronize(h->stream));
+  const bool t_field = field == UVIC_F_T_TAUM1 || field == UVIC_F_T_TAU || field == UVIC_F_T_TAUP1;
+  if (h->host_sync || !up || t_field) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 extern "C" int uvic_gpu_upload_rows(uvic_gpu *h, int field, const double *host, int jlo, int jhi) {
@@ -1202,10 +1266,28 @@ static int launch_isopyc(uvic_gpu *h) {
   h->iso_waited = false;
   const int set = (int)(h->step_no % 3);
   if (int rc = use_iso_set(h, set)) return rc;
+  if (h->iso_set[set].for_step == h->step_no && h->mixing) {
+    // computed ahead for a leapfrog step, but this is a forward step (t(tau-1) := t(tau)): void; redo it behind the chain
+    HIPCHK(hipStreamWaitEvent(h->stream, h->iso_set[set].ev, 0));
+    h->iso_set[set].for_step = -1;
+  }
   if (h->iso_set[set].for_step == h->step_no) {   // computed ahead on a side stream (uvic_gpu_prefetch_isopyc)
     HIPCHK(hipStreamWaitEvent(h->stream, h->iso_set[set].ev, 0));
     h->iso_set[set].for_step = -1;
     h->iso_waited = true;
+    if (h->iso_set[set].vel_stale) {   // this step's velocities arrived after the chain ran
+      const long long nf = (long long)h->d.imt * (h->d.km + 1) * h->d.jmt;
+      hipLaunchKernelGGL(k_tot_vel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, h->stream, h->ctx);
+      mark(h, "tot_vel");
+      h->iso_set[set].vel_stale = false;
+      h->iso_waited = false;   // the T,S stream reads them too: it must not start before this
+    }
+    if (h->ctx.diff_cbt_given && !h->exact) {   // ... and so did the step's own diff_cbt
+      hipLaunchKernelGGL(k_coef_bv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
+      mark(h, "coef_bv");
+      h->iso_waited = false;
+    }
+    HIPCHK(hipGetLastError());
     return 0;
   }
   return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
@@ -1279,6 +1361,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         mark_on(h, "convect_ts", 3);
         HIPCHK(hipEventRecord(h->iso_set[h->iso_fuse_set].ev, h->side_ts));
         h->iso_set[h->iso_fuse_set].for_step = h->step_no + 1;
+        h->iso_set[h->iso_fuse_set].vel_stale = false;
       } else {
         if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
         mark_on(h, "colfct_ts", 3);
@@ -1296,6 +1379,11 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         h->src_from_prefetch = false;
       }
       HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
+      if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
+        HIPCHK(hipMemcpyAsync(h->ts_host, c.t_taup1, (size_t)2 * c.imt * c.km * c.jmt * 8, hipMemcpyDeviceToHost, h->side_ts));
+        HIPCHK(hipEventRecord(h->ev_ts_host, h->side_ts));
+        h->ts_host_queued = true;
+      }
       h->ts_ahead = true;
       h->ts_apply = h->conv_decoupled;
       if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
@@ -1395,18 +1483,18 @@ static int launch_convect(uvic_gpu *h) {
   return 0;
 }
 // per-step scalars, updates/09/source/mom/tracer.F:311-343
-static int mobi_step_scalars(uvic_gpu *h, double c2dtts, mobi_step &S) {
+static int mobi_step_scalars(uvic_gpu *h, double c2dtts, double relyr, mobi_step &S) {
   if (c2dtts == 0.0) return fail_msg("uvic_gpu_mobi: c2dtts not set (uvic_gpu_set_params)");
   S.nbio = (int)(c2dtts / h->mobi_dtnpzd);
   if (S.nbio < 1) return fail_msg("uvic_gpu_mobi: c2dtts/dtnpzd < 1");
   S.dtbio = c2dtts / S.nbio;
   S.rdtts = 1. / c2dtts;
   S.rnbio = 1. / S.nbio;
-  const double yrtime = fmod(h->mobi.relyr, 1.);
+  const double yrtime = fmod(relyr, 1.);
   S.month = 12;
   for (int m = 1; m <= 12; ++m)
     if (yrtime <= m / 12.) { S.month = m; break; }
-  S.declin = sin((fmod(h->mobi.relyr, 1.) - 0.22) * 2. * h->mobi.pi) * 0.4;
+  S.declin = sin((fmod(relyr, 1.) - 0.22) * 2. * h->mobi.pi) * 0.4;
   return 0;
 }
 // the three MOBI passes over the ocean columns of the slab, on stream `st` (profile list `sid`)
@@ -1431,8 +1519,19 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
 }
 static int launch_mobi(uvic_gpu *h) {
   if (!h->have_mobi) return 0;
-  if (h->src_from_prefetch) return 0;  // computed one step ahead on the side stream; launch_transport waits for it
-  if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.S)) return rc;
+  if (h->src_from_prefetch) {   // computed one step ahead on the side stream; launch_transport waits for it
+    // The chain assumed a leapfrog step with c2dtts_next and named a clock and a CO2 value.  The bit-exact path takes its
+    // sources only if all of that came true to the bit; the production path also when the clock it was promised differs
+    // by rounding (a caller that extrapolates relyr), as long as the month of the dust field is the same.
+    auto month_of = [](double relyr) { const double y = fmod(relyr, 1.); int mo = 12; for (int q = 1; q <= 12; ++q) if (y <= q / 12.) { mo = q; break; } return mo; };
+    const bool clock_ok = h->src_relyr == h->mobi.relyr ||
+                          (!h->exact && fabs(h->src_relyr - h->mobi.relyr) <= 1e-9 && month_of(h->src_relyr) == month_of(h->mobi.relyr));
+    if (!h->mixing && h->src_c2dtts == h->ctx.c2dtts && clock_ok && h->src_co2ccn == h->mobi.co2ccn) return 0;
+    // otherwise its sources are void: recompute in line, behind the chain (it wrote the buffer this step reads)
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+    h->src_from_prefetch = false;
+  }
+  if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.relyr, h->mobi.S)) return rc;
   return launch_mobi_on(h, h->ctx, h->mobi, h->stream, 0);
 }
 
@@ -1577,15 +1676,26 @@ extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
   return step_end(h);
 }
 extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next);
+extern "C" int uvic_gpu_prefetch_sources_at(uvic_gpu *h, double c2dtts_next, double relyr_next, double co2ccn_next);
 extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h);
 static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead);
 extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on);
+extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, double relyr_next,
+                                          double co2ccn_next, int iso_ahead);
 // One call per time step for a device-resident loop: what the Python TimeLoop does with six (at 0.2 ms per step of a
 // small slab the host's share counts).  mixing: forward step (t(tau-1) := t(tau), c2dtts = dtts); mobi_ahead, iso_ahead:
 // start the look-ahead chains of the NEXT step (only when that one is a leapfrog step with c2dtts_next and, for MOBI,
 // keeps this step's surface forcing).  The caller then exchanges halo rows if it has neighbours, and calls
 // uvic_gpu_rotate (which also ends a forward step's aliasing).
+// The `_at` form names relyr and co2ccn of the next step (the reference advances its clock every ocean step and takes the
+// month of the dust field and the declination from it, tracer.F:311-338): the look-ahead MOBI chain computes with them,
+// and the next step discards the chain's sources if it is then given other values (uvic_gpu_set_mobi_step).
 extern "C" int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, int iso_ahead) {
+  if (!h) return fail_msg("null handle");
+  return uvic_gpu_step_lookahead_at(h, c2dtts, mixing, mobi_ahead, c2dtts_next, h->mobi.relyr, h->mobi.co2ccn, iso_ahead);
+}
+extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing, int mobi_ahead, double c2dtts_next, double relyr_next,
+                                          double co2ccn_next, int iso_ahead) {
   if (!h) return fail_msg("null handle");
   if (int rc = uvic_gpu_set_mixing(h, mixing)) return rc;
   h->ctx.c2dtts = c2dtts;
@@ -1608,13 +1718,12 @@ extern "C" int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, i
   if (int rc = uvic_gpu_step_async(h)) return rc;
   h->iso_fuse_armed = false;   // not taken (no T,S launches of their own in this configuration): the chain below does it
   if (mobi_ahead && h->have_mobi)
-    if (int rc = uvic_gpu_prefetch_sources(h, c2dtts_next)) return rc;
-  if (!h->ctx.diff_cbt_given) {   // bit 0: the next step is a leapfrog step, bit 1: the step after next is (and no halo exchange follows)
-    if (iso_ahead & 1)
-      if (int rc = prefetch_isopyc_ahead(h, 1)) return rc;
-    if (iso_ahead & 2)
-      if (int rc = prefetch_isopyc_ahead(h, 2)) return rc;
-  }
+    if (int rc = uvic_gpu_prefetch_sources_at(h, c2dtts_next, relyr_next, co2ccn_next)) return rc;
+  // bit 0: the next step is a leapfrog step, bit 1: the step after next is (and no halo exchange follows)
+  if (iso_ahead & 1)
+    if (int rc = prefetch_isopyc_ahead(h, 1)) return rc;
+  if ((iso_ahead & 2) && !h->ctx.diff_cbt_given)
+    if (int rc = prefetch_isopyc_ahead(h, 2)) return rc;
   h->unmix_at_rotate = mixing != 0;
   return 0;
 }
@@ -1622,6 +1731,10 @@ extern "C" int uvic_gpu_step_lookahead(uvic_gpu *h, double c2dtts, int mixing, i
 // the side stream, overlapped with this step's transport.  Call before (preferred: its kernels are then queued ahead of this step's side-stream work) or after uvic_gpu_step_async
 // and before uvic_gpu_rotate; only valid when the next step is a leapfrog step.
 extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
+  if (!h) return fail_msg("null handle");
+  return uvic_gpu_prefetch_sources_at(h, c2dtts_next, h->mobi.relyr, h->mobi.co2ccn);   // a clock that stands still
+}
+extern "C" int uvic_gpu_prefetch_sources_at(uvic_gpu *h, double c2dtts_next, double relyr_next, double co2ccn_next) {
   if (!h) return fail_msg("null handle");
   if (!h->have_mobi) return 0;
   const size_t bytes = (size_t)field_elems(h->d, UVIC_F_SRC) * 8;
@@ -1638,7 +1751,9 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
   mobi_set_work(&m, h->mobi_st.work_side[q], h->d.imt, h->d.jmt, h->d.km);
   c.src = (const double *)h->src_alt;
   c.c2dtts = c2dtts_next;
-  if (int rc = mobi_step_scalars(h, c2dtts_next, m.S)) return rc;
+  m.relyr = relyr_next; m.co2ccn = co2ccn_next;   // tracer.F:311-338 takes month and declination from the step's own relyr
+  h->src_relyr = relyr_next; h->src_co2ccn = co2ccn_next; h->src_c2dtts = c2dtts_next;
+  if (int rc = mobi_step_scalars(h, c2dtts_next, relyr_next, m.S)) return rc;
   if (int rc = step_begin(h)) return rc;
   // src_alt was read last by pass B of the previous step (before ev_step_begin); the other chain writes the other buffer
   // (the end of the previous step's own work is enough: MOBI is column-local, the halo rows do not matter to it)
@@ -1659,7 +1774,8 @@ extern "C" int uvic_gpu_prefetch_sources(uvic_gpu *h, double c2dtts_next) {
 //              rows arrives with the exchange).
 // Call after uvic_gpu_step_async and before uvic_gpu_rotate; only valid when the target step is a leapfrog step.
 static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead) {
-  if (h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_prefetch_isopyc: not with an uploaded diff_cbt (diff_cbt_has_k33 = 1)");
+  // (with an uploaded diff_cbt -- host vmixc, diff_cbt_has_k33 = 1 -- the chain leaves diff_cbt alone and the folded
+  // vertical-diffusion coefficient is renewed by k_coef_bv once that step's diff_cbt is there: launch_isopyc)
   HIPCHK(hipSetDevice(h->device));
   const long long target = h->step_no + ahead;
   const int set = (int)(target % 3), cur = h->iso_cur;
@@ -1684,6 +1800,7 @@ static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead) {
   if (int rc = launch_isopyc_on(h, c, coef, st, sid)) return rc;
   HIPCHK(hipEventRecord(h->iso_set[set].ev, st));
   h->iso_set[set].for_step = target;
+  h->iso_set[set].vel_stale = false;
   return 0;
 }
 extern "C" int uvic_gpu_prefetch_isopyc(uvic_gpu *h) {
@@ -1771,8 +1888,9 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->src_from_prefetch = true;
     h->ev_src_ready = h->ev_src_pending;
   }
-  h->step_no += 1;      // the T,S-derived fields of the new step: launch_isopyc takes set step_no % 3
-  h->ts_final_valid = false;
+  h->step_no += 1;      // the T,S-derived fields of the new step live in set step_no % 3: current from now on, so that
+  h->ts_final_valid = false;   // a diff_cbt uploaded for that step lands in it
+  if (int rc = use_iso_set(h, (int)(h->step_no % 3))) return rc;
   bind_ctx(h);
   return 0;
 }
@@ -1891,13 +2009,23 @@ extern "C" int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc,
 // current step; relyr selects the month of the dust field and the declination; co2ccn the atmospheric CO2)
 extern "C" int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, const double *dnswr, const double *aice,
                                       const double *hice, const double *hsno) {
-  if (!h || !dnswr || !aice || !hice || !hsno) return fail_msg("uvic_gpu_set_mobi_step: null argument");
+  if (!h) return fail_msg("uvic_gpu_set_mobi_step: null argument");
   if (!h->have_mobi) return fail_msg("uvic_gpu_set_mobi_step: call uvic_gpu_set_mobi first");
   HIPCHK(hipSetDevice(h->device));
-  const size_t bytes = (size_t)h->d.imt * h->d.jmt * 8;
   const double *src[4] = {dnswr, aice, hice, hsno};
-  for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  if (dnswr || aice || hice || hsno) {   // (all null: the forcing fields stay, only the clock and the CO2 move on)
+    if (!dnswr || !aice || !hice || !hsno) return fail_msg("uvic_gpu_set_mobi_step: give all four forcing fields or none");
+    // a look-ahead chain still running reads the old fields, and its sources are not those of the new forcing
+    for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
+    h->prefetch_pending = false;
+    if (h->src_from_prefetch) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+      h->src_from_prefetch = false;
+    }
+    const size_t bytes = (size_t)h->d.imt * h->d.jmt * 8;
+    for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, h->stream));
+    if (h->host_sync) HIPCHK(hipStreamSynchronize(h->stream));
+  }
   h->mobi.relyr = relyr;
   h->mobi.co2ccn = co2ccn;
   return 0;
@@ -1912,6 +2040,90 @@ extern "C" int uvic_gpu_pin_host(uvic_gpu *h, void *ptr, int64_t bytes) {
   if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return 0; }
   if (e != hipSuccess) return fail("hipHostRegister", e, __LINE__);
   return 0;
+}
+extern "C" int uvic_gpu_set_host_sync(uvic_gpu *h, int on) {
+  if (!h) return fail_msg("null handle");
+  h->host_sync = on != 0;
+  return 0;
+}
+// -- surface boundary condition sums (u09/mom/set_sbc.F:36-72) kept on the device ---------------------------------------
+// set_sbc adds t(i,1,j,n,taup1) to sbc(i,j,isbc) every step, zeroes sbc at a segment's first step and averages it at
+// the last (ocean points only).  With the state resident the host would need the surface level of every such tracer
+// each step for nothing but this sum: the device keeps the sums (same additions in the same order) and the host fetches
+// them once per segment.
+__global__ void __launch_bounds__(256) k_sbc_accumulate(const uvic_ctx c, const int *tracers, double *acc, int count, int zero_first) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long ns = (long long)c.imt * c.jmt;
+  if (gid >= ns * count) return;
+  const int q = (int)(gid / ns), ij = (int)(gid % ns);
+  const int i = ij % c.imt, j = ij / c.imt;
+  double a = acc[gid];
+  if (zero_first && c.kmt[ij] != 0) a = 0.0;
+  const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+  acc[gid] = a + c.t_taup1[(size_t)(tracers[q] - 1) * N3 + (size_t)i + (size_t)c.imt * c.km * j];
+}
+extern "C" int uvic_gpu_sbc_config(uvic_gpu *h, int count, const int32_t *tracers) {
+  if (!h || count < 0 || (count > 0 && !tracers)) return fail_msg("uvic_gpu_sbc_config: bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  for (int q = 0; q < count; ++q)
+    if (tracers[q] < 1 || tracers[q] > h->d.nt) return fail_msg("uvic_gpu_sbc_config: tracer number outside 1..nt");
+  (void)hipFree(h->sbc_tracer); (void)hipFree(h->sbc_acc);
+  h->sbc_tracer = nullptr; h->sbc_acc = nullptr; h->sbc_count = count;
+  if (count == 0) return 0;
+  const size_t n = (size_t)h->d.imt * h->d.jmt * count;
+  HIPCHK(hipMalloc((void **)&h->sbc_tracer, (size_t)count * 4));
+  HIPCHK(hipMemcpy(h->sbc_tracer, tracers, (size_t)count * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void **)&h->sbc_acc, n * 8));
+  HIPCHK(hipMemset(h->sbc_acc, 0, n * 8));
+  return 0;
+}
+// host (imt, jmt, count) <-> the sums; synchronises the main stream
+extern "C" int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload) {
+  if (!h || !host) return fail_msg("uvic_gpu_sbc_transfer: null argument");
+  if (h->sbc_count == 0) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->d.imt * h->d.jmt * h->sbc_count * 8;
+  if (upload) HIPCHK(hipMemcpyAsync(h->sbc_acc, host, bytes, hipMemcpyHostToDevice, h->stream));
+  else HIPCHK(hipMemcpyAsync(host, h->sbc_acc, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// One call of the resident Fortran overlay: the step and its look-ahead chains are queued, T and S of t(tau+1) travel to
+// `ts_host` (imt, km, jmt, 2) as soon as they are final, the surface sums are updated behind the step, the time levels
+// rotate -- and the call returns when T,S are on the host, while pass B of the other tracers may still be running
+// (the next call queues behind it).
+extern "C" int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_host) {
+  if (!h || !s) return fail_msg("uvic_gpu_overlay_step: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  static const bool timing = getenv("UVIC_OVL_TIMING") != nullptr;   // diagnosis: host wall time of the call's parts
+  const auto tq0 = std::chrono::steady_clock::now();
+  h->ts_host = ts_host;
+  h->ts_host_queued = false;
+  if (int rc = uvic_gpu_step_lookahead_at(h, s->c2dtts, s->mixing, s->mobi_ahead, s->c2dtts_next, s->relyr_next, s->co2ccn_next, s->iso_ahead))
+    return rc;
+  h->ts_host = nullptr;
+  const auto tq1 = std::chrono::steady_clock::now();
+  if (h->sbc_count > 0 && (s->sbc_accumulate || s->sbc_zero)) {
+    const long long n = (long long)h->d.imt * h->d.jmt * h->sbc_count;
+    hipLaunchKernelGGL(k_sbc_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx, (const int *)h->sbc_tracer,
+                       h->sbc_acc, h->sbc_count, s->sbc_zero);
+    HIPCHK(hipGetLastError());
+  }
+  if (ts_host) {
+    if (h->ts_host_queued) {
+      HIPCHK(hipEventSynchronize(h->ev_ts_host));
+    } else {   // no T,S passes of their own in this configuration: behind the whole step
+      HIPCHK(hipMemcpyAsync(ts_host, h->ctx.t_taup1, (size_t)2 * h->d.imt * h->d.km * h->d.jmt * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+  }
+  if (timing) {
+    const auto tq2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "overlay_step: queueing %.3f ms, wait for T,S %.3f ms; row transfers before it %.3f ms\n",
+            std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(tq2 - tq1).count(), g_xfer_ms);
+    g_xfer_ms = 0.0;
+  }
+  return uvic_gpu_rotate(h);
 }
 extern "C" int uvic_gpu_mobi(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");

@@ -14,6 +14,13 @@
         integer(c_int32_t) :: imt, jmt, km, nt, nsrc, ntnpzd
       end type uvic_dims
 
+!     one resident step (include/uvic_gpu.h: uvic_overlay_step)
+      type, bind(C) :: uvic_overlay_step
+        real(c_double) :: c2dtts, c2dtts_next, relyr_next, co2ccn_next
+        integer(c_int32_t) :: mixing, mobi_ahead, iso_ahead, sbc_zero
+        integer(c_int32_t) :: sbc_accumulate, pad
+      end type uvic_overlay_step
+
       type, bind(C) :: uvic_params
         real(c_double) :: c2dtts, aidif, diff_cet, diff_cnt
         real(c_double) :: slmxr, ahisop, athkdf
@@ -155,6 +162,47 @@
           type(c_ptr), value :: h
           integer(c_int) :: rc
         end function
+        function uvic_gpu_set_host_sync(h, on) bind(C,name='uvic_gpu_set_host_sync') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: on
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_sbc_config(h, count, tracers) bind(C,name='uvic_gpu_sbc_config') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: count
+          integer(c_int32_t) :: tracers(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_sbc_transfer(h, host, upload) bind(C,name='uvic_gpu_sbc_transfer') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double) :: host(*)
+          integer(c_int), value :: upload
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_overlay_step(h, s, ts_host) bind(C,name='uvic_gpu_overlay_step') result(rc)
+          import
+          type(c_ptr), value :: h
+          type(uvic_overlay_step) :: s
+          real(c_double) :: ts_host(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_mobi_clock(h, relyr, co2ccn, p1, p2, p3, p4)                                    &
+     &      bind(C,name='uvic_gpu_set_mobi_step') result(rc)
+!         uvic_gpu_set_mobi_step with null forcing fields: only relyr and co2ccn move on
+          import
+          type(c_ptr), value :: h
+          real(c_double), value :: relyr, co2ccn
+          type(c_ptr), value :: p1, p2, p3, p4
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_sync(h) bind(C,name='uvic_gpu_sync') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_last_error() bind(C,name='uvic_gpu_last_error') result(msg)
           import
           type(c_ptr) :: msg
@@ -166,6 +214,10 @@
 !     the device from step to step; uvic_dev_state says that the device holds t(tau-1), t(tau) of the coming step
       logical, save :: uvic_resident = .false.
       logical, save :: uvic_dev_state = .false.
+!     resident mode keeps the surface sums of set_sbc on the device for these tracers (n >= 3 with trsbcindex(n) /= 0)
+      integer, save :: uvic_nsbc = 0
+      integer(c_int32_t), allocatable, save :: uvic_sbc_tracer(:)
+      real(c_double), allocatable, save :: uvic_sbc_plane(:,:,:)
 
       contains
 
