@@ -208,3 +208,42 @@ def test_gpu_time_loop_with_source_prefetch_matches_golden_run(prefetch):
         assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (name, prefetch)
     assert np.array_equal(got[:, :, 1:13, :2], g["t"][:, :, 1:13, :2])
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False])
+def test_lookahead_with_an_advancing_clock_equals_inline(exact):
+    """The reference advances relyr every ocean step and takes the month of the dust field and the solar declination
+    from it (u09/mom/tracer.F:311-338).  The look-ahead chain of step n+1 runs during step n: it must compute with the
+    clock of step n+1 (uvic_gpu_step_lookahead_at), or a run with look-ahead differs from one that computes its sources
+    in line.  Six steps across a month boundary (relyr 1/12), both ways: same bits."""
+    from uvic29_amd.tracer import TracerModel, TimeLoop
+    oc = synthetic.make_ocean("c30", 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    dyr = oc.params.dtts / (365.0 * 86400.0)
+    clock = (1.0 / 12.0 - 2.5 * dyr, dyr, oc.forcing.co2ccn)      # the boundary falls between steps 3 and 4
+    out = {}
+    for ahead in (True, False):
+        m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+        m.set_exact(exact)
+        m.load_ocean(oc, to, so, c)
+        m.set_mobi(oc)
+        loop = TimeLoop(m, oc.params.dtts, oc.params.nmix, prefetch=ahead, clock=clock)
+        for _ in range(6):
+            loop.step()
+        m.sync()
+        out[ahead] = m.download("t_tau")
+        m.close()
+    assert np.array_equal(out[True], out[False])
+    # ... and the clock matters: a run whose clock stands still gives other sources
+    m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.set_exact(exact)
+    m.load_ocean(oc, to, so, c)
+    m.set_mobi(oc)
+    loop = TimeLoop(m, oc.params.dtts, oc.params.nmix)
+    for _ in range(6):
+        loop.step()
+    m.sync()
+    still = m.download("t_tau")
+    m.close()
+    assert not np.array_equal(still, out[True])

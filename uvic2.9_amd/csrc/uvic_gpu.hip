@@ -895,6 +895,10 @@ static int make_tmask(uvic_gpu *h) {
         if (kmt[(size_t)(i - 1) + (size_t)imt * (j - 1)] > 0) wet.push_back((i - 1) + imt * (j - 1));
   }
   h->wet_row_start[jmt + 1] = (int)wet.size();
+  for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));   // a look-ahead chain may still walk the old list
+  HIPCHK(hipStreamSynchronize(h->side2));
+  h->prefetch_pending = h->src_from_prefetch = false;
+  for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;
   (void)hipFree(h->wet_dev);
   h->wet_dev = nullptr;
   HIPCHK(hipMalloc((void **)&h->wet_dev, (wet.size() + 1) * 4));
@@ -1018,6 +1022,19 @@ static int src_clean(uvic_gpu *h, void *src, hipStream_t st) {
   return 0;
 }
 
+// new state (a time level of t) or new sources from the host: whatever the side streams computed ahead from the old ones
+// is void, and they must have finished before the buffers change under them
+static int state_from_host(uvic_gpu *h, int field) {
+  if (field != UVIC_F_T_TAUM1 && field != UVIC_F_T_TAU && field != UVIC_F_T_TAUP1 && field != UVIC_F_SRC) return 0;
+  for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
+  HIPCHK(hipStreamSynchronize(h->side2));
+  HIPCHK(hipStreamSynchronize(h->side_ts));
+  h->prefetch_pending = h->src_from_prefetch = false;
+  for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;
+  h->ts_final_valid = false;
+  h->end_ready = h->end_pending = false;
+  return 0;
+}
 // the host wrote into a time level of t: its land columns are the host's business again (land_clean)
 static void velocity_touched(uvic_gpu *h, int field) {
   if (field != UVIC_F_ADV_VET && field != UVIC_F_ADV_VNT && field != UVIC_F_ADV_VBT) return;
@@ -1036,16 +1053,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
   if (offset < 0 || count < 0 || offset + count > n) return fail_msg(std::string("uvic_gpu_upload: range outside field ") + FIELDS[field].name);
   HIPCHK(hipSetDevice(h->device));
   const size_t es = elem_size(field);
-  if (field == UVIC_F_T_TAUM1 || field == UVIC_F_T_TAU || field == UVIC_F_T_TAUP1) {
-    // new state from the host: whatever the side streams computed ahead from the old one is void
-    for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
-    HIPCHK(hipStreamSynchronize(h->side2));
-  HIPCHK(hipStreamSynchronize(h->side_ts));
-    h->prefetch_pending = h->src_from_prefetch = false;
-    for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;
-    h->ts_final_valid = false;
-    h->end_ready = h->end_pending = false;
-  }
+  if (int rc = state_from_host(h, field)) return rc;
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
   // (the time levels of t are not among what the resident overlay re-fills every step: always waited for)
   const bool t_field = field == UVIC_F_T_TAUM1 || field == UVIC_F_T_TAU || field == UVIC_F_T_TAUP1;
@@ -1089,7 +1097,10 @@ static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, boo
   const int64_t nrows = jhi - jlo + 1;
   HIPCHK(hipSetDevice(h->device));
   if (up && field == UVIC_F_SRC) h->src_zeroed.clear();
-  if (up) { land_touched(h, field); velocity_touched(h, field); }
+  if (up) {
+    if (int rc = state_from_host(h, field)) return rc;
+    land_touched(h, field); velocity_touched(h, field);
+  }
   if (jlo == 1 && jhi == h->d.jmt && ex > 1) {   // every row: the planes of all `extra` entries are one contiguous range
     if (up)                                       // (one copy instead of nt of them: each costs ~10 us of stream time)
       HIPCHK(hipMemcpyAsync(h->buf[field], host, (size_t)ex * plane(h->d, kd) * 8, hipMemcpyHostToDevice, h->stream));

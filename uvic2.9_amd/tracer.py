@@ -262,12 +262,15 @@ class TimeLoop:
     With MOBI, the source terms of the next leapfrog step are started one step ahead on a
     side stream (they depend only on t(tau-1) of that step = t(tau) of this one)."""
 
-    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True, segment=0):
+    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True, segment=0, clock=None):
         """segment = ntspos, the ocean steps per coupling segment (u09/common/UVic_ESCM.F:177-189): the surface forcing
         MOBI reads changes at a segment's first step, whose sources therefore cannot be computed one step ahead
         (0: the forcing never changes during the loop)."""
         self.m, self.dtts, self.nmix, self.shard, self.prefetch = model, float(dtts), int(nmix), shard, prefetch
         self.segment = int(segment)
+        # clock = (relyr of the first step, increment per step, co2ccn): the reference advances relyr every ocean step and
+        # MOBI takes the month of the dust field and the declination from it (u09/mom/tracer.F:311-338); None: it stands still
+        self.clock = clock
         self.iso2 = os.environ.get("UVIC_ISO2", "0") != "0"      # 1: isopyc two steps ahead on the idle MOBI stream (measured: no gain)
         self.itt = 0
 
@@ -288,8 +291,16 @@ class TimeLoop:
             if self.prefetch and not m.params.diff_cbt_has_k33:
                 iso_ahead = (1 if ahead else 0) | (2 if self.shard is None and self.iso2 and not self._mixing(self.itt + 2) else 0)
             c2dtts = self.dtts if mixing else 2.0 * self.dtts
-            check(m.lib.uvic_gpu_step_lookahead(m.h, c2dtts, int(mixing), int(mobi_ahead), 2.0 * self.dtts, int(iso_ahead)),
-                  "step_lookahead")
+            if self.clock is None:
+                check(m.lib.uvic_gpu_step_lookahead(m.h, c2dtts, int(mixing), int(mobi_ahead), 2.0 * self.dtts, int(iso_ahead)),
+                      "step_lookahead")
+            else:
+                relyr0, dyr, co2 = self.clock
+                relyr = relyr0 + (self.itt - 1) * dyr
+                if m.has_mobi:      # this step's clock (forcing fields unchanged), then the step with the next step's named
+                    check(m.lib.uvic_gpu_set_mobi_step(m.h, relyr, co2, None, None, None, None), "set_mobi_step")
+                check(m.lib.uvic_gpu_step_lookahead_at(m.h, c2dtts, int(mixing), int(mobi_ahead), 2.0 * self.dtts,
+                                                       relyr0 + self.itt * dyr, co2, int(iso_ahead)), "step_lookahead_at")
             m.params.c2dtts = c2dtts          # the mirror of uvic_params follows
             if self.shard is not None:
                 self.shard.after_step(m)
