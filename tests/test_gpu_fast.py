@@ -28,10 +28,10 @@ def _rand_src(oc, seed=2029, scale=1e-9):
 
 
 @pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("c30", (102, 102, 19)),
-                                      ("p2", (202, 202, 32))])
+                                      ("p2", (202, 202, 32)), ("c30", (202, 202, 32)), ("perf15", (102, 102, 19))])
 def test_one_step_vs_oracle(cfg, dims):
     from uvic29_amd.tracer import TracerModel
-    oc = synthetic.make_ocean(cfg, *dims)
+    oc = synthetic.make_ocean(performance_set(int(cfg[4:])) if cfg.startswith("perf") else cfg, *dims)
     to, so, c = synthetic.load_eos(dims[2])
     src = _rand_src(oc) if oc.cfg.nsrc else None
     orc = oracle_c.Oracle(oc, to=to, so=so, c=c, src=src)

@@ -15,12 +15,16 @@ NSTEP = 5
 
 
 def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
-    from uvic29_amd import OPTION_SETS, synthetic
+    from uvic29_amd import OPTION_SETS, performance_set, synthetic
     from uvic29_amd.parallel import SlabShard, TracerShard
     from uvic29_amd.tracer import TimeLoop, TracerModel
-    cfg = OPTION_SETS[cfg_name]
+    cfg = OPTION_SETS[cfg_name] if cfg_name in OPTION_SETS else performance_set(int(cfg_name.replace("perf", "")))
     ocean = synthetic.make_ocean(cfg, imt, jmt, km)
     to, so, c = synthetic.load_eos(km)
+    src = None
+    if cfg.nsrc and not cfg.ntnpzd:      # passive performance shape (BASELINE configs 2-3): a given source term
+        rng = np.random.default_rng(2029)
+        src = np.asfortranarray(rng.standard_normal((imt, km, jmt, cfg.nsrc)) * 1e-10 * ocean.topo.tmask[..., None])
     if decomp == "slab":
         shard = SlabShard(jmt, world, rank)
         shard.nt_model = cfg.nt
@@ -29,7 +33,7 @@ def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
     if shard.nt_model != cfg.nt:
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, cfg.nsrc, cfg.ntnpzd, device=0)
-    m.load_ocean(ocean, to, so, c)
+    m.load_ocean(ocean, to, so, c, src=src)
     if cfg.ntnpzd:
         m.set_mobi(ocean)
     m.set_filter(ocean, synthetic.make_filter(ocean.grid, km))      # polar filter on: it must commute with both decompositions
@@ -43,17 +47,17 @@ def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
     return out
 
 
-def _worker(rank, world, port, out_path, decomp="tracer", grid=(14, 14, 6)):
+def _worker(rank, world, port, out_path, decomp="tracer", grid=(14, 14, 6), cfg="c30"):
     import torch.distributed as dist
     for p in (ROOT,):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    got = _run("c30", *grid, world, rank, decomp)
+    got = _run(cfg, *grid, world, rank, decomp)
     np.save(f"{out_path}.{rank}.npy", got)
     if rank == 0:
-        np.save(f"{out_path}.single.npy", _run("c30", *grid, 1, 0))
+        np.save(f"{out_path}.single.npy", _run(cfg, *grid, 1, 0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,6 +98,100 @@ def test_four_latitude_slabs_full_grid(tmp_path):
         js, je = slab_rows(102, 4, r)
         got = np.load(f"{out}.{r}.npy")
         assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_config3_tracer_shards_nt15_full_grid(tmp_path, world):
+    """BASELINE config 3: nt = 15 on 100x100x19, tracer-index shards over 2 and 4 ranks (the tracer dimension is padded
+    to a multiple of the world size), all-gather of t(tau+1) per step, replicated convection and polar filter: every
+    rank ends with the single-rank result bit for bit."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / f"ts{world}")
+    mp.spawn(_worker, args=(world, 29581 + world, out, "tracer", (102, 102, 19), "perf15"), nprocs=world, join=True)
+    ref = np.load(f"{out}.single.npy")
+    assert np.isfinite(ref).all() and ref.shape[3] == 15
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, 1:-1], ref[:, :, 1:-1]), f"rank {r}"
+
+
+def test_config5_four_slabs_refined_grid_nt30(tmp_path):
+    """BASELINE config 5 as worded: the refined 200x200x32 grid with nt = 30 and MOBI, latitude slabs (four here, ranks on
+    one GPU) with the 2-row halo exchange: owned rows equal the single-rank run bit for bit over five steps."""
+    import torch.multiprocessing as mp
+    from uvic29_amd.parallel import slab_rows
+    out = str(tmp_path / "slab4r")
+    mp.spawn(_worker, args=(4, 29591, out, "slab", (202, 202, 32)), nprocs=4, join=True)
+    ref = np.load(f"{out}.single.npy")
+    assert np.isfinite(ref).all()
+    for r in range(4):
+        js, je = slab_rows(202, 4, r)
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
+
+
+def _rccl_loop_worker(rank, port, out_path, backend):
+    """TimeLoop over a slab whose two neighbours are the rank itself: the asynchronous RCCL send/recv of the halo rows,
+    ordered against packing, unpacking and the four-stream look-ahead schedule by the stream alone (backend "nccl"), or
+    the host-staged rehearsal path (backend "gloo") that synchronises every step.  Same bits expected."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    from uvic29_amd import OPTION_SETS, synthetic
+    from uvic29_amd.parallel import SlabShard
+    from uvic29_amd.tracer import TimeLoop, TracerModel
+    cfg = OPTION_SETS["c30"]
+    ocean = synthetic.make_ocean(cfg, 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    m = TracerModel(14, 14, 6, cfg.nt, cfg.nsrc, cfg.ntnpzd, device=0)        # the model before the communicator (DESIGN.md 5)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    m.load_ocean(ocean, to, so, c)
+    m.set_mobi(ocean)
+    sl = SlabShard(14, 1, 0)
+    sl.js, sl.je = 5, 8
+    sl.nt_model = cfg.nt
+    sl.apply(m)
+    sl.world = 2                      # so that after_step exchanges; the peers are overridden below
+    if backend == "nccl":
+        orig = sl.exchange
+        sl.exchange = lambda model, name="t_taup1", peers=None: orig(model, name, peers=(0, 0))
+    else:
+        # the comparison run: the same self-exchange staged through the host with a full synchronisation around it
+        # (gloo cannot send to the sending rank itself)
+        from uvic29_amd.capi import check
+
+        def host_exchange(model, name="t_taup1", peers=None):
+            send_s, send_n, recv_s, recv_n = sl._staging(model)
+            check(model.lib.uvic_gpu_halo_pack(model.h, 1, 1), "halo_pack")
+            model.sync(); torch.cuda.synchronize()
+            hs, hn = send_s.cpu(), send_n.cpu()
+            recv_s.copy_(hs); recv_n.copy_(hn)
+            torch.cuda.synchronize()
+            check(model.lib.uvic_gpu_halo_unpack(model.h, 1, 1), "halo_unpack")
+        sl.exchange = host_exchange
+    loop = TimeLoop(m, ocean.params.dtts, nmix=3, shard=sl)
+    for _ in range(6):                # includes two forward (mixing) steps
+        loop.step()
+    m.sync()
+    np.save(out_path, m.download("t_tau"))
+    m.close()
+    if backend == "nccl":
+        dist.destroy_process_group()
+
+
+def test_rccl_halo_exchange_inside_the_time_loop(tmp_path):
+    import torch.multiprocessing as mp
+    outs = {}
+    for backend, port in (("nccl", 29555), ("host", 29557)):
+        out = str(tmp_path / f"loop_{backend}.npy")
+        mp.spawn(_rccl_loop_worker, args=(port, out, backend), nprocs=1, join=True)
+        outs[backend] = np.load(out)
+    assert np.isfinite(outs["nccl"]).all()
+    assert np.array_equal(outs["nccl"][:, :, 4:8], outs["host"][:, :, 4:8])      # the slab's own rows 5..8
 
 
 def _rccl_worker(rank, port, out_path):
