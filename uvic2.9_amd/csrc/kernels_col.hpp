@@ -327,7 +327,10 @@ __device__ __forceinline__ bool col_decode_rows(const uvic_ctx &c, const ColGrid
 //   PART_ADV (second): low-order fluxes, t_lo, limiter ratios, limited x and z fluxes -> R+-Y and S -= ADV_Tx + ADV_Tz
 //   PART_ALL: both in one sweep
 enum { PART_ALL = 0, PART_ADV = 1, PART_DIF = 2 };
-template <int NTR, int PART>
+// AHEAD: what a level reads is fetched one level ahead into the other of two register sets (+72 VGPRs).  For the bulk launch
+// this ties with none (three waves on a SIMD cover each other's memory waits); for the T,S launch -- a few hundred waves
+// others wait for, among thousands of waves that keep the memory system busy -- every level's wait is otherwise exposed.
+template <int NTR, int PART, bool AHEAD = false>
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
                                             int code, const int (&n1)[NTR], const bool (&live)[NTR]) {
   constexpr bool ADV = PART != PART_DIF, DIF = PART != PART_ADV;
@@ -398,26 +401,40 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     dx_next[q] = me_next[q] - mc1[q]; dxw_next[q] = shfl_w(dx_next[q]);
     fbfin_up[q] = vb0 * (tc1[q] + tc1[q]);
   }
-  for (int s = 1; s <= km; ++s) {
-    const bool last = (s == km);
-    const int sp = last ? km : s + 1;
-    // ---- what the tracers share: velocities, folded coefficients, masks, metrics ------------------------
-    double ve = 0.0, vn = 0.0, vs = 0.0, vb = 0.0;
-    if (ADV) {
-      ve = LD(te, s, 0); vn = LD(tn, s, 0); vs = LD(tn, s, -1);
-      vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
-    }
+  // everything level s reads from memory
+  struct LvlIn {
+    double ve, vn, vs, vb;
     double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
+    double mc2[NTR], ms2[NTR], mn2[NTR], tc2[NTR], t_s[NTR], t_n[NTR];
+  };
+  auto load_in = [&](LvlIn &L, int s) {
+    const int sp = (s == km) ? km : s + 1;
+    L.ve = L.vn = L.vs = L.vb = 0.0;
+    if (ADV) {
+      L.ve = LD(te, s, 0); L.vn = LD(tn, s, 0); L.vs = LD(tn, s, -1);
+      L.vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
+    }
     if (DIF) {
       _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
         const double2 v = CFP(p, s, 0);
-        cfc[2 * p] = v.x; cfc[2 * p + 1] = v.y;
+        L.cfc[2 * p] = v.x; L.cfc[2 * p + 1] = v.y;
       }
       _Pragma("unroll") for (int p = 0; p < 3; ++p) {
         const double2 v = CFP(p, s, -1);
-        cfs[2 * p] = v.x; cfs[2 * p + 1] = v.y;
+        L.cfs[2 * p] = v.x; L.cfs[2 * p + 1] = v.y;
       }
     }
+    FORQ {
+      L.mc2[q] = LDQ(b_tm, sp, 0); L.ms2[q] = LDQ(b_tm, sp, -1); L.mn2[q] = LDQ(b_tm, sp, 1);
+      L.tc2[q] = L.t_s[q] = L.t_n[q] = 0.0;
+      if (ADV) { L.tc2[q] = LDQ(b_tt, sp, 0); L.t_s[q] = LDQ(b_tt, s, -1); L.t_n[q] = LDQ(b_tt, s, 1); }
+    }
+  };
+  auto level = [&](const LvlIn &L, int s) {
+    const bool last = (s == km);
+    // ---- what the tracers share: velocities, folded coefficients, masks, metrics ------------------------
+    const double ve = L.ve, vn = L.vn, vs = L.vs, vb = L.vb;
+    const double *cfc = L.cfc, *cfs = L.cfs;
     const double dzt2r_s = t_dzt2r.at(s - 1), ddztr = t_dztr.at(s - 1);
     const double dzt2r_up = (s >= 2) ? t_dzt2r.at(s - 2) : 0.0;
     const double twodt = c2dtts * t_dtxcel.at(s - 1);
@@ -427,14 +444,13 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
     const double avb = dabs(vb);
     FORQ {
-      const double mc2 = LDQ(b_tm, sp, 0), ms2 = LDQ(b_tm, sp, -1), mn2 = LDQ(b_tm, sp, 1);
+      const double mc2 = L.mc2[q], ms2 = L.ms2[q], mn2 = L.mn2[q];
       const double m_c = mc1[q];
       const double mc2_e = shfl_e(mc2);
       double spart = 0.0;     // what this sweep adds to S of level s, but for the z advection (finalised one level later)
       // =================== advective part (adv_flx) =====================================================
       if (ADV) {
-        const double tc2 = LDQ(b_tt, sp, 0);
-        const double t_s = LDQ(b_tt, s, -1), t_n = LDQ(b_tt, s, 1);
+        const double tc2 = L.tc2[q], t_s = L.t_s[q], t_n = L.t_n[q];
         // the diffusive sweep has stored its share of S already: fetched here, used when level s-1 is finalised
         double sdif_prev = 0.0;
         if (PART == PART_ADV) sdif_prev = bld(b_S[q], lb, OC(s >= 2 ? s - 1 : 1, 0));
@@ -535,6 +551,26 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       mc1[q] = mc2; ms1[q] = ms2; mn1[q] = mn2;
     }
     mk_prev = mk;
+  };
+  if (AHEAD) {
+    // no branch around a load (the compiler's wait counts stay exact on straight-line code only): the level index is
+    // clamped instead (the last pair re-reads level km) and an odd last level is peeled
+    LvlIn A, B;
+    load_in(A, 1);
+    int s = 1;
+    for (; s + 1 <= km; s += 2) {
+      load_in(B, s + 1);
+      level(A, s);
+      load_in(A, imin(s + 2, km));
+      level(B, s + 1);
+    }
+    if (s == km) level(A, km);
+  } else {
+    for (int s = 1; s <= km; ++s) {
+      LvlIn L;
+      load_in(L, s);
+      level(L, s);
+    }
   }
 #undef FORQ
 #undef LDQ
@@ -549,6 +585,11 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 // `ework` is the wave's LDS scratch: e(k) and z(k) of the Thomas recurrence, each (km+1) x 64 doubles laid out
 // [k][lane], so that the forward sweep writes t(tau+1) nowhere and the back substitution stores it once
 // ===========================================================================
+//
+// ZG: the forward sweep parks z(k) in t(tau+1) itself (global memory, read back by the same lane) instead of LDS, so that a
+// wave needs 10 KB of LDS for e(k) instead of 20: sixteen waves fit on a CU instead of eight, and seven instead of three
+// beside a MOBI team (90 KB).  Not with the fused convective replay, which works on the column in LDS.
+template <bool ZG>
 __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int code, int n1,
                                             int fuse_convect) {
   UV_DIMS(c);
@@ -639,7 +680,8 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
       bet = div_pos(mk, b - a * e + eps);
       znew = (f - a * zprev) * bet;
     }
-    zwork[(size_t)k * 64 + lane] = znew;
+    if (ZG) bst(b_tp, lb, OC(k, 0), znew);
+    else zwork[(size_t)k * 64 + lane] = znew;
     zprev = znew;
     cprev = cc;
     dcb_up = L.dcb;
@@ -668,8 +710,8 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   // wave has a mixed segment, the back substitution leaves t(tau+1) in LDS, the segments are replayed in the
   // order they were found (convect.F:257-271: tsm = sum t*dztxcl over kt..kb, in that order, / zsm) and the column
   // is stored once.  Same arithmetic as convect_apply_cell, which this replaces.
-  const int ncv = fuse_convect ? c.cv_nseg[X2(i, r)] : 0;
-  if (__builtin_amdgcn_ballot_w64(ncv > 0) != 0) {
+  const int ncv = (fuse_convect && !ZG) ? c.cv_nseg[X2(i, r)] : 0;
+  if (!ZG && __builtin_amdgcn_ballot_w64(ncv > 0) != 0) {
     double zn = zprev;
     for (int k = km - 1; k >= 1; --k) {
       const double zk = zwork[(size_t)k * 64 + lane] - ework[(size_t)(k + 1) * 64 + lane] * zn;
@@ -694,8 +736,24 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   }
   // back substitution, invtri.F:104-110, and the cyclic images (tracer.F:1153-1155)
   double znext = zprev;
-  bst(b_tp, lb, OC(km, 0), znext);
+  if (!ZG) bst(b_tp, lb, OC(km, 0), znext);
   if (ic) tp[X3(ic, km, r)] = znext;
+  if (ZG) {
+    // z(k) comes back from t(tau+1), six levels at a time ahead of the recurrence that consumes them
+    for (int k0 = km - 1; k0 >= 1; k0 -= 6) {
+      double zq[6];
+      _Pragma("unroll") for (int u = 0; u < 6; ++u) zq[u] = bld(b_tp, lb, OC(imax(k0 - u, 1), 0));
+      _Pragma("unroll") for (int u = 0; u < 6; ++u) {
+        const int k = k0 - u;
+        if (k >= 1) {
+          const double zk = zq[u] - ework[(size_t)(k + 1) * 64 + lane] * znext;
+          bst(b_tp, lb, OC(k, 0), zk);
+          if (ic) tp[X3(ic, k, r)] = zk;
+          znext = zk;
+        }
+      }
+    }
+  } else
   for (int k = km - 1; k >= 1; --k) {
     const double zk = zwork[(size_t)k * 64 + lane] - ework[(size_t)(k + 1) * 64 + lane] * znext;
     bst(b_tp, lb, OC(k, 0), zk);

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_tot_vel(const uvic_ctx c) {
   }
   if (gid < NF) c.tot_b[gid] = c.adv_vbt[gid] + c.adv_vbtiso[gid];
 }
-template <int NTR, int PART>
+template <int NTR, int PART, bool AHEAD = false>
 __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
@@ -155,7 +155,7 @@ __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf,
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: the tracers and the wave of the lane map live in scalar registers
   if (blk >= nblk || !col_decode<NTR>(c, g, blk * 4 + wv, code, n1, live)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colfct_wave<NTR, PART>(c, cf, S, code, n1, live);
+  colfct_wave<NTR, PART, AHEAD>(c, cf, S, code, n1, live);
 }
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
 // the pass as two sweeps, four waves per SIMD each: diffusive fluxes first (S), then the FCT advection (R+-Y, S)
@@ -165,6 +165,10 @@ __global__ void __launch_bounds__(256) k_colfct_adv(const uvic_ctx c, const doub
 __global__ void __launch_bounds__(256) k_colfct2(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<2, PART_ALL>(c, cf, S, g); }
 // the same pass for T and S alone on the side stream: own name, so that a profile tells the two launches apart
 __global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
+#ifdef UV_TS_AHEAD   // measured: the same 100 us in the loop with a level-ahead register set (256 VGPRs): not the memory wait of a level
+__global__ void __launch_bounds__(256) k_colfct_ts_ahead(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL, true>(c, cf, S, g); }
+#endif
+template <bool ZG>
 __device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, const ColGrid &g, double *lds) {
   const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
   const int blk = xcd_remap(blockIdx.x, nblk);
@@ -172,15 +176,20 @@ __device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, code, n1)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colupd_wave(c, S, lds + (size_t)wv * 2 * (c.km + 1) * 64, code, n1, g.fuse_convect);
+  colupd_wave<ZG>(c, S, lds + (size_t)wv * (ZG ? 1 : 2) * (c.km + 1) * 64, code, n1, g.fuse_convect);
 }
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  colupd_body(c, S, g, lds);
+  colupd_body<false>(c, S, g, lds);
+}
+// the same with z(k) parked in t(tau+1) (half the LDS per wave); no fused convective replay
+__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_zg(const uvic_ctx c, const double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colupd_body<true>(c, S, g, lds);
 }
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_ts(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  colupd_body(c, S, g, lds);
+  colupd_body<false>(c, S, g, lds);
 }
 // ---- the T,S chain of step n and the isopyc chain of step n+1 share three launches -------------------------------
 // Both are chains of three short kernels on the same side stream (pass A, pass B, convective walk of T,S; elements,
@@ -206,7 +215,7 @@ __global__ void __launch_bounds__(256) k_ts_iso2(const uvic_ctx c, const double 
                                                  double *cfi, int ncell) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if ((int)blockIdx.x < nts) {
-    if (threadIdx.y == 0) colupd_body(c, S, g, lds);
+    if (threadIdx.y == 0) colupd_body<false>(c, S, g, lds);
     return;
   }
   if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
@@ -493,6 +502,9 @@ struct uvic_gpu {
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
   double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
+  bool mixing_next_guard = false;
+  bool ts_in_bulk;  // T and S go through pass A with the other tracers; their pass B and the walk on the side stream (UVIC_TS_IN_BULK)
+  bool b_zglobal;   // pass B parks z(k) in t(tau+1) instead of LDS (UVIC_B_ZGLOBAL, default 1)
   int a_mode;       // pass A of the bulk launch: 1 = one sweep, 2 = one sweep with two tracers per lane, 3 = two sweeps (UVIC_A_MODE)
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
   int *wet_dev;
@@ -754,6 +766,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   iso_set_adopt(h);   // what was just allocated is set 0
   h->exact = false;
   if (const char *e = getenv("UVIC_EXACT")) h->exact = atoi(e) != 0;
+  h->b_zglobal = false;   // measured: 91 us alone against 80 with both arrays in LDS (the pass is bound by memory traffic, not by occupancy)
+  if (const char *e = getenv("UVIC_B_ZGLOBAL")) h->b_zglobal = atoi(e) != 0;
+  h->ts_in_bulk = false;
+  if (const char *e = getenv("UVIC_TS_IN_BULK")) h->ts_in_bulk = atoi(e) != 0;
   h->a_mode = 1;   // measured (102x102x19, nt = 30, alone): one sweep 131 us, two tracers per lane 116, two sweeps 63 + 79; in the loop all three tie
   if (const char *e = getenv("UVIC_A_MODE")) h->a_mode = atoi(e);
   if (h->a_mode < 1 || h->a_mode > 3) h->a_mode = 1;
@@ -1337,7 +1353,51 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     // sharding, where convection follows the exchange.
     const bool split = convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
                        h->ts_no_src;
-    if (split) {
+    if (split && h->ts_in_bulk) {
+      // T and S ride through pass A with the other tracers (no latency-bound pass A of their own); their pass B and the
+      // convective walk follow on the side stream -- behind the isopyc chain of the next step, which was queued there
+      // first and does not depend on this step -- while the main stream runs pass B of the others; convect_apply joins them
+      if (int rc = land_clean(h, c, h->stream)) return rc;
+      mark(h, "begin");
+      launch_a(c, a, S, h->stream);
+      mark(h, "colfct");
+      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
+      HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
+      uvic_ctx cts = c;
+      cts.nt_local = 2;
+      cts.prio |= 2;
+      ColGrid bts = b;
+      bts.total = bts.nwaves * 2;
+      const WetCols w = wet_range(h, c.js, c.je);
+      mark_on(h, "begin", 3);
+      if (bts.total > 0) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
+      mark_on(h, "colupd_ts", 3);
+      HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+      if (w.count > 0)
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side_ts, cts, w, h->cv_list);
+      mark_on(h, "convect_ts", 3);
+      HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
+      if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
+        HIPCHK(hipMemcpyAsync(h->ts_host, c.t_taup1, (size_t)2 * c.imt * c.km * c.jmt * 8, hipMemcpyDeviceToHost, h->side_ts));
+        HIPCHK(hipEventRecord(h->ev_ts_host, h->side_ts));
+        h->ts_host_queued = true;
+      }
+      h->ts_ahead = true;
+      h->ts_apply = true;
+      if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
+      const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+      uvic_ctx cr = c;
+      cr.n0 = 2; cr.nt_local = c.nt - 2;
+      cr.Rpm = c.Rpm + 2 * N3 * 2;
+      ColGrid br = b;
+      br.total = br.nwaves * cr.nt_local;
+      br.fuse_convect = 0;
+      if (h->src_from_prefetch) {
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+        h->src_from_prefetch = false;
+      }
+      if (br.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+    } else if (split) {
       // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
       // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
       if (h->iso_waited && h->step_begun) {
@@ -1419,7 +1479,12 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       // decoupled: the mixed segments are replayed by convect_apply after this pass (launch_convect), so that the main
       // stream does not stand still between its two passes while the T,S chain (three short kernels) finishes
       if (!dbg_nowait && !h->conv_decoupled) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
-      if (br.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+      if (br.total > 0) {
+        if (h->b_zglobal && !br.fuse_convect)
+          hipLaunchKernelGGL(k_colupd_zg, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds / 2, h->stream, cr, (const double *)(S + 2 * N3), br);
+        else
+          hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+      }
     } else {
       if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
@@ -1429,7 +1494,12 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
-      if (b.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
+      if (b.total > 0) {
+        if (h->b_zglobal)
+          hipLaunchKernelGGL(k_colupd_zg, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds / 2, h->stream, c, (const double *)S, b);
+        else
+          hipLaunchKernelGGL(k_colupd, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
+      }
     }
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
@@ -1726,6 +1796,8 @@ extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing
       h->iso_fuse_armed = true;
     }
   }
+  if (h->ts_in_bulk && (iso_ahead & 1) && !h->mixing_next_guard)
+    if (int rc = prefetch_isopyc_ahead(h, 1)) return rc;   // ahead of this step's T,S work on the same stream (launch_transport)
   if (int rc = uvic_gpu_step_async(h)) return rc;
   h->iso_fuse_armed = false;   // not taken (no T,S launches of their own in this configuration): the chain below does it
   if (mobi_ahead && h->have_mobi)
