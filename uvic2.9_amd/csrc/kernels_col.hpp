@@ -194,7 +194,9 @@ struct ColGrid {
 #define COL_LANE_I(code) ((code) & 0xfff)
 #define COL_LANE_R(code) (((code) >> 12) & 0xfff)
 #define COL_LANE_OWNED(code) (((code) >> 24) & 1)
-#define COLUPD_WAVES 1  // waves per workgroup of pass B: 2 x (km+1) x 512 B of LDS each (20 KB at km = 19), so that workgroups still fit beside a MOBI team (90 KB) on a CU
+#ifndef COLUPD_WAVES
+#define COLUPD_WAVES 1
+#endif //  // waves per workgroup of pass B: 2 x (km+1) x 512 B of LDS each (20 KB at km = 19), so that workgroups still fit beside a MOBI team (90 KB) on a CU
 
 // Neighbour exchange by DPP whole-wave shifts (gfx9 `wave_shr:1` / `wave_shl:1`): one
 // v_mov_b32_dpp per dword at VALU latency instead of an LDS round trip (ds_bpermute) --
@@ -244,6 +246,13 @@ typedef __amdgpu_buffer_rsrc_t brsrc;
 __device__ __forceinline__ brsrc mkbuf(const void *p, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
 }
+#ifdef UV_ABL_NOLOAD   // ablation (timing only, results meaningless): no vector memory loads, operands made up from the offsets
+__device__ __forceinline__ double bld(brsrc, unsigned voff, int soff) { return (double)(int)(voff + (unsigned)soff) * 1e-9 + 1.0; }
+__device__ __forceinline__ double2 bld2(brsrc, unsigned voff, int soff) {
+  const double v = (double)(int)(voff + (unsigned)soff) * 1e-9;
+  return make_double2(v, v + 1e-3);
+}
+#else
 __device__ __forceinline__ double bld(brsrc r, unsigned voff, int soff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
@@ -251,6 +260,7 @@ __device__ __forceinline__ double2 bld2(brsrc r, unsigned voff, int soff) {
   const dv2 v = __builtin_bit_cast(dv2, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
   return make_double2(v.x, v.y);
 }
+#endif
 __device__ __forceinline__ void bst(brsrc r, unsigned voff, int soff, double v) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uv2, v), r, voff, soff, 0);
 }
@@ -330,9 +340,15 @@ enum { PART_ALL = 0, PART_ADV = 1, PART_DIF = 2 };
 // AHEAD: what a level reads is fetched one level ahead into the other of two register sets (+72 VGPRs).  For the bulk launch
 // this ties with none (three waves on a SIMD cover each other's memory waits); for the T,S launch -- a few hundred waves
 // others wait for, among thousands of waves that keep the memory system busy -- every level's wait is otherwise exposed.
-template <int NTR, int PART, bool AHEAD = false>
+// SHARE: the four waves of a workgroup work on four tracers of the SAME lanes, and the 13 coefficient pairs of a level (two
+// thirds of what a wave fetches through the vector memory pipe, which is what bounds the pass: 1.5 GB per step at 64 B per
+// clock and CU) are the same for all four.  Each wave brings a quarter of the next level's pairs into LDS (buffer_load ...
+// lds: no registers), one workgroup barrier per level, and every wave reads all 13 from LDS (256 B per clock).
+// `lds` = 2 x 13 x 64 double2 per workgroup, `wv` = the wave's number in it.
+#define COL_SHARE_SLOTS (CF_PAIRS + 3)
+template <int NTR, int PART, bool AHEAD = false, bool SHARE = false>
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
-                                            int code, const int (&n1)[NTR], const bool (&live)[NTR]) {
+                                            int code, const int (&n1)[NTR], const bool (&live)[NTR], double *lds = nullptr, int wv = 0) {
   constexpr bool ADV = PART != PART_DIF, DIF = PART != PART_ADV;
   UV_DIMS(c);
   const int i = COL_LANE_I(code), r = COL_LANE_R(code);
@@ -414,7 +430,17 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       L.ve = LD(te, s, 0); L.vn = LD(tn, s, 0); L.vs = LD(tn, s, -1);
       L.vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
     }
-    if (DIF) {
+    if (DIF && SHARE) {
+      const double2 *sl = (const double2 *)lds + (size_t)(s & 1) * COL_SHARE_SLOTS * 64 + (threadIdx.x & 63);
+      _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
+        const double2 v = sl[p * 64];
+        L.cfc[2 * p] = v.x; L.cfc[2 * p + 1] = v.y;
+      }
+      _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+        const double2 v = sl[(CF_PAIRS + p) * 64];
+        L.cfs[2 * p] = v.x; L.cfs[2 * p + 1] = v.y;
+      }
+    } else if (DIF) {
       _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
         const double2 v = CFP(p, s, 0);
         L.cfc[2 * p] = v.x; L.cfc[2 * p + 1] = v.y;
@@ -565,6 +591,30 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       level(B, s + 1);
     }
     if (s == km) level(A, km);
+  } else if (SHARE) {
+    // this wave's share of the coefficient pairs of level s: slots wv, wv+4, ... of the 13 (row r: 0..9, row r-1: 10..12)
+    auto bring = [&](int s) {
+      typedef __attribute__((address_space(3))) void *ldsp;
+      _Pragma("unroll") for (int q = 0; q < (COL_SHARE_SLOTS + 3) / 4; ++q) {
+        const int p = wv + 4 * q;
+        if (p < COL_SHARE_SLOTS) {
+          double2 *dst = (double2 *)lds + ((size_t)(s & 1) * COL_SHARE_SLOTS + p) * 64;
+          const int pair = p < CF_PAIRS ? p : p - CF_PAIRS, dj = p < CF_PAIRS ? 0 : -1;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(b_cf, (ldsp)dst, 16, lb2, ((int)(pair) * (int)N3 + (s - 1) * imt + (dj + 1) * rowstride) * 16, 0, 0);
+        }
+      }
+    };
+    bring(1);
+    for (int s = 1; s <= km; ++s) {
+      // the level's pairs have landed (this wave's share: vmcnt; the others': the barrier), and every wave has finished
+      // reading the other buffer (it did so in level s-1, before it came here)
+      __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0), lgkmcnt and expcnt left alone */
+      __builtin_amdgcn_s_barrier();
+      if (s < km) bring(s + 1);
+      LvlIn L;
+      load_in(L, s);
+      level(L, s);
+    }
   } else {
     for (int s = 1; s <= km; ++s) {
       LvlIn L;
