@@ -431,15 +431,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       L.vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
     }
     if (DIF && SHARE) {
-      const double2 *sl = (const double2 *)lds + (size_t)(s & 1) * COL_SHARE_SLOTS * 64 + (threadIdx.x & 63);
-      _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
-        const double2 v = sl[p * 64];
-        L.cfc[2 * p] = v.x; L.cfc[2 * p + 1] = v.y;
-      }
-      _Pragma("unroll") for (int p = 0; p < 3; ++p) {
-        const double2 v = sl[(CF_PAIRS + p) * 64];
-        L.cfs[2 * p] = v.x; L.cfs[2 * p + 1] = v.y;
-      }
+      // (read from LDS where they are used, in the diffusive half of level(): they need not occupy registers before)
     } else if (DIF) {
       _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
         const double2 v = CFP(p, s, 0);
@@ -460,7 +452,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const bool last = (s == km);
     // ---- what the tracers share: velocities, folded coefficients, masks, metrics ------------------------
     const double ve = L.ve, vn = L.vn, vs = L.vs, vb = L.vb;
-    const double *cfc = L.cfc, *cfs = L.cfs;
+    double cfc_l[2 * CF_PAIRS], cfs_l[6];
+    const double *cfc = SHARE ? cfc_l : L.cfc, *cfs = SHARE ? cfs_l : L.cfs;
     const double dzt2r_s = t_dzt2r.at(s - 1), ddztr = t_dztr.at(s - 1);
     const double dzt2r_up = (s >= 2) ? t_dzt2r.at(s - 2) : 0.0;
     const double twodt = c2dtts * t_dtxcel.at(s - 1);
@@ -537,6 +530,17 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       }
       // =================== diffusive part (coefficients folded by ai_coef_cell) ===========================
       if (DIF) {
+        if (SHARE && q == 0) {
+          const double2 *sl = (const double2 *)lds + (size_t)(s & 1) * COL_SHARE_SLOTS * 64 + (threadIdx.x & 63);
+          _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
+            const double2 v = sl[p * 64];
+            cfc_l[2 * p] = v.x; cfc_l[2 * p + 1] = v.y;
+          }
+          _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+            const double2 v = sl[(CF_PAIRS + p) * 64];
+            cfs_l[2 * p] = v.x; cfs_l[2 * p + 1] = v.y;
+          }
+        }
         const double dz_up = dz_c[q], dz_dn = (!last) ? m_c - mc2 : 0.0;          // own column (dz_up = dz_dn of the level above, 0 at the top)
         const double dze_up = dz_e[q], dze_dn = shfl_e(dz_dn);                      // east column
         const double dzs_up = dz_s[q], dzs_dn = (!last) ? ms1[q] - ms2 : 0.0;      // south row
@@ -578,7 +582,41 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     }
     mk_prev = mk;
   };
-  if (AHEAD) {
+  if (AHEAD && SHARE) {
+    // both: the pairs through LDS one level ahead, and what the wave loads for itself one level ahead into a second register set
+    auto bring = [&](int s) {
+      typedef __attribute__((address_space(3))) void *ldsp;
+      _Pragma("unroll") for (int q = 0; q < (COL_SHARE_SLOTS + 3) / 4; ++q) {
+        const int p = wv + 4 * q;
+        if (p < COL_SHARE_SLOTS) {
+          double2 *dst = (double2 *)lds + ((size_t)(s & 1) * COL_SHARE_SLOTS + p) * 64;
+          const int pair = p < CF_PAIRS ? p : p - CF_PAIRS, dj = p < CF_PAIRS ? 0 : -1;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(b_cf, (ldsp)dst, 16, lb2, ((int)(pair) * (int)N3 + (s - 1) * imt + (dj + 1) * rowstride) * 16, 0, 0);
+        }
+      }
+    };
+    LvlIn A, B;
+    bring(1);
+    load_in(A, 1);
+    int s = 1;
+    for (; s + 1 <= km; s += 2) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __builtin_amdgcn_s_barrier();
+      bring(s + 1);
+      load_in(B, s + 1);
+      level(A, s);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __builtin_amdgcn_s_barrier();
+      bring(imin(s + 2, km));          // (an odd km: the pairs of the peeled last level; an even one: level km once more, unused)
+      load_in(A, imin(s + 2, km));
+      level(B, s + 1);
+    }
+    if (s == km) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __builtin_amdgcn_s_barrier();
+      level(A, km);
+    }
+  } else if (AHEAD) {
     // no branch around a load (the compiler's wait counts stay exact on straight-line code only): the level index is
     // clamped instead (the last pair re-reads level km) and an odd last level is peeled
     LvlIn A, B;

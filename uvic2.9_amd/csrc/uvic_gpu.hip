@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(256) k_colfct_adv(const uvic_ctx c, const doub
 // the four waves of a workgroup share the coefficient pairs of a level through LDS: they are four tracers of the same lanes
 // (g.total counts waves = waves of the lane map x the tracer count rounded up to a multiple of four; a wave beyond the
 // launch's tracers stands in for the first one, brings its share of the pairs and stores nothing)
-__global__ void __launch_bounds__(256) k_colfct_sh(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+template <bool AHEAD>
+__device__ __forceinline__ void colfct_sh_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g, double *lds) {
   const int nblk = g.total / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   if (blk >= nblk) return;
@@ -176,7 +176,17 @@ __global__ void __launch_bounds__(256) k_colfct_sh(const uvic_ctx c, const doubl
   bool live[1] = {nl < c.nt_local};
   const int code = g.lanes[(size_t)(blk / ngrp) * 64 + threadIdx.x];
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
-  colfct_wave<1, PART_ALL, false, true>(c, cf, S, code, n1, live, lds, wv);
+  colfct_wave<1, PART_ALL, AHEAD, true>(c, cf, S, code, n1, live, lds, wv);
+}
+__global__ void __launch_bounds__(256) k_colfct_sh(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colfct_sh_body<false>(c, cf, S, g, lds);
+}
+// ... and what a wave loads for itself (t of three rows, velocities) one level ahead into a second register set: 239 VGPRs,
+// two waves on a SIMD, neither of which waits for memory inside a level
+__global__ void __launch_bounds__(256) k_colfct_sha(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colfct_sh_body<true>(c, cf, S, g, lds);
 }
 // two tracers per lane: half the waves, shared coefficient and velocity loads, two dependency chains per wave
 __global__ void __launch_bounds__(256) k_colfct2(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<2, PART_ALL>(c, cf, S, g); }
@@ -789,10 +799,11 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   if (const char *e = getenv("UVIC_TS_IN_BULK")) h->ts_in_bulk = atoi(e) != 0;
   // measured (102x102x19, alone, 30 tracers): 1 = one sweep 131 us, 2 = two tracers per lane 116, 3 = two sweeps 63 + 79 (in the
   // loop these three tie), 4 = one sweep with the coefficient pairs shared through LDS by the four waves of a workgroup:
-  // 100 us for 28 tracers against 117, 151 against 169 in the loop
-  h->a_mode = 4;
+  // 100 us for 28 tracers against 117, 151 against 169 in the loop; 5 = 4 with the wave's own loads one level ahead (239 VGPRs,
+  // two waves on a SIMD): 88 us, 135 in the loop
+  h->a_mode = 5;
   if (const char *e = getenv("UVIC_A_MODE")) h->a_mode = atoi(e);
-  if (h->a_mode < 1 || h->a_mode > 4) h->a_mode = 1;
+  if (h->a_mode < 1 || h->a_mode > 5) h->a_mode = 1;
   // tmask lives in its own buffer (derived data)
   double *tmask;
   HIPCHK(hipMalloc((void **)&tmask, N3 * 8));
@@ -1360,9 +1371,11 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       g.total = g.nwaves * ((cc.nt_local + ntr - 1) / ntr);
       if (g.total <= 0) return;
       const double *cf = (const double *)h->coef;
-      if (h->a_mode == 4) {
+      if (h->a_mode >= 4) {
         g.total = g.nwaves * ((cc.nt_local + 3) / 4) * 4;
-        hipLaunchKernelGGL(k_colfct_sh, dim3(blocks_a(g)), dim3(64, 4), (size_t)2 * COL_SHARE_SLOTS * 64 * 16, st, cc, cf, (double *)Sg, g);
+        const size_t sh_lds = (size_t)2 * COL_SHARE_SLOTS * 64 * 16;
+        if (h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
+        else hipLaunchKernelGGL(k_colfct_sh, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
       } else if (h->a_mode == 2) hipLaunchKernelGGL(k_colfct2, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
       else if (h->a_mode == 3) {
         hipLaunchKernelGGL(k_colfct_dif, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
