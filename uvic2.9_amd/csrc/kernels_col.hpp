@@ -346,10 +346,16 @@ enum { PART_ALL = 0, PART_ADV = 1, PART_DIF = 2 };
 // lds: no registers), one workgroup barrier per level, and every wave reads all 13 from LDS (256 B per clock).
 // `lds` = 2 x 13 x 64 double2 per workgroup, `wv` = the wave's number in it.
 #define COL_SHARE_SLOTS (CF_PAIRS + 3)
-template <int NTR, int PART, bool AHEAD = false, bool SHARE = false>
+// YFIN: the wave also forms t_lo and the y-limiter ratios of the row to its NORTH (from t of rows r+1, r+2 and that row's
+// velocities: five more loads and ~60 more instructions per level) and with them the FINAL, limited advective flux through
+// its north face, which it stores (8 bytes per cell update) instead of the ratio pair R+-Y (16).  Pass B then reads that flux
+// of rows r and r-1 -- not R+-Y of three rows, t(tau-1) and t(tau) of three rows and the velocities to form the fluxes again:
+// 48 bytes per cell update instead of 136, for the pass that is bound by memory traffic.
+template <int NTR, int PART, bool AHEAD = false, bool SHARE = false, bool YFIN = false>
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
                                             int code, const int (&n1)[NTR], const bool (&live)[NTR], double *lds = nullptr, int wv = 0) {
   constexpr bool ADV = PART != PART_DIF, DIF = PART != PART_ADV;
+  static_assert(!YFIN || PART == PART_ALL, "the final y flux is formed by the one-sweep pass");
   UV_DIMS(c);
   const int i = COL_LANE_I(code), r = COL_LANE_R(code);
   const bool owned = COL_LANE_OWNED(code) != 0;
@@ -364,6 +370,10 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const double cstdyt2r = c.cstdyt2r[r - 1], cstdytr = c.cstdytr[r - 1];
   const bool south_wall = (r - 1 == 1);   // no antidiffusive flux through the face to row 1 (adv_flx: jstrt)
   const double c2dtts = c.c2dtts;
+  // YFIN: the row to the north (N = r+1 <= jmt) and the one beyond it (the reference clamps: jp2 = min(j+2, jmt), adv_flx:555)
+  const int rnn = imin(r + 2, jmt);
+  const int kz_nn = YFIN ? c.kmt[X2(i, rnn)] : 0;
+  const double cstdxt2r_N = YFIN ? c.cstr[r] * c.dxtr[i - 1] * 0.5 : 0.0, cstdyt2r_N = YFIN ? c.cstdyt2r[r] : 0.0;
   // addresses = buffer descriptor + wave-uniform byte offset (one scalar register: level and row shift) + the lane's
   // 32-bit offset of its (i, r) column
   const int rowstride = imt * km;
@@ -371,6 +381,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   const unsigned lb = (unsigned)((r - 2) * rowstride + (i - 1)) * 8u;   // level 1 of column i of row r-1, cell fields
   const unsigned lb2 = lb * 2u;
   const unsigned lbf = (unsigned)((r - 1) * imt * (km + 1) + (i - 1)) * 8u;   // face 0 of the lane's column, face fields
+  const unsigned lb_nn = (unsigned)((rnn - 1) * rowstride + (i - 1)) * 8u;     // level 1 of column i of row min(r+2, jmt)
+  const unsigned lbf_N = lbf + (unsigned)(imt * (km + 1)) * 8u;               // face 0 of the column to the north
   const brsrc b_te = mkbuf(c.tot_e, N3 * 8), b_tn = mkbuf(c.tot_n, N3 * 8);
   const brsrc b_tb = mkbuf(c.tot_b, NF * 8), b_vb = mkbuf(c.adv_vbt, NF * 8);
   const brsrc b_cf = mkbuf(cf, N3 * 16 * CF_PAIRS);
@@ -404,6 +416,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   // T(s)-T(s+1) of the own, east, south and north columns; T(i+1)-T(i) and T(i)-T(i-1) at level s+1
   double me_next[NTR], dz_c[NTR], dz_e[NTR], dz_s[NTR], dz_n[NTR], dx_next[NTR], dxw_next[NTR];
   double fbfin_up[NTR];                  // FINAL advective flux through the face above the level being finalised (top: tracer.F:1063)
+  double fbloN_up[NTR];                  // YFIN: low-order flux through the face above level s of the column to the north
   double mk_prev = 0.0;
   FORQ {
     mc1[q] = LDQ(b_tm, 1, 0); ms1[q] = LDQ(b_tm, 1, -1); mn1[q] = LDQ(b_tm, 1, 1);
@@ -416,6 +429,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     dz_c[q] = dz_e[q] = dz_s[q] = dz_n[q] = 0.0;
     dx_next[q] = me_next[q] - mc1[q]; dxw_next[q] = shfl_w(dx_next[q]);
     fbfin_up[q] = vb0 * (tc1[q] + tc1[q]);
+    fbloN_up[q] = YFIN ? bld(b_vb, lbf_N, OF(0)) * 2.0 * mn1[q] : 0.0;
   }
   // everything level s reads from memory
   struct LvlIn {
@@ -462,6 +476,14 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
     const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
     const double avb = dabs(vb);
+    // YFIN: what the row to the north needs beyond what the wave holds anyway, asked for at the head of the level and used in
+    // its second half (the level-ahead register set has no room for them: 250 VGPRs)
+    double veN_[NTR], vnN_[NTR], vbN_[NTR], m_nn_[NTR], t_nn_[NTR];
+    if (YFIN) FORQ {
+      veN_[q] = bld(b_te, lb, OC(s, 1)); vnN_[q] = bld(b_tn, lb, OC(s, 1));
+      vbN_[q] = (s < km) ? bld(b_tb, lbf_N, OF(s)) : 0.0;
+      m_nn_[q] = bld(b_tm[q], lb_nn, OC(s, -1)); t_nn_[q] = bld(b_tt[q], lb_nn, OC(s, -1));   // (lb_nn points at the row itself)
+    }
     FORQ {
       const double mc2 = L.mc2[q], ms2 = L.ms2[q], mn2 = L.mn2[q];
       const double m_c = mc1[q];
@@ -506,7 +528,27 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
           const double fxb = (!last && wet_dn) ? 0.5 * (tt_c + tc2) : tlo;
           fct_ratio(fxa, fxb, tlo, c2dtts * dzt2r_s, afb, afb_up[q], mk, rzp, rzm);
         }
-        if (owned && live[q]) bst2(b_R[q], lb2, OC(s, 0) * 2, ryp, rym);
+        if (YFIN) {
+          // ---- the row to the north: low-order fluxes, t_lo, y-limiter ratios (the same formulas one row up) ----------
+          const double veN = veN_[q], vnN = vnN_[q], vbN = vbN_[q], m_nn = m_nn_[q], t_nn = t_nn_[q];
+          const double m_N = mn1[q];
+          const double mkN = (s <= kz_n) ? 1.0 : 0.0;
+          const double feloN = upstream(veN, m_N, shfl_e(m_N));
+          const double fnloN_n = upstream(vnN, m_N, m_nn);
+          double fbloN = 0.0;
+          if (!last) fbloN = vbN * (mn2 + m_N) + dabs(vbN) * (mn2 - m_N);
+          const double advN = (feloN - shfl_w(feloN)) * cstdxt2r_N + (fnloN_n - fnlo_n) * cstdyt2r_N + (fbloN_up[q] - fbloN) * dzt2r_s;
+          const double tloN = m_N - twodt * advN * mkN;
+          const double afn_nn = vnN * (t_n + t_nn) - fnloN_n;
+          double rypN, rymN;
+          fct_ratio(mk != 0.0 ? 0.5 * (tt_c + t_n) : tloN, (s <= kz_nn) ? 0.5 * (t_n + t_nn) : tloN, tloN, c2dtts * cstdyt2r_N,
+                    vn * (tt_c + t_n) - fnlo_n, afn_nn, mkN, rypN, rymN);
+          // ---- the limited flux through the north face, final (adv_flx:770-783, 994-996) --------------------------------
+          const double afn_n = vn * (tt_c + t_n) - fnlo_n;
+          const double fn_fin = (limited(fmn(rypN, rym), fmn(ryp, rymN), afn_n) + fnlo_n) * mk;
+          if (owned && live[q]) bst(b_R[q], lb, OC(s, 0), fn_fin);
+          fbloN_up[q] = fbloN;
+        } else if (owned && live[q]) bst2(b_R[q], lb2, OC(s, 0) * 2, ryp, rym);
         // ---- limited x flux and its divergence (adv_flx:695-711, 989-992) ---------------
         const double rxp_e = shfl_e(rxp), rxm_e = shfl_e(rxm);
         const double fefin = limited(fmn(rxp_e, rxm), fmn(rxp, rxm_e), afe) + felo;
@@ -677,7 +719,9 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 // ZG: the forward sweep parks z(k) in t(tau+1) itself (global memory, read back by the same lane) instead of LDS, so that a
 // wave needs 10 KB of LDS for e(k) instead of 20: sixteen waves fit on a CU instead of eight, and seven instead of three
 // beside a MOBI team (90 KB).  Not with the fused convective replay, which works on the column in LDS.
-template <bool ZG>
+// YFIN: pass A has left the final advective flux through the north face of every row (see colfct_wave): the pass reads that
+// of rows r and r-1 and none of what it would otherwise need to form them.
+template <bool ZG, bool YFIN = false>
 __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int code, int n1,
                                             int fuse_convect) {
   UV_DIMS(c);
@@ -724,6 +768,14 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
     double m_c, m_s, m_n, t_c, t_s, t_n, vn, vs, rp0, rm0, rps, rms, rpn, rmn, sn, src, dcb;
   };
   auto load_level = [&](Lvl &L, int k) {
+    if (YFIN) {
+      L.m_c = AT(b_tm, k, 0);
+      L.rp0 = bld(b_R, lb, OC(k, 0)); L.rps = bld(b_R, lb, OC(k, -1));   // the final fluxes through the north faces of rows r, r-1
+      L.sn = AT(b_S, k, 0);
+      L.src = AT(b_src, k, 0);
+      L.dcb = AT(b_dcb, k, 0);
+      return;
+    }
     L.m_c = AT(b_tm, k, 0); L.m_s = AT(b_tm, k, -1); L.m_n = AT(b_tm, k, 1);
     L.t_c = AT(b_tt, k, 0); L.t_s = AT(b_tt, k, -1); L.t_n = AT(b_tt, k, 1);
     L.vn = AT(b_tn, k, 0); L.vs = AT(b_tn, k, -1);
@@ -737,14 +789,20 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
   };
   double dcb_up = 0.0;   // diff_cbt of the level above (the reference reads level max(1,k-1); at k=1 its factor is zeroed)
   auto level = [&](const Lvl &L, int k) {
-    const double m_c = L.m_c, t_c = L.t_c;
-    const double mk = (k <= kz) ? 1.0 : 0.0, mk_s = (k <= kz_s) ? 1.0 : 0.0;
-    const double lo_n = upstream(L.vn, m_c, L.m_n), lo_s = upstream(L.vs, L.m_s, m_c);
-    const double f_n = L.vn * (t_c + L.t_n) - lo_n;
-    const double f_s = south_wall ? 0.0 : L.vs * (L.t_s + t_c) - lo_s;
-    const double fn_n = (limited(fmn(L.rpn, L.rm0), fmn(L.rp0, L.rmn), f_n) + lo_n) * mk;
-    const double fn_s = (limited(fmn(L.rp0, L.rms), fmn(L.rps, L.rm0), f_s) + lo_s) * mk_s;
-    const double ADV_Ty = (fn_n - fn_s) * cstdyt2r;
+    const double m_c = L.m_c;
+    const double mk = (k <= kz) ? 1.0 : 0.0;
+    double ADV_Ty;
+    if (YFIN) {
+      ADV_Ty = (L.rp0 - L.rps) * cstdyt2r;
+    } else {
+      const double t_c = L.t_c, mk_s = (k <= kz_s) ? 1.0 : 0.0;
+      const double lo_n = upstream(L.vn, m_c, L.m_n), lo_s = upstream(L.vs, L.m_s, m_c);
+      const double f_n = L.vn * (t_c + L.t_n) - lo_n;
+      const double f_s = south_wall ? 0.0 : L.vs * (L.t_s + t_c) - lo_s;
+      const double fn_n = (limited(fmn(L.rpn, L.rm0), fmn(L.rp0, L.rmn), f_n) + lo_n) * mk;
+      const double fn_s = (limited(fmn(L.rp0, L.rms), fmn(L.rps, L.rm0), f_s) + lo_s) * mk_s;
+      ADV_Ty = (fn_n - fn_s) * cstdyt2r;
+    }
     const double tdt = c.c2dtts * t_dtxcel.at(k - 1);
     const double z = m_c + tdt * (L.sn - ADV_Ty + (has_src ? L.src : 0.0)) * mk;
     // Thomas forward sweep, invtri.F:57-100

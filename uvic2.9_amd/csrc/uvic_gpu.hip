@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_tot_vel(const uvic_ctx c) {
   }
   if (gid < NF) c.tot_b[gid] = c.adv_vbt[gid] + c.adv_vbtiso[gid];
 }
-template <int NTR, int PART, bool AHEAD = false>
+template <int NTR, int PART, bool AHEAD = false, bool YFIN = false>
 __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
   const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
@@ -155,7 +155,7 @@ __device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf,
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: the tracers and the wave of the lane map live in scalar registers
   if (blk >= nblk || !col_decode<NTR>(c, g, blk * 4 + wv, code, n1, live)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colfct_wave<NTR, PART, AHEAD>(c, cf, S, code, n1, live);
+  colfct_wave<NTR, PART, AHEAD, false, YFIN>(c, cf, S, code, n1, live);
 }
 __global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
 // the pass as two sweeps, four waves per SIMD each: diffusive fluxes first (S), then the FCT advection (R+-Y, S)
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_colfct_adv(const uvic_ctx c, const doub
 // the four waves of a workgroup share the coefficient pairs of a level through LDS: they are four tracers of the same lanes
 // (g.total counts waves = waves of the lane map x the tracer count rounded up to a multiple of four; a wave beyond the
 // launch's tracers stands in for the first one, brings its share of the pairs and stores nothing)
-template <bool AHEAD>
+template <bool AHEAD, bool YFIN = false>
 __device__ __forceinline__ void colfct_sh_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g, double *lds) {
   const int nblk = g.total / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void colfct_sh_body(const uvic_ctx &c, const double *
   bool live[1] = {nl < c.nt_local};
   const int code = g.lanes[(size_t)(blk / ngrp) * 64 + threadIdx.x];
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
-  colfct_wave<1, PART_ALL, AHEAD, true>(c, cf, S, code, n1, live, lds, wv);
+  colfct_wave<1, PART_ALL, AHEAD, true, YFIN>(c, cf, S, code, n1, live, lds, wv);
 }
 __global__ void __launch_bounds__(256) k_colfct_sh(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -188,6 +188,16 @@ __global__ void __launch_bounds__(256) k_colfct_sha(const uvic_ctx c, const doub
   extern __shared__ __attribute__((aligned(16))) double lds[];
   colfct_sh_body<true>(c, cf, S, g, lds);
 }
+// the forms that leave the final y flux of the north face to pass B instead of the limiter ratios (kernels_col.hpp: YFIN)
+__global__ void __launch_bounds__(256) k_colfct_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL, false, true>(c, cf, S, g); }
+__global__ void __launch_bounds__(256) k_colfct_sh_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colfct_sh_body<false, true>(c, cf, S, g, lds);
+}
+__global__ void __launch_bounds__(256) k_colfct_sha_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colfct_sh_body<true, true>(c, cf, S, g, lds);
+}
 // two tracers per lane: half the waves, shared coefficient and velocity loads, two dependency chains per wave
 __global__ void __launch_bounds__(256) k_colfct2(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<2, PART_ALL>(c, cf, S, g); }
 // the same pass for T and S alone on the side stream: own name, so that a profile tells the two launches apart
@@ -195,7 +205,7 @@ __global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const doubl
 #ifdef UV_TS_AHEAD   // measured: the same 100 us in the loop with a level-ahead register set (256 VGPRs): not the memory wait of a level
 __global__ void __launch_bounds__(256) k_colfct_ts_ahead(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL, true>(c, cf, S, g); }
 #endif
-template <bool ZG>
+template <bool ZG, bool YFIN = false>
 __device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, const ColGrid &g, double *lds) {
   const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
   const int blk = xcd_remap(blockIdx.x, nblk);
@@ -203,11 +213,16 @@ __device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
   if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, code, n1)) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colupd_wave<ZG>(c, S, lds + (size_t)wv * (ZG ? 1 : 2) * (c.km + 1) * 64, code, n1, g.fuse_convect);
+  colupd_wave<ZG, YFIN>(c, S, lds + (size_t)wv * (ZG ? 1 : 2) * (c.km + 1) * 64, code, n1, g.fuse_convect);
 }
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   colupd_body<false>(c, S, g, lds);
+}
+// pass B reading the final y fluxes pass A left (YFIN)
+__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_y(const uvic_ctx c, const double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  colupd_body<false, true>(c, S, g, lds);
 }
 // the same with z(k) parked in t(tau+1) (half the LDS per wave); no fused convective replay
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_zg(const uvic_ctx c, const double *S, const ColGrid g) {
@@ -530,6 +545,7 @@ struct uvic_gpu {
   double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
   bool mixing_next_guard = false;
+  bool yfin;        // pass A leaves the final y flux of each row's north face, pass B reads two of them (UVIC_YFIN, default 1)
   bool ts_in_bulk;  // T and S go through pass A with the other tracers; their pass B and the walk on the side stream (UVIC_TS_IN_BULK)
   bool b_zglobal;   // pass B parks z(k) in t(tau+1) instead of LDS (UVIC_B_ZGLOBAL, default 1)
   int a_mode;       // pass A of the bulk launch: 1 = one sweep, 2 = one sweep with two tracers per lane, 3 = two sweeps (UVIC_A_MODE)
@@ -795,6 +811,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   if (const char *e = getenv("UVIC_EXACT")) h->exact = atoi(e) != 0;
   h->b_zglobal = false;   // measured: 91 us alone against 80 with both arrays in LDS (the pass is bound by memory traffic, not by occupancy)
   if (const char *e = getenv("UVIC_B_ZGLOBAL")) h->b_zglobal = atoi(e) != 0;
+  h->yfin = true;
+  if (const char *e = getenv("UVIC_YFIN")) h->yfin = atoi(e) != 0;
   h->ts_in_bulk = false;
   if (const char *e = getenv("UVIC_TS_IN_BULK")) h->ts_in_bulk = atoi(e) != 0;
   // measured (102x102x19, alone, 30 tracers): 1 = one sweep 131 us, 2 = two tracers per lane 116, 3 = two sweeps 63 + 79 (in the
@@ -973,7 +991,9 @@ static int build_col_lanes(uvic_gpu *h) {
   };
   auto code_of = [&](int x, int r, int owned) { return (((x % nx + nx) % nx) + 2) | (r << 12) | (owned << 24); };
   std::vector<int> la, lb;
-  const int ra0 = c.js - 1 < 2 ? 2 : c.js - 1, ra1 = c.je + 1 > jmt - 1 ? jmt - 1 : c.je + 1;
+  // (with the final y flux formed in pass A, the pass needs rows js-1..je: the flux through the north face of row je is
+  // formed there from t of rows up to je+2, which the 2-row halo holds; else R+-Y of row je+1 is needed as well)
+  const int ra0 = c.js - 1 < 2 ? 2 : c.js - 1, ra1 = h->yfin ? std::min(c.je, jmt - 1) : (c.je + 1 > jmt - 1 ? jmt - 1 : c.je + 1);
   for (int r = ra0; r <= ra1; ++r) {
     // runs of this row as (start x, length), cyclic
     std::vector<std::pair<int, int>> runs;
@@ -1374,14 +1394,26 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (h->a_mode >= 4) {
         g.total = g.nwaves * ((cc.nt_local + 3) / 4) * 4;
         const size_t sh_lds = (size_t)2 * COL_SHARE_SLOTS * 64 * 16;
-        if (h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
+        if (h->yfin && h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha_y, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
+        else if (h->yfin) hipLaunchKernelGGL(k_colfct_sh_y, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
+        else if (h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
         else hipLaunchKernelGGL(k_colfct_sh, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
+      } else if (h->yfin) {
+        hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
       } else if (h->a_mode == 2) hipLaunchKernelGGL(k_colfct2, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
       else if (h->a_mode == 3) {
         hipLaunchKernelGGL(k_colfct_dif, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
         mark(h, "colfct_dif");
         hipLaunchKernelGGL(k_colfct_adv, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
       } else hipLaunchKernelGGL(k_colfct, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
+    };
+    // pass B of a launch (`ts`: the T,S launch on the side stream, own kernel name for the profiles)
+    auto launch_b = [&](const uvic_ctx &cc, const ColGrid &g, const double *Sg, hipStream_t st, bool ts) {
+      if (g.total <= 0) return;
+      if (h->yfin) hipLaunchKernelGGL(k_colupd_y, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds, st, cc, Sg, g);
+      else if (ts) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds, st, cc, Sg, g);
+      else if (h->b_zglobal && !g.fuse_convect) hipLaunchKernelGGL(k_colupd_zg, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds / 2, st, cc, Sg, g);
+      else hipLaunchKernelGGL(k_colupd, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds, st, cc, Sg, g);
     };
     // T and S first: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both passes and
     // the walk run on the side stream while the main stream works on the other tracers, whose pass B then finds the
@@ -1406,7 +1438,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       bts.total = bts.nwaves * 2;
       const WetCols w = wet_range(h, c.js, c.je);
       mark_on(h, "begin", 3);
-      if (bts.total > 0) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
+      launch_b(cts, bts, (const double *)S, h->side_ts, true);
       mark_on(h, "colupd_ts", 3);
       HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
       if (w.count > 0)
@@ -1432,7 +1464,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
-      if (br.total > 0) hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
+      launch_b(cr, br, (const double *)(S + 2 * N3), h->stream, false);
     } else if (split) {
       // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
       // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
@@ -1452,7 +1484,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       mark_on(h, "begin", 3);
       const WetCols w = wet_range(h, c.js, c.je);
       const size_t cv_lds = (size_t)2 * h->d.km * 64 * 8;
-      if (h->iso_fuse_armed && ats.total > 0 && bts.total > 0 && w.count > 0) {
+      if (h->iso_fuse_armed && !h->yfin && ats.total > 0 && bts.total > 0 && w.count > 0) {
         // the isopyc chain of the next step rides in the same three launches (k_ts_iso*)
         h->iso_fuse_armed = false;
         const uvic_ctx &ci = h->iso_fuse_ctx;
@@ -1470,9 +1502,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         h->iso_set[h->iso_fuse_set].for_step = h->step_no + 1;
         h->iso_set[h->iso_fuse_set].vel_stale = false;
       } else {
-        if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+        if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+        else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
         mark_on(h, "colfct_ts", 3);
-        if (bts.total > 0) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(bts)), dim3(64, COLUPD_WAVES), upd_lds, h->side_ts, cts, (const double *)S, bts);
+        launch_b(cts, bts, (const double *)S, h->side_ts, true);
         mark_on(h, "colupd_ts", 3);
         HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
         if (w.count > 0)
@@ -1515,12 +1548,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       // decoupled: the mixed segments are replayed by convect_apply after this pass (launch_convect), so that the main
       // stream does not stand still between its two passes while the T,S chain (three short kernels) finishes
       if (!dbg_nowait && !h->conv_decoupled) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
-      if (br.total > 0) {
-        if (h->b_zglobal && !br.fuse_convect)
-          hipLaunchKernelGGL(k_colupd_zg, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds / 2, h->stream, cr, (const double *)(S + 2 * N3), br);
-        else
-          hipLaunchKernelGGL(k_colupd, dim3(blocks_b(br)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, cr, (const double *)(S + 2 * N3), br);
-      }
+      launch_b(cr, br, (const double *)(S + 2 * N3), h->stream, false);
     } else {
       if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
@@ -1530,12 +1558,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
-      if (b.total > 0) {
-        if (h->b_zglobal)
-          hipLaunchKernelGGL(k_colupd_zg, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds / 2, h->stream, c, (const double *)S, b);
-        else
-          hipLaunchKernelGGL(k_colupd, dim3(blocks_b(b)), dim3(64, COLUPD_WAVES), upd_lds, h->stream, c, (const double *)S, b);
-      }
+      launch_b(c, b, (const double *)S, h->stream, false);
     }
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
