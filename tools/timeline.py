@@ -8,7 +8,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "?")))
 rows.sort()
 # four steps from the middle of the first (uninstrumented) timed loop of bench.py: counted by the bulk pass A launches
-idx = [n for n, r in enumerate(rows) if r[2] in ("k_colfct", "k_colfct_dif", "k_colfct2")]
+idx = [n for n, r in enumerate(rows) if r[2] in ("k_colfct", "k_colfct_dif", "k_colfct2", "k_colfct_sh", "k_colfct_sha", "k_colfct_sh_y", "k_colfct_sha_y")]
 first = idx[12] if len(idx) >= 17 else idx[0]
 last = idx[16] if len(idx) >= 17 else len(rows)
 t0 = rows[first][0]

@@ -45,7 +45,11 @@ enum {
   CF_AN = 0, CF_CN = 1,   // north face:  A, C[jq + 2*kr]
   CF_AE = 5, CF_CE = 6,   // east face:   A, C[ip + 2*kr]
   CF_BV = 10, CF_CBX = 11, CF_CBY = 15,  // bottom face
-  CF_COUNT = 19, CF_PAIRS = 10
+  CF_COUNT = 19,
+  // the total advective velocities, packed by isopyc_adv_cell and isopyc_column (or k_tot_vel) for the pass-A waves that share a level's pairs through LDS:
+  CF_VE = 20, CF_VN = 21,   // through the east and north faces of the cell
+  CF_VB = 22, CF_VS = 23,   // through the bottom face of level k (adv_vbt at k = km: tracer.F:1065) and the north face of row j-1
+  CF_PAIRS = 12, CF_DPAIRS = 10   // all pair planes; those of the diffusive coefficients
 };
 #define CF_IDX(slot, q, N3) ((((size_t)((slot) / 2) * (N3)) + (q)) * 2 + ((slot) % 2))
 
@@ -345,7 +349,7 @@ enum { PART_ALL = 0, PART_ADV = 1, PART_DIF = 2 };
 // clock and CU) are the same for all four.  Each wave brings a quarter of the next level's pairs into LDS (buffer_load ...
 // lds: no registers), one workgroup barrier per level, and every wave reads all 13 from LDS (256 B per clock).
 // `lds` = 2 x 13 x 64 double2 per workgroup, `wv` = the wave's number in it.
-#define COL_SHARE_SLOTS (CF_PAIRS + 3)
+#define COL_SHARE_SLOTS(YFIN) (CF_PAIRS + 3 + ((YFIN) ? 2 : 0))   /* row r: all pairs; row r-1: the north-face ones; YFIN: the velocity pairs of row r+1 */
 // YFIN: the wave also forms t_lo and the y-limiter ratios of the row to its NORTH (from t of rows r+1, r+2 and that row's
 // velocities: five more loads and ~60 more instructions per level) and with them the FINAL, limited advective flux through
 // its north face, which it stores (8 bytes per cell update) instead of the ratio pair R+-Y (16).  Pass B then reads that flux
@@ -355,6 +359,7 @@ template <int NTR, int PART, bool AHEAD = false, bool SHARE = false, bool YFIN =
 __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__restrict__ cf, double *__restrict__ S,
                                             int code, const int (&n1)[NTR], const bool (&live)[NTR], double *lds = nullptr, int wv = 0) {
   constexpr bool ADV = PART != PART_DIF, DIF = PART != PART_ADV;
+  constexpr int SLOTS = COL_SHARE_SLOTS(YFIN);
   static_assert(!YFIN || PART == PART_ALL, "the final y flux is formed by the one-sweep pass");
   UV_DIMS(c);
   const int i = COL_LANE_I(code), r = COL_LANE_R(code);
@@ -440,14 +445,14 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   auto load_in = [&](LvlIn &L, int s) {
     const int sp = (s == km) ? km : s + 1;
     L.ve = L.vn = L.vs = L.vb = 0.0;
-    if (ADV) {
+    if (ADV && !SHARE) {   // (SHARE: the velocity pairs come through LDS with the coefficients)
       L.ve = LD(te, s, 0); L.vn = LD(tn, s, 0); L.vs = LD(tn, s, -1);
       L.vb = (s < km) ? bld(b_tb, lbf, OF(s)) : bld(b_vb, lbf, OF(km));
     }
     if (DIF && SHARE) {
       // (read from LDS where they are used, in the diffusive half of level(): they need not occupy registers before)
     } else if (DIF) {
-      _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
+      _Pragma("unroll") for (int p = 0; p < CF_DPAIRS; ++p) {
         const double2 v = CFP(p, s, 0);
         L.cfc[2 * p] = v.x; L.cfc[2 * p + 1] = v.y;
       }
@@ -465,7 +470,16 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
   auto level = [&](const LvlIn &L, int s) {
     const bool last = (s == km);
     // ---- what the tracers share: velocities, folded coefficients, masks, metrics ------------------------
-    const double ve = L.ve, vn = L.vn, vs = L.vs, vb = L.vb;
+    double ve = L.ve, vn = L.vn, vs = L.vs, vb = L.vb, veN = 0.0, vnN = 0.0, vbN = 0.0;
+    const double2 *sl = SHARE ? (const double2 *)lds + (size_t)(s & 1) * SLOTS * 64 + (threadIdx.x & 63) : nullptr;
+    if (SHARE && ADV) {
+      const double2 a = sl[(CF_VE / 2) * 64], b = sl[(CF_VB / 2) * 64];
+      ve = a.x; vn = a.y; vb = b.x; vs = b.y;
+      if (YFIN) {
+        const double2 aN = sl[(CF_PAIRS + 3) * 64], bN = sl[(CF_PAIRS + 4) * 64];
+        veN = aN.x; vnN = aN.y; vbN = bN.x;
+      }
+    }
     double cfc_l[2 * CF_PAIRS], cfs_l[6];
     const double *cfc = SHARE ? cfc_l : L.cfc, *cfs = SHARE ? cfs_l : L.cfs;
     const double dzt2r_s = t_dzt2r.at(s - 1), ddztr = t_dztr.at(s - 1);
@@ -478,10 +492,12 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const double avb = dabs(vb);
     // YFIN: what the row to the north needs beyond what the wave holds anyway, asked for at the head of the level and used in
     // its second half (the level-ahead register set has no room for them: 250 VGPRs)
-    double veN_[NTR], vnN_[NTR], vbN_[NTR], m_nn_[NTR], t_nn_[NTR];
+    double m_nn_[NTR], t_nn_[NTR];
+    if (YFIN && !SHARE) {
+      veN = bld(b_te, lb, OC(s, 1)); vnN = bld(b_tn, lb, OC(s, 1));
+      vbN = (s < km) ? bld(b_tb, lbf_N, OF(s)) : 0.0;
+    }
     if (YFIN) FORQ {
-      veN_[q] = bld(b_te, lb, OC(s, 1)); vnN_[q] = bld(b_tn, lb, OC(s, 1));
-      vbN_[q] = (s < km) ? bld(b_tb, lbf_N, OF(s)) : 0.0;
       m_nn_[q] = bld(b_tm[q], lb_nn, OC(s, -1)); t_nn_[q] = bld(b_tt[q], lb_nn, OC(s, -1));   // (lb_nn points at the row itself)
     }
     FORQ {
@@ -530,7 +546,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
         }
         if (YFIN) {
           // ---- the row to the north: low-order fluxes, t_lo, y-limiter ratios (the same formulas one row up) ----------
-          const double veN = veN_[q], vnN = vnN_[q], vbN = vbN_[q], m_nn = m_nn_[q], t_nn = t_nn_[q];
+          const double m_nn = m_nn_[q], t_nn = t_nn_[q];
           const double m_N = mn1[q];
           const double mkN = (s <= kz_n) ? 1.0 : 0.0;
           const double feloN = upstream(veN, m_N, shfl_e(m_N));
@@ -573,8 +589,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       // =================== diffusive part (coefficients folded by ai_coef_cell) ===========================
       if (DIF) {
         if (SHARE && q == 0) {
-          const double2 *sl = (const double2 *)lds + (size_t)(s & 1) * COL_SHARE_SLOTS * 64 + (threadIdx.x & 63);
-          _Pragma("unroll") for (int p = 0; p < CF_PAIRS; ++p) {
+          _Pragma("unroll") for (int p = 0; p < CF_DPAIRS; ++p) {
             const double2 v = sl[p * 64];
             cfc_l[2 * p] = v.x; cfc_l[2 * p + 1] = v.y;
           }
@@ -628,11 +643,12 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     // both: the pairs through LDS one level ahead, and what the wave loads for itself one level ahead into a second register set
     auto bring = [&](int s) {
       typedef __attribute__((address_space(3))) void *ldsp;
-      _Pragma("unroll") for (int q = 0; q < (COL_SHARE_SLOTS + 3) / 4; ++q) {
+      _Pragma("unroll") for (int q = 0; q < (SLOTS + 3) / 4; ++q) {
         const int p = wv + 4 * q;
-        if (p < COL_SHARE_SLOTS) {
-          double2 *dst = (double2 *)lds + ((size_t)(s & 1) * COL_SHARE_SLOTS + p) * 64;
-          const int pair = p < CF_PAIRS ? p : p - CF_PAIRS, dj = p < CF_PAIRS ? 0 : -1;
+        if (p < SLOTS) {
+          double2 *dst = (double2 *)lds + ((size_t)(s & 1) * SLOTS + p) * 64;
+          const int pair = p < CF_PAIRS ? p : (p < CF_PAIRS + 3 ? p - CF_PAIRS : p - (CF_PAIRS + 3) + CF_VE / 2);
+          const int dj = p < CF_PAIRS ? 0 : (p < CF_PAIRS + 3 ? -1 : 1);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(b_cf, (ldsp)dst, 16, lb2, ((int)(pair) * (int)N3 + (s - 1) * imt + (dj + 1) * rowstride) * 16, 0, 0);
         }
       }
@@ -675,11 +691,12 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     // this wave's share of the coefficient pairs of level s: slots wv, wv+4, ... of the 13 (row r: 0..9, row r-1: 10..12)
     auto bring = [&](int s) {
       typedef __attribute__((address_space(3))) void *ldsp;
-      _Pragma("unroll") for (int q = 0; q < (COL_SHARE_SLOTS + 3) / 4; ++q) {
+      _Pragma("unroll") for (int q = 0; q < (SLOTS + 3) / 4; ++q) {
         const int p = wv + 4 * q;
-        if (p < COL_SHARE_SLOTS) {
-          double2 *dst = (double2 *)lds + ((size_t)(s & 1) * COL_SHARE_SLOTS + p) * 64;
-          const int pair = p < CF_PAIRS ? p : p - CF_PAIRS, dj = p < CF_PAIRS ? 0 : -1;
+        if (p < SLOTS) {
+          double2 *dst = (double2 *)lds + ((size_t)(s & 1) * SLOTS + p) * 64;
+          const int pair = p < CF_PAIRS ? p : (p < CF_PAIRS + 3 ? p - CF_PAIRS : p - (CF_PAIRS + 3) + CF_VE / 2);
+          const int dj = p < CF_PAIRS ? 0 : (p < CF_PAIRS + 3 ? -1 : 1);
           __builtin_amdgcn_raw_ptr_buffer_load_lds(b_cf, (ldsp)dst, 16, lb2, ((int)(pair) * (int)N3 + (s - 1) * imt + (dj + 1) * rowstride) * 16, 0, 0);
         }
       }

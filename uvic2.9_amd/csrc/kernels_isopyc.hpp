@@ -247,7 +247,8 @@ UVIC_DEV double gm_taper(double ath0, double m1, double m2, double abss, double 
   return ath0 * m1 * m2;
 }
 
-UVIC_DEV void isopyc_adv_cell(const uvic_ctx &c, int i, int k, int j) {
+// `ven` (column-kernel path, else null): the plane of (tot_e, tot_n) pairs that pass A reads (kernels_col.hpp: CF_VE)
+UVIC_DEV void isopyc_adv_cell(const uvic_ctx &c, int i, int k, int j, double *ven = nullptr) {
   UV_DIMS(c);
   const double sc = 1.0 / (c.slmxr * c.dtxsqr[k - 1]);
   const int kp1 = imin(k + 1, km);
@@ -266,6 +267,7 @@ UVIC_DEV void isopyc_adv_cell(const uvic_ctx &c, int i, int k, int j) {
     const double v = -(ath_t * stn * top_bc - ath_b * sbn * bot_bc) * c.dztr[k - 1] * c.csu[j - 1];
     c.adv_vntiso[X3(i, k, j)] = v;
     c.tot_n[X3(i, k, j)] = c.adv_vnt[X3(i, k, j)] + v;
+    if (ven) ven[2 * X3(i, k, j) + 1] = c.adv_vnt[X3(i, k, j)] + v;
   }
   if (j >= 2 && i >= 2 && i <= imt - 1) {  // zonal, isopyc.F:1436-1488 (+ setbcx)
     const double Ath0 = c.athkdf * 0.5 * (c.fisop[XFIS(i, j, k)] + c.fisop[XFIS(i + 1, j, k)]);
@@ -276,6 +278,7 @@ UVIC_DEV void isopyc_adv_cell(const uvic_ctx &c, int i, int k, int j) {
     const double v = -(ath_t * ste * top_bc - ath_b * sbe * bot_bc) * c.dztr[k - 1];
     c.adv_vetiso[X3(i, k, j)] = v;
     c.tot_e[X3(i, k, j)] = c.adv_vet[X3(i, k, j)] + v;
+    if (ven) ven[2 * X3(i, k, j)] = c.adv_vet[X3(i, k, j)] + v;
     if (i == 2) {
       c.adv_vetiso[X3(imt, k, j)] = v;
       c.tot_e[X3(imt, k, j)] = c.adv_vet[X3(imt, k, j)] + v;
@@ -293,7 +296,8 @@ UVIC_DEV void isopyc_adv_cell(const uvic_ctx &c, int i, int k, int j) {
 // (updates/09/source/mom/vmixc.F:182-188) and the total vertical advective
 // velocity.  One thread per column, i = 2..imt-1, j = 2..jmt-1.
 // ---------------------------------------------------------------------------
-UVIC_DEV void isopyc_column(const uvic_ctx &c, int i, int j) {
+// `vbs` (column-kernel path, else null): the plane of (tot_b of face k, tot_n of row j-1) pairs of pass A (kernels_col.hpp: CF_VB)
+UVIC_DEV void isopyc_column(const uvic_ctx &c, int i, int j, double *vbs = nullptr) {
   UV_DIMS(c);
   double run = 0.0;
   const int kz = c.kmt[X2(i, j)];
@@ -302,12 +306,13 @@ UVIC_DEV void isopyc_column(const uvic_ctx &c, int i, int j) {
   // so a level-by-level loop would pay one memory round trip per level.
 #define IDXF(ii) XF(ii, k, j)
   for (int k0 = 0; k0 <= km; k0 += 8) {
-    double d[8], vb[8];
+    double d[8], vb[8], vs[8];
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {
       const int k = k0 + u;
-      d[u] = 0.0; vb[u] = 0.0;
+      d[u] = 0.0; vb[u] = 0.0; vs[u] = 0.0;
       if (k <= km) {
         vb[u] = c.adv_vbt[XF(i, k, j)];
+        if (vbs && k >= 1) vs[u] = c.tot_n[X3(i, k, j - 1)];
         if (k >= 1 && k <= km - 1)
           d[u] = c.dzt[k - 1] * c.cstr[j - 1] *
                  ((c.adv_vetiso[X3(i, k, j)] - c.adv_vetiso[X3(i - 1, k, j)]) * c.dxtr[i - 1] +
@@ -325,6 +330,10 @@ UVIC_DEV void isopyc_column(const uvic_ctx &c, int i, int j) {
       if (k == kz) v = 0.0;
       UV_CYC_STORE(c.adv_vbtiso, IDXF, i, v);
       UV_CYC_STORE(c.tot_b, IDXF, i, vb[u] + v);
+      if (vbs && k >= 1) {   // (at k = km v is zero: adv_vbt itself, the flux through the bottom face, tracer.F:1065)
+        vbs[2 * X3(i, k, j)] = vb[u] + v;
+        vbs[2 * X3(i, k, j) + 1] = vs[u];
+      }
     }
   }
 #undef IDXF

@@ -64,18 +64,18 @@ __global__ void __launch_bounds__(256) k_isopyc_ai(const uvic_ctx c) {
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   isopyc_ai_cell(c, i, k, j);
 }
-__global__ void __launch_bounds__(256) k_isopyc_adv(const uvic_ctx c) {
+__global__ void __launch_bounds__(256) k_isopyc_adv(const uvic_ctx c, double *cf) {
   if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   CELL_DECODE(c);
   if (j > c.jmt - 1 || SLAB_OUT(c, j)) return;
-  isopyc_adv_cell(c, i, k, j);
+  isopyc_adv_cell(c, i, k, j, cf + CF_IDX(CF_VE, 0, (size_t)c.imt * c.km * c.jmt));
 }
-__global__ void __launch_bounds__(128) k_isopyc_column(const uvic_ctx c) {
+__global__ void __launch_bounds__(128) k_isopyc_column(const uvic_ctx c, double *cf) {
   if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
   if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
-  isopyc_column(c, i, j);
+  isopyc_column(c, i, j, cf + CF_IDX(CF_VB, 0, (size_t)c.imt * c.km * c.jmt));
 }
 
 // one workgroup per (row, local tracer, longitude chunk)
@@ -137,12 +137,21 @@ __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
 // The total advective velocities adv_v?t + adv_v?tiso are formed by the isopyc kernels.  When those ran a step ahead and the
 // host has since uploaded this step's adv_vet/vnt/vbt (the Fortran overlay does, every step), the sums are formed again
 // from the new velocities and the GM velocities computed ahead: the same additions, element by element.
-__global__ void __launch_bounds__(256) k_tot_vel(const uvic_ctx c) {
+__global__ void __launch_bounds__(256) k_tot_vel(const uvic_ctx c, double *cf) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long N3 = (long long)c.imt * c.km * c.jmt, NF = (long long)c.imt * (c.km + 1) * c.jmt;
   if (gid < N3) {
-    c.tot_e[gid] = c.adv_vet[gid] + c.adv_vetiso[gid];
-    c.tot_n[gid] = c.adv_vnt[gid] + c.adv_vntiso[gid];
+    const double e = c.adv_vet[gid] + c.adv_vetiso[gid], n = c.adv_vnt[gid] + c.adv_vntiso[gid];
+    c.tot_e[gid] = e;
+    c.tot_n[gid] = n;
+    // ... and their packed copies for pass A (isopyc_adv_cell, isopyc_column)
+    const long long rowstride = (long long)c.imt * c.km;
+    const int j = (int)(gid / rowstride) + 1, k = (int)(gid % rowstride) / c.imt + 1, i = (int)(gid % c.imt) + 1;
+    const size_t fq = (size_t)(i - 1) + (size_t)c.imt * ((size_t)k + (size_t)(c.km + 1) * (j - 1));   // face k of the column
+    cf[CF_IDX(CF_VE, gid, N3)] = e;
+    cf[CF_IDX(CF_VN, gid, N3)] = n;
+    cf[CF_IDX(CF_VB, gid, N3)] = (k < c.km) ? c.adv_vbt[fq] + c.adv_vbtiso[fq] : c.adv_vbt[fq];
+    cf[CF_IDX(CF_VS, gid, N3)] = (j >= 2) ? c.adv_vnt[gid - rowstride] + c.adv_vntiso[gid - rowstride] : 0.0;
   }
   if (gid < NF) c.tot_b[gid] = c.adv_vbt[gid] + c.adv_vbtiso[gid];
 }
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(256) k_ts_iso2(const uvic_ctx c, const double 
   const bool second = b >= ncell;   // first the mixing tensor and the folded coefficients, then the GM velocities
   CELL_DECODE_ID(ci, (long long)(second ? b - ncell : b) * 256 + threadIdx.y * 64 + threadIdx.x);
   if (j > ci.jmt - 1 || SLAB_OUT(ci, j)) return;
-  if (second) { isopyc_adv_cell(ci, i, k, j); return; }
+  if (second) { isopyc_adv_cell(ci, i, k, j, cfi + CF_IDX(CF_VE, 0, (size_t)ci.imt * ci.km * ci.jmt)); return; }
   if (i < 2 || i > ci.imt - 1) return;
   ai_coef_cell(ci, cfi, i, k, j);
 }
@@ -297,7 +306,7 @@ __global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCo
   if (cvl && c.cv_nseg[wid_] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid_;
 }
 // third shared launch: the convective T,S walk beside the column sums of isopyc
-__global__ void __launch_bounds__(256) k_ts_iso3(const uvic_ctx c, const WetCols w, int nts, const uvic_ctx ci, int *cvl) {
+__global__ void __launch_bounds__(256) k_ts_iso3(const uvic_ctx c, const WetCols w, int nts, const uvic_ctx ci, int *cvl, double *cfi) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if ((int)blockIdx.x < nts) {
     const int gid = blockIdx.x * 64 + threadIdx.x;
@@ -312,7 +321,7 @@ __global__ void __launch_bounds__(256) k_ts_iso3(const uvic_ctx c, const WetCols
   const int gid = (blockIdx.x - nts) * 256 + threadIdx.y * 64 + threadIdx.x;
   const int i = gid % ci.imt + 1, j = gid / ci.imt + 1;
   if (j < 2 || j > ci.jmt - 1 || i < 2 || i > ci.imt - 1 || SLAB_OUT(ci, j)) return;
-  isopyc_column(ci, i, j);
+  isopyc_column(ci, i, j, cfi + CF_IDX(CF_VB, 0, (size_t)ci.imt * ci.km * ci.jmt));
 }
 // The columns in which the walk mixed something, as a list: cvl[0] counts them, cvl[1..] holds their ids ((i-1) + imt*(j-1)).
 // Few columns convect in a step, and convect_apply over the list is a handful of waves instead of one thread per
@@ -1333,9 +1342,9 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
   else   // column-kernel path: mixing tensor and folded coefficients in one pass (Ai_* stay in registers)
     hipLaunchKernelGGL(k_ai_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef);
   mark_on(h, "isopyc_ai", sid);
-  hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
+  hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef);
   mark_on(h, "isopyc_adv", sid);
-  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, st, c);
+  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, st, c, coef);
   mark_on(h, "isopyc_column", sid);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1355,7 +1364,7 @@ static int launch_isopyc(uvic_gpu *h) {
     h->iso_waited = true;
     if (h->iso_set[set].vel_stale) {   // this step's velocities arrived after the chain ran
       const long long nf = (long long)h->d.imt * (h->d.km + 1) * h->d.jmt;
-      hipLaunchKernelGGL(k_tot_vel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, h->stream, h->ctx);
+      hipLaunchKernelGGL(k_tot_vel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
       mark(h, "tot_vel");
       h->iso_set[set].vel_stale = false;
       h->iso_waited = false;   // the T,S stream reads them too: it must not start before this
@@ -1393,7 +1402,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       const double *cf = (const double *)h->coef;
       if (h->a_mode >= 4) {
         g.total = g.nwaves * ((cc.nt_local + 3) / 4) * 4;
-        const size_t sh_lds = (size_t)2 * COL_SHARE_SLOTS * 64 * 16;
+        const size_t sh_lds = (size_t)2 * COL_SHARE_SLOTS(h->yfin) * 64 * 16;
         if (h->yfin && h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha_y, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
         else if (h->yfin) hipLaunchKernelGGL(k_colfct_sh_y, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
         else if (h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
@@ -1496,7 +1505,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
                            ci, h->iso_fuse_coef, ncell256);
         mark_on(h, "colupd_ts", 3);
         HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
-        hipLaunchKernelGGL(k_ts_iso3, dim3((unsigned)(n3 + ncol256)), dim3(64, 4), cv_lds, h->side_ts, cts, w, n3, ci, h->cv_list);
+        hipLaunchKernelGGL(k_ts_iso3, dim3((unsigned)(n3 + ncol256)), dim3(64, 4), cv_lds, h->side_ts, cts, w, n3, ci, h->cv_list, h->iso_fuse_coef);
         mark_on(h, "convect_ts", 3);
         HIPCHK(hipEventRecord(h->iso_set[h->iso_fuse_set].ev, h->side_ts));
         h->iso_set[h->iso_fuse_set].for_step = h->step_no + 1;
