@@ -441,6 +441,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     double ve, vn, vs, vb;
     double cfc[2 * CF_PAIRS], cfs[6];   // folded coefficients of row r and the north-face ones (slots 0..4) of row r-1
     double mc2[NTR], ms2[NTR], mn2[NTR], tc2[NTR], t_s[NTR], t_n[NTR];
+    double m_nn[NTR], t_nn[NTR];   // YFIN: t(tau-1), t(tau) of level s two rows to the north
   };
   auto load_in = [&](LvlIn &L, int s) {
     const int sp = (s == km) ? km : s + 1;
@@ -465,6 +466,8 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
       L.mc2[q] = LDQ(b_tm, sp, 0); L.ms2[q] = LDQ(b_tm, sp, -1); L.mn2[q] = LDQ(b_tm, sp, 1);
       L.tc2[q] = L.t_s[q] = L.t_n[q] = 0.0;
       if (ADV) { L.tc2[q] = LDQ(b_tt, sp, 0); L.t_s[q] = LDQ(b_tt, s, -1); L.t_n[q] = LDQ(b_tt, s, 1); }
+      L.m_nn[q] = L.t_nn[q] = 0.0;
+      if (YFIN) { L.m_nn[q] = bld(b_tm[q], lb_nn, OC(s, -1)); L.t_nn[q] = bld(b_tt[q], lb_nn, OC(s, -1)); }   // (lb_nn points at the row itself)
     }
   };
   auto level = [&](const LvlIn &L, int s) {
@@ -490,15 +493,10 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
     const bool wet_w = s <= kz_w, wet_e = s <= kz_e, wet_s = s <= kz_s, wet_n = s <= kz_n;
     const bool wet_up = s - 1 >= 1 && s - 1 <= kz, wet_dn = s + 1 <= kz;
     const double avb = dabs(vb);
-    // YFIN: what the row to the north needs beyond what the wave holds anyway, asked for at the head of the level and used in
-    // its second half (the level-ahead register set has no room for them: 250 VGPRs)
-    double m_nn_[NTR], t_nn_[NTR];
+    // YFIN without SHARE (the T,S launch): the velocities of the row to the north, asked for at the head of the level
     if (YFIN && !SHARE) {
       veN = bld(b_te, lb, OC(s, 1)); vnN = bld(b_tn, lb, OC(s, 1));
       vbN = (s < km) ? bld(b_tb, lbf_N, OF(s)) : 0.0;
-    }
-    if (YFIN) FORQ {
-      m_nn_[q] = bld(b_tm[q], lb_nn, OC(s, -1)); t_nn_[q] = bld(b_tt[q], lb_nn, OC(s, -1));   // (lb_nn points at the row itself)
     }
     FORQ {
       const double mc2 = L.mc2[q], ms2 = L.ms2[q], mn2 = L.mn2[q];
@@ -546,7 +544,7 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
         }
         if (YFIN) {
           // ---- the row to the north: low-order fluxes, t_lo, y-limiter ratios (the same formulas one row up) ----------
-          const double m_nn = m_nn_[q], t_nn = t_nn_[q];
+          const double m_nn = L.m_nn[q], t_nn = L.t_nn[q];
           const double m_N = mn1[q];
           const double mkN = (s <= kz_n) ? 1.0 : 0.0;
           const double feloN = upstream(veN, m_N, shfl_e(m_N));
