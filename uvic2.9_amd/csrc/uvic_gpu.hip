@@ -70,12 +70,64 @@ __global__ void __launch_bounds__(256) k_isopyc_adv(const uvic_ctx c, double *cf
   if (j > c.jmt - 1 || SLAB_OUT(c, j)) return;
   isopyc_adv_cell(c, i, k, j, cf + CF_IDX(CF_VE, 0, (size_t)c.imt * c.km * c.jmt));
 }
-__global__ void __launch_bounds__(128) k_isopyc_column(const uvic_ctx c, double *cf) {
+// isopyc_column (kernels_isopyc.hpp) with eight threads per column.  One thread per column walks the levels in batches and
+// pays a memory round trip per batch: ~30 us however few columns there are, on the chain every step waits for.  Here the
+// eight threads of a column fetch the operands of all levels at once and form the divergence terms (phase 1), one of them
+// adds them up top-down in the reference's order through LDS (phase 2: the only sequential part, no memory access in it),
+// and all eight store (phase 3).  Same operations in the same order per element: bit-identical to isopyc_column.
+#define ISO_COL_PARTS 8
+__global__ void __launch_bounds__(64 * ISO_COL_PARTS) k_isopyc_column(const uvic_ctx c, double *cf) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gid % c.imt + 1, j = gid / c.imt + 1;
-  if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
-  isopyc_column(c, i, j, cf + CF_IDX(CF_VB, 0, (size_t)c.imt * c.km * c.jmt));
+  UV_DIMS(c);
+  const int x = threadIdx.x, y = threadIdx.y;
+  const int gid = blockIdx.x * 64 + x;
+  const int i = gid % imt + 1, j = gid / imt + 1;
+  const bool live = !(j < 2 || j > jmt - 1 || i < 2 || i > imt - 1 || SLAB_OUT(c, j));
+  double *ld = lds + x, *lvb = lds + (size_t)(km + 1) * 64 + x, *lvs = lds + (size_t)2 * (km + 1) * 64 + x;
+  double *vbs = cf + CF_IDX(CF_VB, 0, N3);
+  if (live) {
+#pragma unroll 2
+    for (int k = y; k <= km; k += ISO_COL_PARTS) {
+      double d = 0.0, vs = 0.0;
+      if (k >= 1 && k <= km - 1)
+        d = c.dzt[k - 1] * c.cstr[j - 1] *
+            ((c.adv_vetiso[X3(i, k, j)] - c.adv_vetiso[X3(i - 1, k, j)]) * c.dxtr[i - 1] +
+             (c.adv_vntiso[X3(i, k, j)] - c.adv_vntiso[X3(i, k, j - 1)]) * c.dytr[j - 1]);
+      if (k >= 1) vs = c.tot_n[X3(i, k, j - 1)];
+      ld[(size_t)k * 64] = d;
+      lvb[(size_t)k * 64] = c.adv_vbt[XF(i, k, j)];
+      lvs[(size_t)k * 64] = vs;
+      if (!c.diff_cbt_given && k >= 1) c.diff_cbt[X3(i, k, j)] = c.diff_cbt_bg[X3(i, k, j)] + c.K33[X3(i, k, j)];
+    }
+  }
+  __syncthreads();
+  if (live && y == 0) {
+    const int kz = c.kmt[X2(i, j)];
+    double run = 0.0;
+    for (int k = 0; k <= km; ++k) {
+      double v = 0.0;
+      if (k >= 1 && k <= km - 1) {
+        run = ld[(size_t)k * 64] + run;
+        v = run;
+      }
+      if (k == kz) v = 0.0;
+      ld[(size_t)k * 64] = v;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+#define IDXF(ii) XF(ii, k, j)
+  for (int k = y; k <= km; k += ISO_COL_PARTS) {
+    const double v = ld[(size_t)k * 64], tb = lvb[(size_t)k * 64] + v;
+    UV_CYC_STORE(c.adv_vbtiso, IDXF, i, v);
+    UV_CYC_STORE(c.tot_b, IDXF, i, tb);
+    if (k >= 1) {   // the pair plane of pass A (kernels_col.hpp: CF_VB; at k = km v is zero: adv_vbt itself, tracer.F:1065)
+      vbs[2 * X3(i, k, j)] = tb;
+      vbs[2 * X3(i, k, j) + 1] = lvs[(size_t)k * 64];
+    }
+  }
+#undef IDXF
 }
 
 // one workgroup per (row, local tracer, longitude chunk)
@@ -1344,7 +1396,7 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
   mark_on(h, "isopyc_ai", sid);
   hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef);
   mark_on(h, "isopyc_adv", sid);
-  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 128)), dim3(128), 0, st, c, coef);
+  hipLaunchKernelGGL(k_isopyc_column, dim3(col_blocks(h, 64)), dim3(64, ISO_COL_PARTS), (size_t)3 * (h->d.km + 1) * 64 * 8, st, c, coef);
   mark_on(h, "isopyc_column", sid);
   HIPCHK(hipGetLastError());
   return 0;
