@@ -644,6 +644,8 @@ struct uvic_gpu {
   // before step n waits for the chain of step n: `_pending` = recorded during this step, `_ready` = what this step waits for
   int ev_flip;
   hipEvent_t ev_src_ready, ev_src_pending;
+  hipEvent_t ev_src_consumed;   // the MOBI chain whose sources the previous step took (its last reader of t(tau-1) then)
+  bool src_consumed_valid, src_consumed_now, prev_mixing, halo_seen, iso2_used, ts_free_opt;
   hipEvent_t ev_step_end[2], ev_end_ready, ev_end_pending;   // end of a step's own work (step_end)
   bool end_ready, end_pending;
   // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
@@ -830,7 +832,9 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->ev_flip = 0;
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
-  h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
+  h->ev_src_ready = h->ev_src_pending = h->ev_src_consumed = h->ev_src_next[0];
+  h->src_consumed_valid = h->src_consumed_now = h->prev_mixing = h->halo_seen = h->iso2_used = false;
+  h->ts_free_opt = getenv("UVIC_TS_FREE") && atoi(getenv("UVIC_TS_FREE")) != 0;   // measured: ties; off by default
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_step_end[q], hipEventDisableTiming));
   h->ev_end_ready = h->ev_end_pending = h->ev_step_end[0];
   h->end_ready = h->end_pending = false;
@@ -1529,7 +1533,20 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     } else if (split) {
       // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
       // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
-      if (h->iso_waited && h->step_begun) {
+      // T and S of step n depend on T and S of step n-1 and on nothing else the main stream does: their passes may run
+      // while the main stream is still in step n-1.  What has to be kept apart (ts_free): pass B of T,S writes the buffer
+      // that was t(tau-1) of step n-1, which the MOBI chain of that step read (-> wait for that chain); the convective walk
+      // rewrites the segment records that the replay of step n-1 reads (-> wait for the main stream's step n-1 there, not
+      // before pass A).  Any step that is not plain (forward step now or before, sources or isopyc in line, halo rows
+      // arriving, the filter, a buffer whose land is not cleared yet) keeps the whole chain behind the previous step.
+      bool land_ok = false;
+      for (void *q : h->land_zeroed) land_ok = land_ok || q == (void *)c.t_taup1;
+      const bool ts_free = h->ts_free_opt && h->iso_waited && h->step_begun && !h->mixing && !h->prev_mixing && !h->halo_seen &&
+                           !h->iso2_used && land_ok && h->flt_nitems == 0 && (!h->have_mobi || h->src_consumed_valid) &&
+                           !h->iso_fuse_armed;
+      if (ts_free) {
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
+      } else if (h->iso_waited && h->step_begun) {
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
       } else {
@@ -1566,8 +1583,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
         else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
         mark_on(h, "colfct_ts", 3);
+        if (ts_free && h->have_mobi) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_src_consumed, 0));
         launch_b(cts, bts, (const double *)S, h->side_ts, true);
         mark_on(h, "colupd_ts", 3);
+        if (ts_free) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
         HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
         if (w.count > 0)
           hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds, h->side_ts, cts, w, h->cv_list);
@@ -1604,6 +1623,8 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
+        h->ev_src_consumed = h->ev_src_ready;
+        h->src_consumed_now = true;
       }
       static const bool dbg_nowait = getenv("UVIC_DBG_NOWAIT_TS") != nullptr;   // timing experiment only: results are wrong
       // decoupled: the mixed segments are replayed by convect_apply after this pass (launch_convect), so that the main
@@ -1986,6 +2007,7 @@ static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead) {
   hipStream_t st = h->side2;
   int sid = 2;
   if (ahead == 2) {
+    h->iso2_used = true;
     if (!h->ts_final_valid) return 0;                  // nothing says when T,S are final: leave it to ahead = 1 of the next step
     st = h->side_m[h->mobi_flip];
     sid = h->mobi_flip ? 4 : 1;
@@ -2067,6 +2089,7 @@ extern "C" int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north) {
 // ... and the received rows into the halo rows beyond the slab
 extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
   if (!h) return fail_msg("null handle");
+  h->halo_seen = true;   // rows of t(tau+1) of every tracer, T and S too, arrive on the main stream after the step
   if (south) if (int rc = halo_move(h, 2, h->ctx.js - UVIC_HALO, 1)) return rc;
   if (north) if (int rc = halo_move(h, 3, h->ctx.je + 1, 1)) return rc;
   return 0;
@@ -2074,6 +2097,9 @@ extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
 extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   h->step_begun = false;
+  h->prev_mixing = h->mixing;
+  h->src_consumed_valid = h->src_consumed_now;
+  h->src_consumed_now = false;
   if (h->unmix_at_rotate) { h->mixing = false; h->unmix_at_rotate = false; }
   h->ev_flip ^= 1;
   h->end_ready = h->end_pending;
