@@ -52,6 +52,8 @@ CONFIGS = {
     "p2": BASE,
     # option set E, nt=13
     "e13": BASE + "O_mobi O_mobi_o2 O_mobi_iron O_carbon O_mobi_caco3".split(),
+    # option set F = E + alkalinity + nitrogen, nt=18
+    "f18": BASE + "O_mobi O_mobi_o2 O_mobi_iron O_carbon O_mobi_caco3 O_mobi_alk O_mobi_nitrogen".split(),
     # option set C == BASELINE config 4, nt=30
     "c30": BASE + ("O_mobi O_mobi_o2 O_mobi_iron O_carbon O_mobi_alk O_mobi_nitrogen "
                    "O_carbon_13 O_carbon_14 O_mobi_nitrogen_15").split(),

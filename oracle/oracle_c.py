@@ -13,7 +13,8 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 LIB = HERE / "liboracle.so"
-SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c", HERE / "prep_oracle.c", HERE / "filter_oracle.c"]
+SOURCES = [HERE / "uvic_oracle.c", HERE / "mobi_oracle.c", HERE / "mobi_gen_oracle.c", HERE / "prep_oracle.c",
+           HERE / "filter_oracle.c"]
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int)

@@ -82,6 +82,33 @@ def mobi_fixture():
     print("wrote", p)
 
 
+def mobi_set_fixture(cfg_name):
+    """The same for the option sets served by the run-time-flag MOBI path (f18, s37): every scalar and level array of
+    COMMON /npzd_r/ the path reads, after the reference's own mobi_init, for km = 6 and 19."""
+    import build_ref
+    import mobi_gen_c
+    out = {}
+    for km in (6, 19):
+        if not refmodel.available(cfg_name, 14, 14, km):
+            build_ref.build(cfg_name, 14, 14, km)
+        oc = synthetic.make_ocean(cfg_name, 14, 14, km)
+        ro = refdriver.RefOcean(oc)
+        o = oc.cfg.options
+        names = (mobi_gen_c.SCALARS + (mobi_gen_c.SCALARS_CACO3 if "mobi_caco3" in o else [])
+                 + (mobi_gen_c.SCALARS_SIL if "mobi_silicon" in o else []) + ["dtnpzd"])
+        d = {n.lower(): float(ro.v[n.lower()][0]) for n in names}
+        for n in mobi_gen_c.ARRAYS:
+            if (n == "wc" and "mobi_caco3" not in o) or (n == "wo" and "mobi_silicon" not in o):
+                continue
+            d[n] = ro.v[n].tolist()
+        # the column order of tnpzd as tracer_init assigned it
+        d["imobi"] = {n: int(ro.v["imobi" + n][0]) for n in mobi_gen_c.X if "imobi" + n in ro.v and oc.cfg.imobi(n)}
+        out[str(km)] = d
+    p = ROOT / "uvic2.9_amd" / "data" / f"mobi_{cfg_name}.json"
+    p.write_text(json.dumps(out))
+    print("wrote", p)
+
+
 def step_fixture(cfg, imt, jmt, km):
     oc = synthetic.make_ocean(cfg, imt, jmt, km)
     ro = refdriver.RefOcean(oc)
@@ -132,3 +159,6 @@ if __name__ == "__main__":
     step_fixture("c30", 14, 14, 6)
     run_fixture("p2", 14, 14, 6, 20)
     run_fixture("c30", 14, 14, 6, 20)
+    for name in ("f18", "s37"):
+        mobi_set_fixture(name)
+        step_fixture(name, 14, 14, 6)

@@ -118,7 +118,7 @@ def _build(name, opts):
             src += ["zoopc13", "detrc13"]
             if has("mobi_nitrogen"):
                 src += ["doc13", "diazc13"]
-    mobi = []
+    mobi = []      # column order of tnpzd: imobi* as tracer_init assigns them (checked against the compiled reference)
     if has("mobi"):
         mobi += ["po4", "phyt", "phyt_phos", "zoop", "detr", "detr_phos"]
         if has("carbon"):
@@ -127,10 +127,20 @@ def _build(name, opts):
             mobi += ["dic13", "phytc13", "zoopc13", "detrc13"]
             if has("mobi_nitrogen"):
                 mobi += ["doc13", "diazc13"]
+            if has("mobi_silicon"):
+                mobi.append("diatc13")
+            if has("mobi_caco3"):
+                mobi.append("caco3c13")
         if has("mobi_nitrogen"):
             mobi += ["dop", "no3", "don", "diaz"]
             if has("mobi_nitrogen_15"):
                 mobi += ["din15", "don15", "phytn15", "zoopn15", "detrn15", "diazn15"]
+                if has("mobi_silicon"):
+                    mobi.append("diatn15")
+        if has("mobi_caco3"):
+            mobi.append("caco3")
+        if has("mobi_silicon"):
+            mobi += ["diat", "sil", "opl"]
         if has("mobi_iron"):
             mobi += ["dfe", "detrfe"]
     return OptionSet(name, tuple(tr), tuple(src), tuple(mobi), o)
@@ -142,6 +152,13 @@ OPTION_SETS = {
     # BASELINE config 4 == SURVEY option set C (nt=30, nsrc=28, ntnpzd=25)
     "c30": _build("c30", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen",
                           "carbon_13", "carbon_14", "mobi_nitrogen_15"]),
+    # SURVEY option set E (nt=13): the nearest buildable set to BASELINE config 2
+    "e13": _build("e13", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_caco3"]),
+    # SURVEY option set F (nt=18): the nearest buildable set to BASELINE config 3
+    "f18": _build("f18", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_caco3", "mobi_alk", "mobi_nitrogen"]),
+    # the shipped run/mk.in set (nt=37): C + prognostic CaCO3 + diatoms/silicon
+    "s37": _build("s37", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen", "carbon_13", "carbon_14",
+                          "mobi_nitrogen_15", "mobi_caco3", "mobi_silicon"]),
 }
 
 
