@@ -132,6 +132,25 @@ typedef struct uvic_mobi_forcing {
   const double *fe_hydr;   /* (imt,jmt,km) mobi.h */
 } uvic_mobi_forcing;
 
+/* The cpp options of u09/mom/mobi.F that differ between the option sets the reference can build, and
+ * what they add to COMMON /npzd_r/.  Always on: O_mobi_o2, O_mobi_iron, O_carbon, O_mobi_alk, O_mobi_nitrogen.
+ * `im`/`is`: position in tnpzd (imobi*) and source slot (is*) of every MOBI column tracer, 0 = not in this set, in the
+ * order  po4 phyt phyt_phos zoop detr detr_phos dic dic13 phytc13 zoopc13 detrc13 doc13 diazc13 dop no3 don diaz
+ *        din15 don15 phytn15 zoopn15 detrn15 diazn15 dfe detrfe caco3 diat sil opl diatn15 diatc13 caco3c13 */
+#define UVIC_MOBI_NX 32
+typedef struct uvic_mobi_options {
+  int32_t n15, c13, caco3, silicon;   /* O_mobi_nitrogen_15, O_carbon_13, O_mobi_caco3, O_mobi_silicon */
+  int32_t im[UVIC_MOBI_NX], is[UVIC_MOBI_NX];
+  int32_t is_alk, is_o2, is_c14, pad_;
+  double kc_c, dissk0, caprmax, kcapr;                                           /* O_mobi_caco3 (mobi.h) */
+  double abiodiat, kfemin_Diat, kfemax_Diat, knmin_Diat, knmax_Diat, pmax_Diat;  /* O_mobi_silicon */
+  double zprefDiat, nu_diat, nudt0, opl_disk0;
+  double wc[64], wo[64];                                                         /* sinking of CaCO3 and opal per level */
+} uvic_mobi_options;
+/* uvic_gpu_set_mobi for any of those option sets.  With the flags of set C (n15 = c13 = 1, caco3 = silicon = 0) it is
+ * uvic_gpu_set_mobi; otherwise the sources come from the general column kernel (csrc/kernels_mobi_gen.hpp). */
+int uvic_gpu_set_mobi_opt(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_options *o, const uvic_mobi_forcing *f);
+
 /* upload MOBI parameters and forcing; after this uvic_gpu_tracer computes the
  * source terms itself (replaces the column loop of u09/mom/tracer.F:355-545 with
  * mobi_driver/mobi_src/co2calc_SWS and the 14C source, tracer.F:853-867) instead

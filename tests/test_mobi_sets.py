@@ -110,3 +110,99 @@ def test_mobi_driver_columns_match_compiled_reference(cfg):
         assert np.array_equal(s1, s2) and np.array_equal(tn1, tn2), trial
         checked += 1
     assert checked > 30
+
+
+# ---- the device ---------------------------------------------------------------------------------------------
+MOBI_RTOL = 1e-11     # device exp/log/pow/tanh differ from libm in the last bits (as for option set C, tests/test_mobi.py)
+
+
+def _table(cfg, km):
+    return pm.load_table(cfg, km)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,dims", [("f18", (14, 14, 6)), ("s37", (14, 14, 6)), ("s37", (102, 102, 19)), ("f18", (102, 102, 19))])
+def test_gpu_sources_of_the_other_option_sets_vs_oracle(cfg, dims):
+    """uvic_gpu_set_mobi_opt + uvic_gpu_mobi (the general column kernel) against the run-time-flag oracle."""
+    from uvic29_amd.tracer import TracerModel
+    oc = synthetic.make_ocean(cfg, *dims)
+    prm = _table(cfg, dims[2])
+    to, so, c = synthetic.load_eos(dims[2])
+    want = mobi_gen_c.mobi_sources(oc, prm, oc.t_taum1, 2 * oc.params.dtts)
+    m = TracerModel(*dims, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.load_ocean(oc, to, so, c)
+    m.set_mobi(oc)
+    m.mobi()
+    got = m.download("src")
+    worst = 0.0
+    for s, name in enumerate(oc.cfg.sources):
+        scale = np.abs(want[..., s]).max()
+        err = np.abs(got[..., s] - want[..., s]).max()
+        worst = max(worst, err / scale)
+        assert scale > 0 and err <= MOBI_RTOL * scale, (name, err, scale)
+    print("worst relative source error", cfg, dims, worst)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_general_kernel_with_the_flags_of_set_c_vs_the_set_c_oracle(monkeypatch):
+    """The general kernel forced onto option set C (UVIC_MOBI_GENERIC=1) against the oracle that is pinned hardest."""
+    from uvic29_amd.tracer import TracerModel
+    monkeypatch.setenv("UVIC_MOBI_GENERIC", "1")
+    oc = synthetic.make_ocean("c30", 14, 14, 6)
+    prm = pm.load_table("c30", 6)
+    to, so, c = synthetic.load_eos(6)
+    want = mobi_c.mobi_sources(oc, prm, oc.t_taum1, 2 * oc.params.dtts)
+    m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.load_ocean(oc, to, so, c)
+    m.set_mobi(oc)
+    m.mobi()
+    got = m.download("src")
+    for s, name in enumerate(oc.cfg.sources):
+        scale = np.abs(want[..., s]).max()
+        assert np.abs(got[..., s] - want[..., s]).max() <= MOBI_RTOL * scale, name
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", SETS)
+def test_gpu_full_step_of_the_other_option_sets_vs_golden(cfg):
+    """One complete `tracer` step (MOBI + transport + convection, bit-exact transport) against the golden output of the
+    compiled reference; T and S have no biological source: bit-exact."""
+    from uvic29_amd.tracer import TracerModel
+    oc = synthetic.make_ocean(cfg, 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    g = np.load(GOLD / f"step_{cfg}_14x14x6.npz")
+    m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+    m.set_exact(True)
+    m.load_ocean(oc, to, so, c)
+    m.set_mobi(oc)
+    m.isopyc(); m.tracer()
+    got = m.download("t_taup1")
+    for n, name in enumerate(oc.cfg.tracers):
+        a, b = got[:, :, 1:13, n], g["t_taup1"][:, :, 1:13, n]
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (name, np.abs(a - b).max(), np.abs(b).max())
+    assert np.array_equal(got[:, :, 1:13, :2], g["t_taup1"][:, :, 1:13, :2])
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", SETS)
+def test_gpu_time_loop_of_the_other_option_sets_lookahead_equals_inline(cfg):
+    """Ten steps of the production loop (sources one step ahead on the side streams, a forward step inside) against the
+    same steps with everything in line: the look-ahead machinery does not care which MOBI kernel runs."""
+    from uvic29_amd.tracer import TracerModel, TimeLoop
+    oc = synthetic.make_ocean(cfg, 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    out = {}
+    for how in ("ahead", "inline"):
+        m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
+        m.load_ocean(oc, to, so, c)
+        m.set_mobi(oc)
+        loop = TimeLoop(m, oc.params.dtts, 4, segment=0 if how == "ahead" else 1)
+        for _ in range(10):
+            loop.step()
+        m.sync()
+        out[how] = m.download("t_tau")
+        m.close()
+    assert np.isfinite(out["ahead"]).all() and np.array_equal(out["ahead"], out["inline"])

@@ -51,6 +51,7 @@ struct mobi_step {
 // device view of the MOBI inputs
 struct mobi_dev {
   const uvic_mobi_params *P;   // device copy
+  const uvic_mobi_options *O;  // device copy; null: option set C (the kernels of this file)
   const double *tlat, *dnswr, *aice, *hice, *hsno, *sg_bathy, *fe_atmdep, *fe_hydr;
   double pi, radian, relyr, co2ccn;
   // work planes of one MOBI pass (one set per stream that may run it):
@@ -1090,12 +1091,13 @@ UVIC_DEV void mobi_post_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k,
 struct mobi_store {
   void *params;
   double *f[8];
+  void *opts;
   double *work, *work_side[2];  // work planes, one set per stream: the two side streams work ahead in turn
 };
 static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp, const uvic_mobi_forcing *hf, mobi_dev *dev,
-                            mobi_store *st, hipStream_t stream, std::string &err) {
+                            mobi_store *st, hipStream_t stream, std::string &err, const uvic_mobi_options *ho = nullptr) {
   if (hp->km != km) { err = "uvic_gpu_set_mobi: params.km differs from the model's km"; return 2; }
-  {
+  if (!ho) {
     const int32_t want[MI::count] = {MI::po4, MI::phyt, MI::phyt_phos, MI::zoop, MI::detr, MI::detr_phos, MI::dic, MI::dic13,
                                      MI::phytc13, MI::zoopc13, MI::detrc13, MI::doc13, MI::diazc13, MI::dop, MI::no3, MI::don,
                                      MI::diaz, MI::din15, MI::don15, MI::phytn15, MI::zoopn15, MI::detrn15, MI::diazn15,
@@ -1129,6 +1131,12 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
   }
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
   dev->P = (const uvic_mobi_params *)st->params;
+  dev->O = nullptr;
+  if (ho) {   // another option set: the general column kernel reads the flags and the extra parameters from here
+    if (!st->opts && (e = hipMalloc(&st->opts, sizeof(uvic_mobi_options))) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    if ((e = hipMemcpy(st->opts, ho, sizeof(uvic_mobi_options), hipMemcpyHostToDevice)) != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    dev->O = (const uvic_mobi_options *)st->opts;
+  }
   dev->tlat = st->f[0]; dev->dnswr = st->f[1]; dev->aice = st->f[2]; dev->hice = st->f[3]; dev->hsno = st->f[4];
   dev->sg_bathy = st->f[5]; dev->fe_atmdep = st->f[6]; dev->fe_hydr = st->f[7];
   mobi_set_work(dev, st->work, imt, jmt, km);

@@ -24,6 +24,7 @@
 #include "kernels_fct.hpp"
 #include "kernels_isopyc.hpp"
 #include "kernels_mobi.hpp"
+#include "kernels_mobi_gen.hpp"
 #include "uvic_ctx.h"
 
 using namespace uvic;
@@ -489,6 +490,13 @@ __global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c,
   }
 #endif
 }
+// any other option set (kernels_mobi_gen.hpp): one thread per ocean column, the reference's three loops
+__global__ void __launch_bounds__(64) k_mobi_gen(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= w.count) return;
+  WET_DECODE(w, gid);
+  mobig_column(c, m, i, j);
+}
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= w.count) return;
@@ -729,7 +737,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 3; }
+extern "C" int uvic_gpu_abi_version(void) { return 4; }   // 4: uvic_gpu_set_mobi_opt (MOBI option sets other than C)
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -967,6 +975,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
     (void)hipFree(h->mobi_st.work);
+    (void)hipFree(h->mobi_st.opts);
     for (int q = 0; q < 2; ++q) (void)hipFree(h->mobi_st.work_side[q]);
     for (int q = 0; q < 8; ++q) (void)hipFree(h->mobi_st.f[q]);
   }
@@ -1725,6 +1734,12 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
   if (int rc = src_clean(h, (void *)c.src, st)) return rc;
   mark_on(h, "begin", sid);
   const unsigned cells = (unsigned)(((long long)w.count * c.km + 127) / 128), cols = (unsigned)((w.count + 63) / 64);
+  if (m.O) {   // an option set other than C: the general column kernel does all of it
+    if (w.count > 0) hipLaunchKernelGGL(k_mobi_gen, dim3(cols), dim3(64), 0, st, c, m, w);
+    mark_on(h, "mobi_gen", sid);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (w.count > 0) hipLaunchKernelGGL(k_mobi_pre, dim3(2 * cells), dim3(128), 0, st, c, m, w);   // two threads per cell
   mark_on(h, "mobi_pre", sid);
   if (w.count > 0) {
@@ -2204,6 +2219,41 @@ extern "C" int uvic_gpu_set_mobi(uvic_gpu *h, const uvic_mobi_params *p, const u
   if (p->dtnpzd <= 0.0) return fail_msg("uvic_gpu_set_mobi: dtnpzd must be positive");
   HIPCHK(hipSetDevice(h->device));
   int rc = mobi_bind(h->d.imt, h->d.jmt, h->d.km, p, f, &h->mobi, &h->mobi_st, h->stream, g_err);
+  if (rc) return rc;
+  h->mobi_dtnpzd = p->dtnpzd;
+  h->have_mobi = true;
+  return 0;
+}
+extern "C" int uvic_gpu_set_mobi_opt(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_options *o, const uvic_mobi_forcing *f) {
+  if (!h || !p || !o || !f) return fail_msg("uvic_gpu_set_mobi_opt: null argument");
+  static const bool force_gen = getenv("UVIC_MOBI_GENERIC") && atoi(getenv("UVIC_MOBI_GENERIC")) != 0;   // cross-check only
+  if (o->n15 && o->c13 && !o->caco3 && !o->silicon && !force_gen) return uvic_gpu_set_mobi(h, p, f);   // option set C: its own kernels
+  if (p->nsrc != h->d.nsrc || p->ntnpzd != h->d.ntnpzd) return fail_msg("uvic_gpu_set_mobi_opt: nsrc/ntnpzd differ from uvic_gpu_create");
+  if (p->dtnpzd <= 0.0) return fail_msg("uvic_gpu_set_mobi_opt: dtnpzd must be positive");
+  if (p->ntnpzd > UV_MOBI_MAXT) return fail_msg("uvic_gpu_set_mobi_opt: ntnpzd > 40");
+  // what the general kernel indexes with must be there: every pool of the set has a column position, a tracer and a slot
+  static const int always[] = {X_po4, X_phyt, X_phyt_phos, X_zoop, X_detr, X_detr_phos, X_dic, X_dop, X_no3, X_don, X_diaz, X_dfe, X_detrfe};
+  static const int n15s[] = {X_din15, X_don15, X_phytn15, X_zoopn15, X_detrn15, X_diazn15};
+  static const int c13s[] = {X_dic13, X_phytc13, X_zoopc13, X_detrc13, X_doc13, X_diazc13};
+  std::vector<int> need(always, always + sizeof always / sizeof *always);
+  if (o->n15) need.insert(need.end(), n15s, n15s + 6);
+  if (o->c13) need.insert(need.end(), c13s, c13s + 6);
+  if (o->caco3) need.push_back(X_caco3);
+  if (o->silicon) { need.push_back(X_diat); need.push_back(X_sil); need.push_back(X_opl); }
+  if (o->silicon && o->n15) need.push_back(X_diatn15);
+  if (o->silicon && o->c13) need.push_back(X_diatc13);
+  if (o->caco3 && o->c13) need.push_back(X_caco3c13);
+  for (int x : need) {
+    const int m = o->im[x], s = o->is[x];
+    if (m < 1 || m > p->ntnpzd || s < 1 || s > p->nsrc) return fail_msg("uvic_gpu_set_mobi_opt: a MOBI tracer of this option set has no column position or source slot");
+    if (p->tracer_of_mobi[m - 1] < 1 || p->tracer_of_mobi[m - 1] > h->d.nt) return fail_msg("uvic_gpu_set_mobi_opt: tracer_of_mobi out of range");
+  }
+  if (o->is_alk < 1 || o->is_alk > p->nsrc || o->is_o2 < 1 || o->is_o2 > p->nsrc || o->is_c14 < 0 || o->is_c14 > p->nsrc)
+    return fail_msg("uvic_gpu_set_mobi_opt: source slot of alk, o2 or c14 out of range");
+  if (p->itemp < 1 || p->isalt < 1 || p->idic < 1 || p->ialk < 1 || p->io2 < 1 || (o->is_c14 > 0 && p->ic14 < 1))
+    return fail_msg("uvic_gpu_set_mobi_opt: temp, salt, dic, alk and o2 are needed (without O_mobi_alk the reference itself is undefined: ialk = 0)");
+  HIPCHK(hipSetDevice(h->device));
+  int rc = mobi_bind(h->d.imt, h->d.jmt, h->d.km, p, f, &h->mobi, &h->mobi_st, h->stream, g_err, o);
   if (rc) return rc;
   h->mobi_dtnpzd = p->dtnpzd;
   h->have_mobi = true;

@@ -41,6 +41,56 @@ class MobiParams(ctypes.Structure):
 _DP = ctypes.POINTER(ctypes.c_double)
 
 
+# every MOBI column tracer of every option set, in the order of uvic_mobi_options.im / .is (include/uvic_gpu.h)
+X = ("po4 phyt phyt_phos zoop detr detr_phos dic dic13 phytc13 zoopc13 detrc13 doc13 diazc13 "
+     "dop no3 don diaz din15 don15 phytn15 zoopn15 detrn15 diazn15 dfe detrfe "
+     "caco3 diat sil opl diatn15 diatc13 caco3c13").split()
+OPT_SCALARS = ("kc_c dissk0 caprmax kcapr abiodiat kfemin_Diat kfemax_Diat knmin_Diat knmax_Diat pmax_Diat "
+               "zprefDiat nu_diat nudt0 opl_disk0").split()
+
+
+class MobiOptions(ctypes.Structure):
+    _fields_ = ([(n, ctypes.c_int32) for n in ("n15", "c13", "caco3", "silicon")]
+                + [("im", ctypes.c_int32 * len(X)), ("is_", ctypes.c_int32 * len(X))]
+                + [(n, ctypes.c_int32) for n in ("is_alk", "is_o2", "is_c14", "pad_")]
+                + [(n, ctypes.c_double) for n in OPT_SCALARS]
+                + [("wc", ctypes.c_double * 64), ("wo", ctypes.c_double * 64)])
+
+
+def supported(cfg) -> bool:
+    """Option sets the device serves: everything the reference can build with a defined result --
+    O_mobi_alk and O_mobi_nitrogen on; set E is out (the reference reads t(..,ialk=0,..) there)."""
+    o = cfg.options
+    return all(x in o for x in ("mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen"))
+
+
+def is_set_c(cfg) -> bool:
+    o = cfg.options
+    return "mobi_nitrogen_15" in o and "carbon_13" in o and "mobi_caco3" not in o and "mobi_silicon" not in o
+
+
+def make_options(cfg, grid, prm: dict) -> MobiOptions:
+    o = cfg.options
+    O = MobiOptions()
+    O.n15, O.c13 = int("mobi_nitrogen_15" in o), int("carbon_13" in o)
+    O.caco3, O.silicon = int("mobi_caco3" in o), int("mobi_silicon" in o)
+    slot = lambda n: cfg.sources.index(n) + 1 if n in cfg.sources else 0  # noqa: E731
+    for q, n in enumerate(X):
+        O.im[q], O.is_[q] = cfg.imobi(n), slot(n)
+    O.is_alk, O.is_o2, O.is_c14 = slot("alk"), slot("o2"), slot("c14")
+    names = (OPT_SCALARS[:4] if O.caco3 else []) + (OPT_SCALARS[4:] if O.silicon else [])
+    for n in names:
+        setattr(O, n, float(prm[n.lower()]))
+    for n, on in (("wc", O.caco3), ("wo", O.silicon)):
+        if on:
+            a = np.asarray(prm[n], dtype=np.float64)
+            if a.size != grid.km:
+                raise ValueError(f"MOBI array {n} has {a.size} levels, model has {grid.km}")
+            for k in range(grid.km):
+                getattr(O, n)[k] = a[k]
+    return O
+
+
 class MobiForcing(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_double) for n in ("pi", "radian", "relyr", "co2ccn")]
                 + [(n, _DP) for n in ("tlat", "dnswr", "aice", "hice", "hsno", "sg_bathy", "fe_atmdep", "fe_hydr")])
@@ -54,14 +104,14 @@ def load_table(cfg_name: str, km: int) -> dict:
 
 
 def make_params(cfg, grid, prm: dict) -> MobiParams:
-    if cfg.name != "c30":
-        raise NotImplementedError("the MOBI column kernel is written for option set C (c30); "
-                                  "other option sets compile different equations (SURVEY.md §2c)")
+    if not supported(cfg):
+        raise NotImplementedError(f"option set {cfg.name}: the device serves the sets with O_mobi_alk and O_mobi_nitrogen "
+                                  "(C, F, the shipped nt=37 set); set E is undefined in the reference itself (ialk = 0)")
     P = MobiParams()
     km = grid.km
     P.km, P.ntnpzd, P.nsrc = km, cfg.ntnpzd, cfg.nsrc
     for n in _IDX:
-        setattr(P.im, n, cfg.imobi(n))
+        setattr(P.im, n, cfg.imobi(n) if n in cfg.mobi else 0)
         setattr(P.is_, n, cfg.sources.index(n) + 1 if n in cfg.sources else 0)
     for m, name in enumerate(cfg.mobi):
         P.tracer_of_mobi[m] = cfg.index(name)

@@ -108,7 +108,11 @@ class TracerModel:
         prm = table if table is not None else pm.load_table(ocean.cfg.name, ocean.grid.km)
         P = pm.make_params(ocean.cfg, ocean.grid, prm)
         F = pm.Forcing(ocean)
-        check(self.lib.uvic_gpu_set_mobi(self.h, ctypes.byref(P), ctypes.byref(F.c)), "set_mobi")
+        if pm.is_set_c(ocean.cfg) and os.environ.get("UVIC_MOBI_GENERIC", "0") == "0":
+            check(self.lib.uvic_gpu_set_mobi(self.h, ctypes.byref(P), ctypes.byref(F.c)), "set_mobi")
+        else:   # another option set of SURVEY.md §2c: flags and the extra parameters travel in uvic_mobi_options
+            O = pm.make_options(ocean.cfg, ocean.grid, prm)
+            check(self.lib.uvic_gpu_set_mobi_opt(self.h, ctypes.byref(P), ctypes.byref(O), ctypes.byref(F.c)), "set_mobi_opt")
         self.has_mobi = True
 
     def mobi(self):
