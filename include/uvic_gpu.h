@@ -151,6 +151,13 @@ typedef struct uvic_mobi_options {
  * uvic_gpu_set_mobi; otherwise the sources come from the general column kernel (csrc/kernels_mobi_gen.hpp). */
 int uvic_gpu_set_mobi_opt(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_options *o, const uvic_mobi_forcing *f);
 
+/* the same for callers without C structs (Fortran), in two calls: this one names the option set and is followed by
+ * uvic_gpu_set_mobi_flat, which then goes through uvic_gpu_set_mobi_opt.  flags = n15, c13, caco3, silicon;
+ * im, is: UVIC_MOBI_NX entries each in the order above; isx = is_alk, is_o2, is_c14; oscal = the 14 doubles of
+ * uvic_mobi_options from kc_c to opl_disk0; wc, wo: km values each (ignored without the option) */
+int uvic_gpu_mobi_options_flat(uvic_gpu *h, const int32_t *flags, const int32_t *im, const int32_t *is, const int32_t *isx,
+                               const double *oscal, const double *wc, const double *wo, int km);
+
 /* upload MOBI parameters and forcing; after this uvic_gpu_tracer computes the
  * source terms itself (replaces the column loop of u09/mom/tracer.F:355-545 with
  * mobi_driver/mobi_src/co2calc_SWS and the 14C source, tracer.F:853-867) instead

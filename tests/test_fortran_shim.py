@@ -26,7 +26,8 @@ PROD_TOL = 1e-11     # production path through the overlay, relative to max|fiel
 
 
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("c30", (102, 102, 19))])
+@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("c30", (102, 102, 19)),
+                                      ("f18", (14, 14, 6)), ("s37", (14, 14, 6))])   # (f18, s37: SURVEY.md §2c sets F and run/mk.in's)
 def test_overlay_tracer_matches_reference_tracer(cfg, dims, exact, monkeypatch):
     _arith(monkeypatch, exact)
     if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
@@ -88,7 +89,7 @@ def _segment_switches(r, it, nseg):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6))])
+@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("s37", (14, 14, 6))])
 def test_resident_overlay_over_several_steps(cfg, dims, exact, monkeypatch):
     """UVIC_RESIDENT=1: t stays on the device and rotates there (what loadmw/putmw and the
     ramdrive do on the host); per step only T and S come back, the call returns as soon as they have, the sources and

@@ -42,7 +42,7 @@ EXPORTS = [
     "uvic_gpu_download", "uvic_gpu_upload_rows", "uvic_gpu_download_rows", "uvic_gpu_field_elems",
     "uvic_gpu_field_devptr", "uvic_gpu_stream", "uvic_gpu_set_params", "uvic_gpu_set_shard", "uvic_gpu_isopyc",
     "uvic_gpu_transport", "uvic_gpu_convect", "uvic_gpu_tracer", "uvic_gpu_rotate", "uvic_gpu_sync",
-    "uvic_gpu_profile", "uvic_gpu_profile_live", "uvic_gpu_profile_read", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_set_mobi_opt", "uvic_gpu_set_mobi_flat", "uvic_gpu_mobi", "uvic_gpu_prefetch_sources",
+    "uvic_gpu_profile", "uvic_gpu_profile_live", "uvic_gpu_profile_read", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_set_mobi_opt", "uvic_gpu_mobi_options_flat", "uvic_gpu_set_mobi_flat", "uvic_gpu_mobi", "uvic_gpu_prefetch_sources",
     "uvic_gpu_set_mixing", "uvic_gpu_set_exact", "uvic_gpu_adv_vel", "uvic_gpu_set_vmix_params", "uvic_gpu_vmixc", "uvic_gpu_set_filter", "uvic_gpu_prefetch_isopyc",
     "uvic_gpu_step_lookahead", "uvic_gpu_download_level", "uvic_gpu_set_mobi_step", "uvic_gpu_pin_host", "uvic_gpu_halo_elems", "uvic_gpu_halo_buffer", "uvic_gpu_halo_pack", "uvic_gpu_halo_unpack",
     "uvic_gpu_step_lookahead_at", "uvic_gpu_prefetch_sources_at", "uvic_gpu_set_host_sync", "uvic_gpu_sbc_config",

@@ -635,6 +635,8 @@ struct uvic_gpu {
   uvic_ctx ctx;
   mobi_dev mobi;
   mobi_store mobi_st;
+  uvic_mobi_options opt_staged;   // uvic_gpu_mobi_options_flat: taken by the next uvic_gpu_set_mobi_flat
+  bool have_opt_staged;
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
   // polar filter (uvic_gpu_set_filter): strips and operators, built once
@@ -794,6 +796,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   for (int q = 0; q < 4; ++q) h->halo[q] = nullptr;
   h->wet_row_start.assign((size_t)dims->jmt + 2, 0);
   memset(&h->mobi_st, 0, sizeof h->mobi_st);
+  memset(&h->opt_staged, 0, sizeof h->opt_staged);
+  h->have_opt_staged = false;
   memset(&h->mobi, 0, sizeof h->mobi);
   // The main stream carries the bulk passes (pass A and B of the nt-2 tracers): their waves fill every SIMD for most of
   // a step, and the short kernels of the latency chains on the side streams (isopyc, MOBI pre/post, the T,S passes) then
@@ -2282,7 +2286,23 @@ extern "C" int uvic_gpu_set_mobi_flat(uvic_gpu *h, int km, int ntnpzd, int nsrc,
   F.pi = fsc[0]; F.radian = fsc[1]; F.relyr = fsc[2]; F.co2ccn = fsc[3];
   F.tlat = tlat; F.dnswr = dnswr; F.aice = aice; F.hice = hice; F.hsno = hsno;
   F.sg_bathy = sg_bathy; F.fe_atmdep = fe_atmdep; F.fe_hydr = fe_hydr;
+  if (h && h->have_opt_staged) return uvic_gpu_set_mobi_opt(h, &P, &h->opt_staged, &F);
   return uvic_gpu_set_mobi(h, &P, &F);
+}
+extern "C" int uvic_gpu_mobi_options_flat(uvic_gpu *h, const int32_t *flags, const int32_t *im, const int32_t *is, const int32_t *isx,
+                                          const double *oscal, const double *wc, const double *wo, int km) {
+  if (!h || !flags || !im || !is || !isx || !oscal) return fail_msg("uvic_gpu_mobi_options_flat: null argument");
+  if (km < 1 || km > 64) return fail_msg("uvic_gpu_mobi_options_flat: km out of range");
+  uvic_mobi_options &O = h->opt_staged;
+  memset(&O, 0, sizeof O);
+  O.n15 = flags[0]; O.c13 = flags[1]; O.caco3 = flags[2]; O.silicon = flags[3];
+  for (int q = 0; q < UVIC_MOBI_NX; ++q) { O.im[q] = im[q]; O.is[q] = is[q]; }
+  O.is_alk = isx[0]; O.is_o2 = isx[1]; O.is_c14 = isx[2];
+  memcpy(&O.kc_c, oscal, (size_t)((&O.opl_disk0 - &O.kc_c) + 1) * sizeof(double));
+  if (O.caco3) { if (!wc) return fail_msg("uvic_gpu_mobi_options_flat: wc missing"); memcpy(O.wc, wc, (size_t)km * 8); }
+  if (O.silicon) { if (!wo) return fail_msg("uvic_gpu_mobi_options_flat: wo missing"); memcpy(O.wo, wo, (size_t)km * 8); }
+  h->have_opt_staged = true;
+  return 0;
 }
 // the part of the MOBI forcing that changes from step to step (tracer.F:355-390 reads dnswr, aice, hice, hsno of the
 // current step; relyr selects the month of the dust field and the declination; co2ccn the atmospheric CO2)

@@ -104,6 +104,15 @@
           real(c_double) :: sgb(*), fe_atmdep(*), fe_hydr(*)
           integer(c_int) :: rc
         end function
+        function uvic_gpu_mobi_options_flat(h, flags, im, is, isx, oscal, wc, wo, km)                              &
+     &      bind(C,name='uvic_gpu_mobi_options_flat') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int32_t) :: flags(*), im(*), is(*), isx(*)
+          real(c_double) :: oscal(*), wc(*), wo(*)
+          integer(c_int), value :: km
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_set_filter(h, pi, jfrst, jft0, jft1, jft2, lsegf) bind(C,name='uvic_gpu_set_filter') result(rc)
           import
           type(c_ptr), value :: h
