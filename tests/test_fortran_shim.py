@@ -128,7 +128,8 @@ def test_resident_overlay_over_several_steps(cfg, dims, exact, monkeypatch):
         assert _same(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2], exact), it
         if it % 3 == 0:     # ... and at a segment's last step the surface averages for the atmosphere
             for n, k in slots.items():
-                assert _same(shim.v["sbc"][1:-1, 1:jmt - 1, k - 1], ref.v["sbc"][1:-1, 1:jmt - 1, k - 1], exact), (it, n)
+                # (T, S: bit for bit in the exact arithmetic; dic, o2, alk carry MOBI sources, whose device exp/log differ from libm)
+                assert _same(shim.v["sbc"][1:-1, 1:jmt - 1, k - 1], ref.v["sbc"][1:-1, 1:jmt - 1, k - 1], exact and n < 2), (it, n)
         ref.rotate(); shim.rotate()
     if oc.cfg.nt > 2:   # resident for real: below the surface the host copy of the other tracers is stale until the flush
         assert not np.array_equal(shim.v["t"][:, 1:, 1:jmt - 1, 2:, 1], ref.v["t"][:, 1:, 1:jmt - 1, 2:, 1])

@@ -4,7 +4,8 @@
 // Always on, as in every set the reference can build: O_mobi_o2, O_mobi_iron, O_carbon, O_mobi_alk, O_mobi_nitrogen.
 // One thread per ocean column walks mobi_driver's three loops as the reference does (mobi.F:519-1482, mobi_src
 // :1485-3313, the caller's part tracer.F:355-545, 853-867), expression by expression in the reference's order, no
-// contraction: the results differ from the CPU only through the device's exp/log/pow/tanh.  Option set C keeps its own
+// reassociation: the results differ from the CPU through the device's exp/log/tanh, fused mul+add pairs and powers taken
+// as exp(y log x) (UV_POWP, as in the kernels of set C) -- 3e-12 of the oracle at most, tested at 1e-11.  Option set C keeps its own
 // three-pass, four-wave-team kernels (kernels_mobi.hpp); this form is the general one, not the fast one: the flags are
 // wave-uniform branches, the column state lives in local memory.
 // Set E (no O_mobi_alk) is not served: the reference itself reads t(i,:,j,ialk,taum1) with ialk = 0 there (tracer.F:491).
@@ -22,6 +23,11 @@ typedef const uvic_mobi_options *mobi_options_cp;
 #endif
 
 namespace uvic {
+
+// tolerance-tested like the kernels of set C (1e-11 on the sources): mul+add pairs may fuse on the device
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UV_NO_CONTRACT)
+#pragma clang fp contract(fast)
+#endif
 
 // positions in uvic_mobi_options::im / ::is (include/uvic_gpu.h)
 enum {
@@ -49,15 +55,21 @@ typedef struct {
 } gsrc_out;
 
 /* mobi_src, mobi.F:1485-3313 */
-UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St, double capr, double *bioin, double gl, double bct, double impo, double dzt,
+// TN15 .. TSIL: 1/0 = the option fixed at compile time (the sets of SURVEY.md §2c are instantiated so: dead branches and
+// their state vanish), -1 = read from the flags at run time (any other combination)
+template <int TN15, int TC13, int TCACO3, int TSIL>
+UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St, double capr, double (&bioin)[X_COUNT], double gl, double bct, double impo, double dzt,
                          double impo_phos, double dayfrac, double wwd, double nud, double impocaco3, double wwc, double dissk1,
-                         double impoopl, double wwo, double opl_disk1, double nudop, double nudon, double *bioout, double bctz,
+                         double impoopl, double wwo, double opl_disk1, double nudop, double nudon, double (&bioout)[X_COUNT], double bctz,
                          double rn15impo, double rc13impo, double ac13b, double rcaco3c13impo, double impofe, double o2,
                          double aou, gsrc_out *out) {
   const int *I = O->im;
-  const int N15 = O->n15, C13 = O->c13, CACO3 = O->caco3, SIL = O->silicon;
-#define BIN(x) bioin[I[x] - 1]
-#define BGET(x) (I[x] > 0 ? bioin[I[x] - 1] : 0.0)
+  const int N15 = TN15 < 0 ? O->n15 : TN15, C13 = TC13 < 0 ? O->c13 : TC13, CACO3 = TCACO3 < 0 ? O->caco3 : TCACO3;
+  const int SIL = TSIL < 0 ? O->silicon : TSIL;
+/* the pools travel indexed by their identity (X_*), not by their position in tnpzd: every index is a compile-time
+   constant and the vectors live in registers; a pool the set does not have arrives as 0 */
+#define BIN(x) bioin[x]
+#define BGET(x) bioin[x]
   double biopo4 = BIN(X_po4), biophyt = BIN(X_phyt), biophyt_phos = BIN(X_phyt_phos), biozoop = BIN(X_zoop);
   double biodetr = BIN(X_detr), biodetr_phos = BIN(X_detr_phos);
   double ptn_P = biophyt_phos / biophyt;
@@ -98,7 +110,7 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
   if (CACO3) caco3flag = g_flag01(biocaco3 - UV_TRCMIN);
   if (SIL) { diatflag = g_flag01(biodiat - UV_TRCMIN); silflag = g_flag01(biosil - UV_TRCMIN); oplflag = g_flag01(bioopl - UV_TRCMIN); }
   /* clamp the caller's column and the working copies, mobi.F:1894-1960 */
-  for (int m = 0; m < P->ntnpzd; ++m) bioin[m] = g_max(bioin[m], UV_TRCMIN);
+  _Pragma("unroll") for (int x = 0; x < X_COUNT; ++x) bioin[x] = g_max(bioin[x], UV_TRCMIN);
   biopo4 = g_max(biopo4, UV_TRCMIN); biophyt = g_max(biophyt, UV_TRCMIN); biozoop = g_max(biozoop, UV_TRCMIN);
   biodetr = g_max(biodetr, UV_TRCMIN); biophyt_phos = g_max(biophyt_phos, UV_TRCMIN); biodetr_phos = g_max(biodetr_phos, UV_TRCMIN);
   biodic = g_max(biodic, UV_TRCMIN); biono3 = g_max(biono3, UV_TRCMIN); biodop = g_max(biodop, UV_TRCMIN);
@@ -263,10 +275,10 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
     double remife = nud * bct * biodetrfe;
     /* iron scavenging, mobi.F:2313-2342 */
     const double o2flag = tanh(g_max(o2, 0.));
-    const double ligand = g_max(pow(g_max(aou, 40.), 0.8) / 66. + pow(biodon, 0.8) / 4.8, 0.5) / 1000.;
+    const double ligand = g_max(UV_POWP(g_max(aou, 40.), 0.8) / 66. + UV_POWP(biodon, 0.8) / 4.8, 0.5) / 1000.;
     const double fepa = (1.0 + P->kfeleq * (ligand - biodfe)) * o2flag;
     const double feprime = ((-fepa + sqrt(fepa * fepa + 4.0 * P->kfeleq * biodfe)) / (2.0 * P->kfeleq)) * o2flag;
-    double feorgads = (P->kfeorg * (pow((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
+    double feorgads = (P->kfeorg * (UV_POWP((biodetr * detrflag) * P->mc * redctn, 0.58)) * feprime) * o2flag;
     double fecol = P->kfecol * (feprime * feprime) * o2flag;
     double expofe = wwd * biodetrfe;
     /* negative prevention, mobi.F:2343-2445 */
@@ -590,8 +602,8 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
   }
   (void)dic13flag; (void)doc13flag; (void)phytc13flag; (void)zoopc13flag; (void)detrc13flag; (void)diazc13flag;
   (void)diatn15flag; (void)diatc13flag; (void)caco3c13flag;
-  for (int m = 0; m < P->ntnpzd; ++m) bioout[m] = 0.0;
-#define BOUT(x, v) do { if (I[x] > 0) bioout[I[x] - 1] = (v) - bioin[I[x] - 1]; } while (0)
+  _Pragma("unroll") for (int x = 0; x < X_COUNT; ++x) bioout[x] = 0.0;
+#define BOUT(x, v) do { if (I[x] > 0) bioout[x] = (v) - bioin[x]; } while (0)
   BOUT(X_po4, biopo4); BOUT(X_phyt, biophyt); BOUT(X_phyt_phos, biophyt_phos); BOUT(X_zoop, biozoop);
   BOUT(X_detr, biodetr); BOUT(X_detr_phos, biodetr_phos); BOUT(X_dic, biodic); BOUT(X_dop, biodop);
   BOUT(X_no3, biono3); BOUT(X_don, biodon); BOUT(X_diaz, biodiaz); BOUT(X_din15, biodin15);
@@ -609,6 +621,7 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
 }
 
 /* mobi_driver (mobi.F:519-1482) with the caller's column set-up, iron inputs and 14C (tracer.F:355-545, 853-867) */
+template <int TN15, int TC13, int TCACO3, int TSIL>
 UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
   UV_DIMS(c);
   mobi_params_cp P = UV_CONST_AS(M.P);
@@ -626,7 +639,8 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
   dayfrac = g_max(1e-12, acos(g_max(-1., dayfrac)) / M.pi);
   double swr = P->tap * M.dnswr[ij] * 1e-3 * (1. + ai * (exp(-P->ki * (hi + hs)) - 1.));
   const int *I = O->im, *S = O->is;
-  const int N15 = O->n15, C13 = O->c13, CACO3 = O->caco3, SIL = O->silicon;
+  const int N15 = TN15 < 0 ? O->n15 : TN15, C13 = TC13 < 0 ? O->c13 : TC13, CACO3 = TCACO3 < 0 ? O->caco3 : TCACO3;
+  const int SIL = TSIL < 0 ? O->silicon : TSIL;
 /* tnpzd(k, x): the column is not copied -- a level is clamped (mobi.F:1894, through mobi_src's copy-out) before anything
    reads it except the light terms, which clamp themselves or (caco3in) want the raw value: TNR */
 #define TIN(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
@@ -639,13 +653,9 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
   double rcaco3c13impo = 0.0, rcaco3c13expo = 0.0, caco3in = 0.0, impocaco3 = 0.0, expocaco3 = 0.0, dissk1 = 0.0;
   double expoopl = 0.0, impoopl = 0.0, opl_disk1 = 0.0;
   double capr = P->capr;
-  double snpzd[UV_MOBI_MAXT], bioin[UV_MOBI_MAXT];
-  double rcalpro[64], rdissl[64], rexpocaco3[64], rexpoopl[64];
-  double bdeni[64], nfix[64], dic_npzd_sms[64], rtdic13[64], rtcaco3c13[64];
+  double snpzd[X_COUNT], bioin[X_COUNT];
   for (int s = 1; s <= P->nsrc; ++s)
     for (int k = 1; k <= km; ++k) SRC(k, s) = 0.0;
-  for (int k = 0; k < km; ++k)
-    rcalpro[k] = rdissl[k] = rexpocaco3[k] = rexpoopl[k] = bdeni[k] = nfix[k] = dic_npzd_sms[k] = rtdic13[k] = rtcaco3c13[k] = 0.0;
   const double redctn = P->redctn;
   for (int k = 1; k <= kmx; ++k) {
     const double t_in = TIN(k, P->itemp), o2_in = TIN(k, P->io2) * 1000., s_in = 1.e3 * TIN(k, P->isalt) + 35.0;
@@ -659,6 +669,8 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
       o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
       aou_in = o2sat - o2_in;
     }
+    double rcalpro_k = 0.0, rdissl_k = 0.0, rexpocaco3_k = 0.0, rexpoopl_k = 0.0, bdeni_k = 0.0, nfix_k = 0.0;
+    double dic_npzd_sms_k = 0.0, rtdic13_k = 0.0, rtcaco3c13_k = 0.0;
     if (N15) rn15impo = rn15expo;
     double ac13b = 0.0;
     if (C13 || CACO3) {
@@ -691,15 +703,15 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     impo = expo * P->dztr[k - 1];
     impo_phos = expo_phos * P->dztr[k - 1];
     impofe = expofe * P->dztr[k - 1];
-    const double bct = pow(P->bbio, P->cbio * t_in);
+    const double bct = UV_POWP(P->bbio, P->cbio * t_in);
     if (SIL) impoopl = expoopl * P->dztr[k - 1];
-    const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * pow(P->bbio, P->cbio * t_in);
+    const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * UV_POWP(P->bbio, P->cbio * t_in);
     const double nud = P->nud0 * (0.6 + 0.4 * tanh(0.22 * g_max(o2_in, 0.)));
     const double nudon = P->nudon0, nudop = P->nudop0;
-    /* tnpzd(k,:) is passed as a strided section: copy in, clamp, copy out */
-    for (int m = 1; m <= P->ntnpzd; ++m) bioin[m - 1] = c.t_taum1[X3(i, k, j) + (size_t)(P->tracer_of_mobi[m - 1] - 1) * N3];
+    /* tnpzd(k,:) is passed as a strided section: copy in, clamp, copy out -- bioin[] holds the clamped level from here on */
+    _Pragma("unroll") for (int x = 0; x < X_COUNT; ++x) bioin[x] = I[x] > 0 ? TNR(k, x) : 0.0;
     gsrc_out so;
-    mobig_src(P, O, St, capr, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, impocaco3, O->wc[k - 1],
+    mobig_src<TN15, TC13, TCACO3, TSIL>(P, O, St, capr, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, impocaco3, O->wc[k - 1],
                  dissk1, impoopl, O->wo[k - 1], opl_disk1, nudop, nudon, snpzd, bctz, rn15impo, rc13impo, ac13b, rcaco3c13impo,
                  impofe, o2_in, aou_in, &so);
     expo = so.expo; expo_phos = so.expo_phos; expofe = so.expofe;
@@ -708,13 +720,13 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     if (C13 && CACO3) rcaco3c13expo = so.rcaco3c13expo;
     if (CACO3) expocaco3 = so.expocaco3;
     if (SIL) expoopl = so.expoopl;
-    nfix[k - 1] = so.nfix;
-    for (int m = 0; m < P->ntnpzd; ++m) snpzd[m] = snpzd[m] * St.rdtts;
+    nfix_k = so.nfix;
+    _Pragma("unroll") for (int x = 0; x < X_COUNT; ++x) snpzd[x] = snpzd[x] * St.rdtts;
     expofe = expofe * St.rnbio;
     if (CACO3) expocaco3 = expocaco3 * St.rnbio;
     if (SIL) {
       expoopl = expoopl * St.rnbio;
-      rexpoopl[k - 1] = expoopl;
+      rexpoopl_k = expoopl;
     }
     expo = expo * St.rnbio;
     expo_phos = expo_phos * St.rnbio;
@@ -723,27 +735,27 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
       rc13expo = rc13expo * St.rnbio;
       if (CACO3) rcaco3c13expo = rcaco3c13expo * St.rnbio;
     }
-    rcalpro[k - 1] = so.calpro * St.rnbio;
+    rcalpro_k = so.calpro * St.rnbio;
     if (CACO3) {
-      rdissl[k - 1] = so.dissl * St.rnbio;
-      rexpocaco3[k - 1] = expocaco3;
+      rdissl_k = so.dissl * St.rnbio;
+      rexpocaco3_k = expocaco3;
     }
     const double sgb = M.sg_bathy[ij + NS * (k - 1)];
-#define SN(x) snpzd[I[x] - 1]
+#define SN(x) snpzd[x]
     /* benthic denitrification, mobi.F:1033-1085 */
-    const double no3flag = g_flag01(TN(k, X_no3) - UV_TRCMIN);
-    const double din15flag = N15 ? g_flag01(TN(k, X_din15) - UV_TRCMIN) : 1.;
-    const double lno3 = 0.5 * tanh(TN(k, X_no3) * 10 - 5.0);
-    double sg_bdeni = (0.06 + 0.19 * pow(0.99, g_max(o2_in, UV_TRCMIN) - g_max(TN(k, X_no3), UV_TRCMIN))) *
+    const double no3flag = g_flag01(bioin[X_no3] - UV_TRCMIN);
+    const double din15flag = N15 ? g_flag01(bioin[X_din15] - UV_TRCMIN) : 1.;
+    const double lno3 = 0.5 * tanh(bioin[X_no3] * 10 - 5.0);
+    double sg_bdeni = (0.06 + 0.19 * UV_POWP(0.99, g_max(o2_in, UV_TRCMIN) - g_max(bioin[X_no3], UV_TRCMIN))) *
                       g_max(expo * sgb, UV_TRCMIN) * redctn * 1.e3;
     sg_bdeni = g_min(sg_bdeni, sgb * expo);
     sg_bdeni = g_max(sg_bdeni, 0.);
     sg_bdeni = sg_bdeni * (0.5 + lno3) * no3flag * din15flag;
-    bdeni[k - 1] = sg_bdeni;
+    bdeni_k = sg_bdeni;
     SN(X_no3) = SN(X_no3) + sgb * expo - sg_bdeni;
     if (N15) {
       const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
-      double rno3 = g_max(TN(k, X_din15), r15min) / g_max(TN(k, X_no3) - TN(k, X_din15), r15min);
+      double rno3 = g_max(bioin[X_din15], r15min) / g_max(bioin[X_no3] - bioin[X_din15], r15min);
       rno3 = g_min(rno3, 2. * UV_RN15STD);
       rno3 = g_max(rno3, UV_RN15STD / 2.);
       const double eps_bdeni = P->eps_bdeni0 * exp(-2.5e-6 * (P->zt[k - 1]));
@@ -755,7 +767,7 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     const double oblinc = -1.26e-6 * coxdepth + 0.203;
     const double obexpc = -6.e-7 * coxdepth + 1.14;
     const double dztk = P->dzt[k - 1];
-    const double nburial = (oblinc * pow(expo * sgb * dztk / 100 * 86400. * 365. * redctn * 1000., obexpc)) /
+    const double nburial = (oblinc * UV_POWP(expo * sgb * dztk / 100 * 86400. * 365. * redctn * 1000., obexpc)) /
                            (86400. * 365. * dztk / 100 * redctn * 1000.);
     const double coxsed = expo * sgb - nburial;
     const double fesedmax = 85.;
@@ -771,25 +783,25 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     expo = expo - sgb * expo;
     expo_phos = expo_phos - sgb * expo_phos;
     /* scatter into the source slots, mobi.F:1149-1205 */
-    for (int x = 0; x < X_COUNT; ++x)
-      if (I[x] > 0 && S[x] > 0) SRC(k, S[x]) = snpzd[I[x] - 1];
+    _Pragma("unroll") for (int x = 0; x < X_COUNT; ++x)
+      if (I[x] > 0 && S[x] > 0) SRC(k, S[x]) = snpzd[x];
     /* DIC / alkalinity / 13C bookkeeping, mobi.F:1228-1266 */
-    dic_npzd_sms[k - 1] = SN(X_dic);
-    const double dprca = rcalpro[k - 1] * 1e-3;
+    dic_npzd_sms_k = SN(X_dic);
+    const double dprca = rcalpro_k * 1e-3;
     prca = prca + dprca * dztk;
     if (!CACO3) SX(k, X_dic) = SN(X_dic) - dprca;
     if (C13) {
       const double r13min = UV_TRCMIN * UV_RC13STD / (1 + UV_RC13STD);
-      double r = g_max(TN(k, X_dic13), r13min) / g_max(dic_in, UV_TRCMIN);
+      double r = g_max(bioin[X_dic13], r13min) / g_max(dic_in, UV_TRCMIN);
       r = g_min(r, 2. * UV_RC13STD / (1 + UV_RC13STD));
       r = g_max(r, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
-      rtdic13[k - 1] = r;
+      rtdic13_k = r;
       prca13 = prca13 + dprca * dztk * r;
       if (CACO3) {
-        double rc = g_max(TN(k, X_caco3c13), r13min) / g_max(TN(k, X_caco3), UV_TRCMIN);
+        double rc = g_max(bioin[X_caco3c13], r13min) / g_max(bioin[X_caco3], UV_TRCMIN);
         rc = g_min(rc, 2. * UV_RC13STD / (1 + UV_RC13STD));
         rc = g_max(rc, 0.5 * UV_RC13STD / (1 + UV_RC13STD));
-        rtcaco3c13[k - 1] = rc;
+        rtcaco3c13_k = rc;
       } else {
         SX(k, X_dic13) = SX(k, X_dic13) - r * dprca;
       }
@@ -806,60 +818,56 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     expofe = expofe * dztk;
     if (CACO3) expocaco3 = expocaco3 * dztk;
     if (SIL) expoopl = expoopl * dztk;
-  }
-  /* second pass: oxygen, water-column denitrification, 15N (mobi.F:1302-1365) */
-  for (int k = 1; k <= kmx; ++k) {
-    const double o2_in = TIN(k, P->io2) * 1000.;
-    const double fo2 = tanh(0.22 * g_max(o2_in, 0.));
-    const double so2 = dic_npzd_sms[k - 1] * P->redotc + nfix[k - 1] * St.rnbio * 1.25e-3;
-    const double no3flag = g_flag01(TN(k, X_no3) - UV_TRCMIN);
-    const double din15flag = N15 ? g_flag01(TN(k, X_din15) - UV_TRCMIN) : 1.;
-    const double lno3 = 0.5 * tanh(TN(k, X_no3) - 2.5);
-    double wcdeni = 800. * no3flag * so2 * (1.0 - fo2) * (0.5 + lno3);
-    if (N15) wcdeni = wcdeni * din15flag;
-    wcdeni = g_max(wcdeni, 0.);
-    SX(k, X_no3) = SX(k, X_no3) - wcdeni;
-    if (N15) {
-      double uno3 = wcdeni * twodt / TN(k, X_no3);
-      uno3 = g_min(uno3, 0.999);
-      uno3 = g_max(uno3, UV_TRCMIN);
-      const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
-      double rno3 = g_max(TN(k, X_din15), r15min) / g_max(TN(k, X_no3) - TN(k, X_din15), r15min);
-      rno3 = g_min(rno3, 2. * UV_RN15STD);
-      rno3 = g_max(rno3, UV_RN15STD / 2.);
-      const double bwcdeni = g_rayleigh(rno3, P->eps_wcdeni, uno3);
-      SX(k, X_din15) = SX(k, X_din15) - (bwcdeni / (1 + bwcdeni)) * wcdeni;
+    { /* mobi_driver's second loop (oxygen, water-column denitrification, 15N: mobi.F:1302-1365) touches level k only */
+      const double fo2 = tanh(0.22 * g_max(o2_in, 0.));
+      const double so2 = dic_npzd_sms_k * P->redotc + nfix_k * St.rnbio * 1.25e-3;
+      const double no3flag = g_flag01(bioin[X_no3] - UV_TRCMIN);
+      const double din15flag = N15 ? g_flag01(bioin[X_din15] - UV_TRCMIN) : 1.;
+      const double lno3 = 0.5 * tanh(bioin[X_no3] - 2.5);
+      double wcdeni = 800. * no3flag * so2 * (1.0 - fo2) * (0.5 + lno3);
+      if (N15) wcdeni = wcdeni * din15flag;
+      wcdeni = g_max(wcdeni, 0.);
+      SX(k, X_no3) = SX(k, X_no3) - wcdeni;
+      if (N15) {
+        double uno3 = wcdeni * twodt / bioin[X_no3];
+        uno3 = g_min(uno3, 0.999);
+        uno3 = g_max(uno3, UV_TRCMIN);
+        const double r15min = UV_TRCMIN * UV_RN15STD / (1 + UV_RN15STD);
+        double rno3 = g_max(bioin[X_din15], r15min) / g_max(bioin[X_no3] - bioin[X_din15], r15min);
+        rno3 = g_min(rno3, 2. * UV_RN15STD);
+        rno3 = g_max(rno3, UV_RN15STD / 2.);
+        const double bwcdeni = g_rayleigh(rno3, P->eps_wcdeni, uno3);
+        SX(k, X_din15) = SX(k, X_din15) - (bwcdeni / (1 + bwcdeni)) * wcdeni;
+      }
+      SRC(k, O->is_alk) = SRC(k, O->is_alk) + wcdeni * 1.e-3;
+      SRC(k, O->is_alk) = SRC(k, O->is_alk) + bdeni_k * 1.e-3;
+      SRC(k, O->is_alk) = SRC(k, O->is_alk) - nfix_k * St.rnbio * 1.e-3;
+      SRC(k, O->is_o2) = -so2 * fo2;
+      }
+    if (CACO3) { /* ... and so does the third with prognostic CaCO3 (mobi.F:1373-1436) */
+      const double rexp = (k == kmx) ? rexpocaco3_k : 0.0;
+      if (k < kmx) {
+        SX(k, X_dic) = SX(k, X_dic) + rdissl_k * 1.e-3 - rcalpro_k * 1.e-3;
+        if (C13) SX(k, X_dic13) = SX(k, X_dic13) + rdissl_k * 1.e-3 * rtcaco3c13_k - rcalpro_k * 1.e-3 * rtdic13_k;
+        SRC(k, O->is_alk) = SRC(k, O->is_alk) + 2. * rdissl_k * 1.e-3 - 2. * rcalpro_k * 1.e-3;
+      } else {
+        SX(k, X_dic) = SX(k, X_dic) + rdissl_k * 1.e-3 - rcalpro_k * 1.e-3 + rexp * 1.e-3;
+        if (C13) SX(k, X_dic13) = SX(k, X_dic13) + rdissl_k * 1.e-3 * rtcaco3c13_k - rcalpro_k * 1.e-3 * rtdic13_k + rexp * 1.e-3 * rtcaco3c13_k;
+        SRC(k, O->is_alk) = SRC(k, O->is_alk) + 2. * rdissl_k * 1.e-3 - 2. * rcalpro_k * 1.e-3 + 2. * rexp * 1.e-3;
+      }
     }
-    SRC(k, O->is_alk) = SRC(k, O->is_alk) + wcdeni * 1.e-3;
-    SRC(k, O->is_alk) = SRC(k, O->is_alk) + bdeni[k - 1] * 1.e-3;
-    SRC(k, O->is_alk) = SRC(k, O->is_alk) - nfix[k - 1] * St.rnbio * 1.e-3;
-    SRC(k, O->is_o2) = -so2 * fo2;
+    if (SIL && k == kmx) SX(k, X_sil) = SX(k, X_sil) + rexpoopl_k;
   }
-  /* third pass: calcite (mobi.F:1373-1436) */
-  for (int k = 1; k <= kmx - 1; ++k) {
-    if (CACO3) {
-      SX(k, X_dic) = SX(k, X_dic) + rdissl[k - 1] * 1.e-3 - rcalpro[k - 1] * 1.e-3;
-      if (C13) SX(k, X_dic13) = SX(k, X_dic13) + rdissl[k - 1] * 1.e-3 * rtcaco3c13[k - 1] - rcalpro[k - 1] * 1.e-3 * rtdic13[k - 1];
-      SRC(k, O->is_alk) = SRC(k, O->is_alk) + 2. * rdissl[k - 1] * 1.e-3 - 2. * rcalpro[k - 1] * 1.e-3;
-    } else {
+  if (!CACO3) { /* the third loop without prognostic CaCO3: the column's calcite production comes back by a fixed profile */
+    for (int k = 1; k <= kmx - 1; ++k) {
       SX(k, X_dic) = SX(k, X_dic) + prca * P->rcak[k - 1];
       if (C13) SX(k, X_dic13) = SX(k, X_dic13) + prca13 * P->rcak[k - 1];
       SRC(k, O->is_alk) = SRC(k, O->is_alk) + 2. * prca * P->rcak[k - 1];
     }
-  }
-  if (CACO3) {
-    SX(kmx, X_dic) = SX(kmx, X_dic) + rdissl[kmx - 1] * 1.e-3 - rcalpro[kmx - 1] * 1.e-3 + rexpocaco3[kmx - 1] * 1.e-3;
-    if (C13)
-      SX(kmx, X_dic13) = SX(kmx, X_dic13) + rdissl[kmx - 1] * 1.e-3 * rtcaco3c13[kmx - 1] -
-                         rcalpro[kmx - 1] * 1.e-3 * rtdic13[kmx - 1] + rexpocaco3[kmx - 1] * 1.e-3 * rtcaco3c13[kmx - 1];
-    SRC(kmx, O->is_alk) = SRC(kmx, O->is_alk) + 2. * rdissl[kmx - 1] * 1.e-3 - 2. * rcalpro[kmx - 1] * 1.e-3 +
-                          2. * rexpocaco3[kmx - 1] * 1.e-3;
-  } else {
     SX(kmx, X_dic) = SX(kmx, X_dic) + prca * P->rcab[kmx - 1];
     if (C13) SX(kmx, X_dic13) = SX(kmx, X_dic13) + prca13 * P->rcab[kmx - 1];
     SRC(kmx, O->is_alk) = SRC(kmx, O->is_alk) + 2. * prca * P->rcab[kmx - 1];
   }
-  if (SIL) SX(kmx, X_sil) = SX(kmx, X_sil) + rexpoopl[kmx - 1];
   /* iron inputs, tracer.F:538-545 */
   const int isdfe = S[X_dfe];
   SRC(1, isdfe) = SRC(1, isdfe) + M.fe_atmdep[ij + NS * (St.month - 1)] * 1000 / (P->dzt[0] / 100.);
@@ -876,5 +884,8 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
 }
 
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(off)
+#endif
 }  // namespace uvic
 #endif

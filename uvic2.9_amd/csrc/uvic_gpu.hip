@@ -490,12 +490,14 @@ __global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c,
   }
 #endif
 }
-// any other option set (kernels_mobi_gen.hpp): one thread per ocean column, the reference's three loops
+// any other option set (kernels_mobi_gen.hpp): one thread per ocean column, the reference's three loops.  One kernel
+// per option set of SURVEY.md 2c (own register allocation each), one with the flags at run time for anything else.
+template <int TN15, int TC13, int TCACO3, int TSIL>
 __global__ void __launch_bounds__(64) k_mobi_gen(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= w.count) return;
   WET_DECODE(w, gid);
-  mobig_column(c, m, i, j);
+  mobig_column<TN15, TC13, TCACO3, TSIL>(c, m, i, j);
 }
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -637,6 +639,7 @@ struct uvic_gpu {
   mobi_store mobi_st;
   uvic_mobi_options opt_staged;   // uvic_gpu_mobi_options_flat: taken by the next uvic_gpu_set_mobi_flat
   bool have_opt_staged;
+  int mobi_key;   // n15 | c13<<1 | caco3<<2 | silicon<<3 of the set bound by uvic_gpu_set_mobi_opt
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
   // polar filter (uvic_gpu_set_filter): strips and operators, built once
@@ -1739,7 +1742,12 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
   mark_on(h, "begin", sid);
   const unsigned cells = (unsigned)(((long long)w.count * c.km + 127) / 128), cols = (unsigned)((w.count + 63) / 64);
   if (m.O) {   // an option set other than C: the general column kernel does all of it
-    if (w.count > 0) hipLaunchKernelGGL(k_mobi_gen, dim3(cols), dim3(64), 0, st, c, m, w);
+    if (w.count > 0) {
+      if (h->mobi_key == 4) hipLaunchKernelGGL((k_mobi_gen<0, 0, 1, 0>), dim3(cols), dim3(64), 0, st, c, m, w);         // set F
+      else if (h->mobi_key == 15) hipLaunchKernelGGL((k_mobi_gen<1, 1, 1, 1>), dim3(cols), dim3(64), 0, st, c, m, w);   // run/mk.in's set
+      else if (h->mobi_key == 3) hipLaunchKernelGGL((k_mobi_gen<1, 1, 0, 0>), dim3(cols), dim3(64), 0, st, c, m, w);    // set C (cross-check)
+      else hipLaunchKernelGGL((k_mobi_gen<-1, -1, -1, -1>), dim3(cols), dim3(64), 0, st, c, m, w);
+    }
     mark_on(h, "mobi_gen", sid);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2259,6 +2267,7 @@ extern "C" int uvic_gpu_set_mobi_opt(uvic_gpu *h, const uvic_mobi_params *p, con
   HIPCHK(hipSetDevice(h->device));
   int rc = mobi_bind(h->d.imt, h->d.jmt, h->d.km, p, f, &h->mobi, &h->mobi_st, h->stream, g_err, o);
   if (rc) return rc;
+  h->mobi_key = (o->n15 != 0) | ((o->c13 != 0) << 1) | ((o->caco3 != 0) << 2) | ((o->silicon != 0) << 3);
   h->mobi_dtnpzd = p->dtnpzd;
   h->have_mobi = true;
   return 0;
