@@ -194,6 +194,7 @@ struct ColGrid {
   const int *lanes;
   int nwaves, total;           // total = nwaves * nt_local work items (one wave each)
   int fuse_convect;            // pass B: replay the convective mixing found by the T,S walk before t(tau+1) is stored
+  int *zero_word;              // pass B of T,S: a counter the NEXT kernel on the stream wants cleared (spares a memset node)
 };
 #define COL_LANE_I(code) ((code) & 0xfff)
 #define COL_LANE_R(code) (((code) >> 12) & 0xfff)

@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, 
 // pass B reading the final y fluxes pass A left (YFIN)
 __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_y(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (g.zero_word && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *g.zero_word = 0;
   colupd_body<false, true>(c, S, g, lds);
 }
 // the same with z(k) parked in t(tau+1) (half the LDS per wave); no fused convective replay
@@ -379,12 +380,46 @@ __global__ void __launch_bounds__(256) k_ts_iso3(const uvic_ctx c, const WetCols
 // The columns in which the walk mixed something, as a list: cvl[0] counts them, cvl[1..] holds their ids ((i-1) + imt*(j-1)).
 // Few columns convect in a step, and convect_apply over the list is a handful of waves instead of one thread per
 // (ocean column, tracer) that finds nothing to do.
-__global__ void __launch_bounds__(256) k_convect_apply_list(const uvic_ctx c, const int *cvl) {
-  const int ncol = cvl[0];
-  const long long total = (long long)ncol * (c.nt - 2);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
-    const int wid = cvl[1 + (int)(q % ncol)];   // columns fastest
-    convect_apply_cell(c, wid % c.imt + 1, wid / c.imt + 1, (int)(q / ncol) + 3);
+// (A handful of waves on the main stream between pass B and the next pass A: what counts is its chain of dependent memory
+// round trips -- each costs microseconds while the other streams keep the memory system busy.  The list entry is fetched
+// beside the count, a segment's levels in batches of eight instead of one round trip per level: same sums in the same
+// order as convect_apply_cell.)
+__global__ void __launch_bounds__(256) k_convect_apply_list(const uvic_ctx c, const int *cvl, int maxcol) {
+  UV_DIMS(c);
+  const int ntr = c.nt - 2;
+  const double *dz = c.dztxcl;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;; q += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(q / ntr), n = (int)(q % ntr) + 3;   // tracers fastest: a wave shares its columns' segment records
+    const int ncol = cvl[0];
+    const int wid = cvl[1 + (col < maxcol ? col : maxcol - 1)];   // (fetched beside the count, not after it)
+    if (col >= ncol) break;
+    const int i = wid % imt + 1, j = wid / imt + 1;
+    const int nseg = c.cv_nseg[X2(i, j)];
+    double *t = c.t_taup1 + (size_t)(n - 1) * N3;
+    for (int s = 1; s <= nseg; ++s) {
+      const int kt = c.cv_kt[X3(i, s, j)], kb = c.cv_kb[X3(i, s, j)];
+      const double zsm = c.cv_z[X3(i, s, j)];
+      double tsm3 = 0.0;
+      for (int k0 = kt; k0 <= kb; k0 += 8) {
+        double v[8];
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {
+          const int k = k0 + u <= kb ? k0 + u : kb;
+          v[u] = t[X3(i, k, j)] * dz[k - 1];
+        }
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)
+          if (k0 + u <= kb) tsm3 = tsm3 + v[u];
+      }
+      const double tmx3 = tsm3 / zsm;
+      for (int k = kt; k <= kb; ++k) t[X3(i, k, j)] = tmx3;
+    }
+    const int ic = (i == 2) ? imt : ((i == imt - 1) ? 1 : 0);
+    if (ic && nseg > 0)
+      for (int k0 = 1; k0 <= km; k0 += 8) {
+        double v[8];
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) v[u] = t[X3(i, (k0 + u <= km ? k0 + u : km), j)];
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)
+          if (k0 + u <= km) t[X3(ic, k0 + u, j)] = v[u];
+      }
   }
 }
 __global__ void __launch_bounds__(256) k_convect_apply(const uvic_ctx c, const WetCols w) {
@@ -1463,6 +1498,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     b.lanes = h->lanes_dev + (size_t)h->nwaves_a * 64; b.nwaves = h->nwaves_b; b.total = b.nwaves * c.nt_local;
     double *S = h->work[3];
     a.fuse_convect = b.fuse_convect = 0;
+    a.zero_word = b.zero_word = nullptr;
     const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
     auto blocks_a = [](const ColGrid &g) { return (unsigned)((((g.total + 3) / 4 + 7) / 8) * 8); };
     // the bulk launch of pass A: a_ntr tracers per lane (g.total counts waves)
@@ -1600,10 +1636,13 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
         mark_on(h, "colfct_ts", 3);
         if (ts_free && h->have_mobi) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_src_consumed, 0));
+        // (the list counter of the convective walk is cleared by pass B before it: a memset node costs the chain ~10 us)
+        const bool zero_in_b = h->yfin && bts.total > 0 && !ts_free;
+        if (zero_in_b) bts.zero_word = h->cv_list;
         launch_b(cts, bts, (const double *)S, h->side_ts, true);
         mark_on(h, "colupd_ts", 3);
         if (ts_free) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
-        HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+        if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
         if (w.count > 0)
           hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds, h->side_ts, cts, w, h->cv_list);
         mark_on(h, "convect_ts", 3);
@@ -1695,7 +1734,7 @@ static int launch_convect(uvic_gpu *h) {
       h->ts_apply = false;
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
       if (w.count > 0 && h->d.nt > 2)   // over the list of columns the walk mixed (few): 64 workgroups stride over it
-        hipLaunchKernelGGL(k_convect_apply_list, dim3(64), dim3(256), 0, h->stream, h->ctx, (const int *)h->cv_list);
+        hipLaunchKernelGGL(k_convect_apply_list, dim3(64), dim3(256), 0, h->stream, h->ctx, (const int *)h->cv_list, w.count);
       mark(h, "convect_apply");
     }
     if (!fused) {
