@@ -590,17 +590,31 @@ UVIC_DEV void convect_column(const uvic_ctx &c, int i, int j) {
 // are mixed over them afterwards (:257-271), so the replay is exact and exposes
 // nt-2 times more parallelism; most columns have no unstable segment at all.
 // ===========================================================================
-UVIC_DEV void convect_ts_column(const uvic_ctx &c, int i, int j, double *colT, double *colS, int stride) {
+// `tab` (optional): the per-level tables of the walk -- c(km,9), to, so, dztxcl, in this order -- where the caller has staged
+// them (LDS): the walk evaluates two densities per step with the level depending on the data, and every evaluation
+// through global memory is a round trip on a chain others wait for
+UVIC_DEV void convect_ts_column(const uvic_ctx &c, int i, int j, double *colT, double *colS, int stride, const double *tab = nullptr) {
   UV_DIMS(c);
   double *ts = c.t_taup1;
-#define DENS(tq, sq, k) eos_dens(c.c, km, tq, sq, k)
+  const double *eosc = tab ? tab : c.c;
+#define DENS(tq, sq, k) eos_dens(eosc, km, tq, sq, k)
 #define CT(k) colT[(size_t)((k)-1) * stride]
 #define CS(k) colS[(size_t)((k)-1) * stride]
-  const double *to = c.to, *so = c.so, *dz = c.dztxcl;
+  const double *to = tab ? tab + (size_t)9 * km : c.to, *so = tab ? tab + (size_t)10 * km : c.so;
+  const double *dz = tab ? tab + (size_t)11 * km : c.dztxcl;
   const int kbo = c.kmt[X2(i, j)];
-  for (int k = 1; k <= km; ++k) {
-    CT(k) = ts[X3(i, k, j)];
-    CS(k) = ts[X3(i, k, j) + N3];
+  for (int k0 = 1; k0 <= km; k0 += 8) {   // (eight levels per memory round trip, not one)
+    double a[8], b[8];
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u <= km ? k0 + u : km;
+      a[u] = ts[X3(i, k, j)];
+      b[u] = ts[X3(i, k, j) + N3];
+    }
+    _Pragma("unroll") for (int u = 0; u < 8; ++u)
+      if (k0 + u <= km) {
+        CT(k0 + u) = a[u];
+        CS(k0 + u) = b[u];
+      }
   }
   int nseg = 0;
   int kt = 1, kb = 2;

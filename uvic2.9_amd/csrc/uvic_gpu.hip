@@ -353,10 +353,17 @@ struct WetCols {
 __global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCols w, int *cvl) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= w.count) return;
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
+  // the per-level tables of the walk go to LDS first (12 km doubles for the 64 columns of the workgroup)
+  double *tab = lds + (size_t)2 * c.km * 64;
+  for (int q = threadIdx.x; q < 12 * c.km; q += 64) {
+    const int a = q / c.km, k = q % c.km;
+    tab[q] = a < 9 ? c.c[q] : (a == 9 ? c.to[k] : (a == 10 ? c.so[k] : c.dztxcl[k]));
+  }
+  __syncthreads();
+  if (gid >= w.count) return;
   WET_DECODE(w, gid);
-  convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
+  convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64, tab);
   if (cvl && c.cv_nseg[wid_] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid_;
 }
 // third shared launch: the convective T,S walk beside the column sums of isopyc
@@ -1559,7 +1566,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       mark_on(h, "colupd_ts", 3);
       HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
       if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->side_ts, cts, w, h->cv_list);
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8 + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
       mark_on(h, "convect_ts", 3);
       HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
       if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
@@ -1644,7 +1651,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         if (ts_free) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
         if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
         if (w.count > 0)
-          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds, h->side_ts, cts, w, h->cv_list);
+          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
         mark_on(h, "convect_ts", 3);
       }
       // one barrier packet less on the main stream (~8 us each): the side stream waits for the sources as well before it
@@ -1739,7 +1746,7 @@ static int launch_convect(uvic_gpu *h) {
     }
     if (!fused) {
       if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8, h->stream, h->ctx, w, (int *)nullptr);
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8 + (size_t)12 * h->d.km * 8, h->stream, h->ctx, w, (int *)nullptr);
       mark(h, "convect_ts");
     }
     if (h->d.nt > 2 && !fused) {
