@@ -740,6 +740,7 @@ struct uvic_gpu {
     void *f[16];
     double *work[3], *coef;
     hipEvent_t ev;          // recorded behind the chain that filled the set
+    hipStream_t st;         // ... on this stream
     long long for_step;     // the step whose fields a look-ahead chain put there, -1: none
     bool vel_stale;         // adv_vet/vnt/vbt were uploaded after the chain had formed the total velocities from them
     bool allocated;
@@ -749,6 +750,9 @@ struct uvic_gpu {
   hipEvent_t ev_ts_final;   // T and S of this step's t(tau+1) are final (after convection and the polar filter)
   bool ts_final_valid;
   hipEvent_t ev_step_begin, ev_src_next[2];
+  hipEvent_t ev_begin_cur;      // the event that stands for this step's begin: ev_step_begin, or the previous step's end event
+  bool idle_until_next;         // the caller has promised that nothing follows the step on the main stream before the next one
+  long long ts_waited_begin;    // the step whose begin event the T,S stream has waited for already
   void *src_alt;
   bool prefetch_pending, src_from_prefetch, mixing;
   int nchunk, fct_threads, upd_threads;
@@ -883,11 +887,15 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   for (int q = 0; q < 3; ++q) {
     memset(&h->iso_set[q], 0, sizeof h->iso_set[q]);
     HIPCHK(hipEventCreateWithFlags(&h->iso_set[q].ev, hipEventDisableTiming));
+    h->iso_set[q].st = nullptr;
     h->iso_set[q].for_step = -1;
   }
   h->iso_cur = 0; h->step_no = 0; h->ts_final_valid = false;
   h->ev_flip = 0;
   HIPCHK(hipEventCreateWithFlags(&h->ev_step_begin, hipEventDisableTiming));
+  h->ev_begin_cur = h->ev_step_begin;
+  h->idle_until_next = false;
+  h->ts_waited_begin = -1;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
   h->ev_src_ready = h->ev_src_pending = h->ev_src_consumed = h->ev_src_next[0];
   h->src_consumed_valid = h->src_consumed_now = h->prev_mixing = h->halo_seen = h->iso2_used = false;
@@ -1237,6 +1245,7 @@ static void land_touched(uvic_gpu *h, int field) {
   v.erase(std::remove(v.begin(), v.end(), h->buf[field]), v.end());
 }
 extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t offset, int64_t count) {
+  if (h) h->idle_until_next = false;   // something is queued on the main stream between two steps
   if (!h || !host) return fail_msg("uvic_gpu_upload: null argument");
   if (field < 0 || field >= UVIC_F_COUNT) return fail_msg("uvic_gpu_upload: bad field id");
   const int64_t n = field_elems(h->d, field);
@@ -1310,6 +1319,7 @@ static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, boo
   return 0;
 }
 extern "C" int uvic_gpu_upload_rows(uvic_gpu *h, int field, const double *host, int jlo, int jhi) {
+  if (h) h->idle_until_next = false;   // something is queued on the main stream between two steps
   return rows_xfer(h, field, (double *)host, jlo, jhi, true);
 }
 extern "C" int uvic_gpu_download_rows(uvic_gpu *h, int field, double *host, int jlo, int jhi) {
@@ -1606,8 +1616,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (ts_free) {
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
       } else if (h->iso_waited && h->step_begun) {
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
+        h->ts_waited_begin = getenv("UVIC_FEWER_PACKETS") && atoi(getenv("UVIC_FEWER_PACKETS")) == 0 ? -1 : h->step_no;
+        if (h->iso_set[h->iso_cur].st != h->side_ts || h->ts_waited_begin < 0)   // (the chain ran on this very stream: nothing to wait for)
+          HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
       } else {
         HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
@@ -1636,6 +1648,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         hipLaunchKernelGGL(k_ts_iso3, dim3((unsigned)(n3 + ncol256)), dim3(64, 4), cv_lds, h->side_ts, cts, w, n3, ci, h->cv_list, h->iso_fuse_coef);
         mark_on(h, "convect_ts", 3);
         HIPCHK(hipEventRecord(h->iso_set[h->iso_fuse_set].ev, h->side_ts));
+        h->iso_set[h->iso_fuse_set].st = h->side_ts;
         h->iso_set[h->iso_fuse_set].for_step = h->step_no + 1;
         h->iso_set[h->iso_fuse_set].vel_stale = false;
       } else {
@@ -1648,7 +1661,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
         if (zero_in_b) bts.zero_word = h->cv_list;
         launch_b(cts, bts, (const double *)S, h->side_ts, true);
         mark_on(h, "colupd_ts", 3);
-        if (ts_free) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_step_begin, 0));
+        if (ts_free) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
         if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
         if (w.count > 0)
           hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
@@ -1948,7 +1961,15 @@ extern "C" int uvic_gpu_tracer(uvic_gpu *h) {
 // for.  Recorded once per step by whichever of step_async / step_pre_async / prefetch_* comes first.
 static int step_begin(uvic_gpu *h) {
   if (h->step_begun) return 0;
-  HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));
+  if (h->idle_until_next && h->end_ready) {
+    // nothing was queued on the main stream since the previous step's end event: it is this step's begin (one marker
+    // packet less on the stream whose chain is the step: ~6 us)
+    h->ev_begin_cur = h->ev_end_ready;
+  } else {
+    HIPCHK(hipEventRecord(h->ev_step_begin, h->stream));
+    h->ev_begin_cur = h->ev_step_begin;
+  }
+  h->idle_until_next = false;
   h->step_begun = true;
   return 0;
 }
@@ -2022,6 +2043,8 @@ extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing
   if ((iso_ahead & 2) && !h->ctx.diff_cbt_given)
     if (int rc = prefetch_isopyc_ahead(h, 2)) return rc;
   h->unmix_at_rotate = mixing != 0;
+  static const bool fewer = getenv("UVIC_MAIN_ALIAS") && atoi(getenv("UVIC_MAIN_ALIAS")) != 0;
+  h->idle_until_next = fewer && (iso_ahead & 4) != 0;   // bit 2: the caller queues nothing on the main stream before the next step
   return 0;
 }
 // MOBI sources of the NEXT step from t(tau) (= next step's t(tau-1) on a leapfrog step) on
@@ -2054,7 +2077,7 @@ extern "C" int uvic_gpu_prefetch_sources_at(uvic_gpu *h, double c2dtts_next, dou
   if (int rc = step_begin(h)) return rc;
   // src_alt was read last by pass B of the previous step (before ev_step_begin); the other chain writes the other buffer
   // (the end of the previous step's own work is enough: MOBI is column-local, the halo rows do not matter to it)
-  HIPCHK(hipStreamWaitEvent(st, h->end_ready ? h->ev_end_ready : h->ev_step_begin, 0));
+  HIPCHK(hipStreamWaitEvent(st, h->end_ready ? h->ev_end_ready : h->ev_begin_cur, 0));
   if (int rc = launch_mobi_on(h, c, m, st, sid)) return rc;
   h->ev_src_pending = h->ev_src_next[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_src_pending, st));
@@ -2094,9 +2117,12 @@ static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead) {
   c.t_taum1 = (ahead == 2) ? (const double *)h->ctx.t_taup1 : h->ctx.t_tau;
   if (int rc = step_begin(h)) return rc;
   // the set was last read by step target-3; whatever this step still does with t does not touch what the chain reads
-  HIPCHK(hipStreamWaitEvent(st, ahead == 2 ? h->ev_ts_final : h->ev_step_begin, 0));
+  if (ahead == 2) HIPCHK(hipStreamWaitEvent(st, h->ev_ts_final, 0));
+  else if (!(st == h->side_ts && h->ts_waited_begin == h->step_no))   // (this stream has waited for the step's begin already)
+    HIPCHK(hipStreamWaitEvent(st, h->ev_begin_cur, 0));
   if (int rc = launch_isopyc_on(h, c, coef, st, sid)) return rc;
   HIPCHK(hipEventRecord(h->iso_set[set].ev, st));
+  h->iso_set[set].st = st;
   h->iso_set[set].for_step = target;
   h->iso_set[set].vel_stale = false;
   return 0;
@@ -2154,6 +2180,7 @@ static int halo_move(uvic_gpu *h, int which, int j0, int dir) {
 }
 // pack the outermost owned rows of t(tau+1) (the slab of uvic_gpu_set_shard) into the send buffers, on the main stream
 extern "C" int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north) {
+  if (h) h->idle_until_next = false;   // something is queued on the main stream between two steps
   if (!h) return fail_msg("null handle");
   if (south) if (int rc = halo_move(h, 0, h->ctx.js, 0)) return rc;
   if (north) if (int rc = halo_move(h, 1, h->ctx.je - UVIC_HALO + 1, 0)) return rc;
@@ -2161,6 +2188,7 @@ extern "C" int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north) {
 }
 // ... and the received rows into the halo rows beyond the slab
 extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
+  if (h) h->idle_until_next = false;   // something is queued on the main stream between two steps
   if (!h) return fail_msg("null handle");
   h->halo_seen = true;   // rows of t(tau+1) of every tracer, T and S too, arrive on the main stream after the step
   if (south) if (int rc = halo_move(h, 2, h->ctx.js - UVIC_HALO, 1)) return rc;
@@ -2363,6 +2391,7 @@ extern "C" int uvic_gpu_mobi_options_flat(uvic_gpu *h, const int32_t *flags, con
 // current step; relyr selects the month of the dust field and the declination; co2ccn the atmospheric CO2)
 extern "C" int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, const double *dnswr, const double *aice,
                                       const double *hice, const double *hsno) {
+  if (h) h->idle_until_next = false;   // something is queued on the main stream between two steps
   if (!h) return fail_msg("uvic_gpu_set_mobi_step: null argument");
   if (!h->have_mobi) return fail_msg("uvic_gpu_set_mobi_step: call uvic_gpu_set_mobi first");
   HIPCHK(hipSetDevice(h->device));

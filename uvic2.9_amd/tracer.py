@@ -293,7 +293,8 @@ class TimeLoop:
             # t(tau+1) (single rank only: a latitude slab gets the halo rows of t(tau+1) with the exchange that follows)
             iso_ahead = 0
             if self.prefetch and not m.params.diff_cbt_has_k33:
-                iso_ahead = (1 if ahead else 0) | (2 if self.shard is None and self.iso2 and not self._mixing(self.itt + 2) else 0)
+                iso_ahead = ((1 if ahead else 0) | (2 if self.shard is None and self.iso2 and not self._mixing(self.itt + 2) else 0)
+                             | (4 if self.shard is None else 0))   # 4: nothing follows on the main stream before the next step
             c2dtts = self.dtts if mixing else 2.0 * self.dtts
             if self.clock is None:
                 check(m.lib.uvic_gpu_step_lookahead(m.h, c2dtts, int(mixing), int(mobi_ahead), 2.0 * self.dtts, int(iso_ahead)),
