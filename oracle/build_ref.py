@@ -190,10 +190,11 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
 DEFAULT_BUILDS = [
     ("p2", 14, 14, 6), ("c30", 14, 14, 6),
     ("p2", 102, 102, 19), ("c30", 102, 102, 19),
+    ("f18", 14, 14, 6), ("s37", 14, 14, 6),       # MOBI option sets F and run/mk.in's (tests/test_mobi_sets.py)
 ]
 
 
-SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19)]
+SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f18", 14, 14, 6), ("s37", 14, 14, 6)]
 
 
 def build_default(force: bool = False, verbose: bool = False):
