@@ -5,7 +5,8 @@
 // One thread per ocean column walks mobi_driver's three loops as the reference does (mobi.F:519-1482, mobi_src
 // :1485-3313, the caller's part tracer.F:355-545, 853-867), expression by expression in the reference's order, no
 // reassociation: the results differ from the CPU through the device's exp/log/tanh, fused mul+add pairs and powers taken
-// as exp(y log x) (UV_POWP, as in the kernels of set C) -- 3e-12 of the oracle at most, tested at 1e-11.  Option set C keeps its own
+// as exp(y log x) and quotients whose denominator cannot vanish without range handling (UV_POWP, div_safe, as in the
+// kernels of set C; the quotients the reference lets run to +-inf and clamps keep `/`) -- 3e-12 of the oracle at most, tested at 1e-11.  Option set C keeps its own
 // three-pass, four-wave-team kernels (kernels_mobi.hpp); this form is the general one, not the fast one: the flags are
 // wave-uniform branches, the column state lives in local memory.
 // Set E (no O_mobi_alk) is not served: the reference itself reads t(i,:,j,ialk,taum1) with ialk = 0 there (tracer.F:491).
@@ -191,48 +192,48 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
   for (int n = 1; n <= St.nbio; ++n) { /* mobi.F:2148-3252 */
     p1 = g_min(biophyt, P->pmax);
     p2 = g_max(0.0, biophyt - P->pmax);
-    const double k1n = (P->knmin * p1 + P->knmax * p2) / (p1 + p2);
+    const double k1n = div_safe(P->knmin * p1 + P->knmax * p2, p1 + p2);
     const double k1p_P = k1n * ptn_P;
-    kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
-    deffe = biodfe / (kfevar + biodfe);
+    kfevar = div_safe(P->kfemin * p1 + P->kfemax * p2, p1 + p2);
+    deffe = div_safe(biodfe, kfevar + biodfe);
     jmax = P->abio_P * bct * deffe;
     double k1n_Diat = 0., k1p_Diat = 0.;
     if (SIL) {
       p1 = g_min(biodiat, O->pmax_Diat);
       p2 = g_max(0.0, biodiat - O->pmax_Diat);
-      kfevar_Diat = (O->kfemin_Diat * p1 + O->kfemax_Diat * p2) / (p1 + p2);
-      k1n_Diat = (O->knmin_Diat * p1 + O->knmax_Diat * p2) / (p1 + p2);
+      kfevar_Diat = div_safe(O->kfemin_Diat * p1 + O->kfemax_Diat * p2, p1 + p2);
+      k1n_Diat = div_safe(O->knmin_Diat * p1 + O->knmax_Diat * p2, p1 + p2);
       k1p_Diat = k1n_Diat * redptn;
-      deffe_Diat = biodfe / (kfevar_Diat + biodfe);
+      deffe_Diat = div_safe(biodfe, kfevar_Diat + biodfe);
       jmax_Diat = O->abiodiat * bct * deffe_Diat;
     }
-    deffe_D = biodfe / (P->kfe_D + biodfe);
+    deffe_D = div_safe(biodfe, P->kfe_D + biodfe);
     jmax_D = g_max(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
-    double limP_dop = P->hdop * biodop / (k1p_P + biodop);
-    double limP_po4 = biopo4 / (k1p_P + biopo4);
+    double limP_dop = div_safe(P->hdop * biodop, k1p_P + biodop);
+    double limP_po4 = div_safe(biopo4, k1p_P + biopo4);
     const double dopupt_flag = g_flag01(limP_dop - limP_po4);
     const double limP = limP_dop * dopupt_flag + limP_po4 * (1. - dopupt_flag);
     double u_P = g_min(avej, jmax * limP);
     double u_Diat = 0., dopupt_Diat_flag = 0.;
     if (SIL) {
       const double k1si = 5.e-3;
-      const double limSi = biosil / (k1si + biosil);
-      limP_dop = P->hdop * biodop / (k1p_Diat + biodop);
-      limP_po4 = biopo4 / (k1p_Diat + biopo4);
+      const double limSi = div_safe(biosil, k1si + biosil);
+      limP_dop = div_safe(P->hdop * biodop, k1p_Diat + biodop);
+      limP_po4 = div_safe(biopo4, k1p_Diat + biopo4);
       dopupt_Diat_flag = g_flag01(limP_dop - limP_po4);
       const double limP_Diat = limP_dop * dopupt_Diat_flag + limP_po4 * (1. - dopupt_Diat_flag);
       u_Diat = g_min(avej_Diat, jmax_Diat * limSi);
       u_Diat = g_min(u_Diat, jmax_Diat * limP_Diat);
     }
-    u_P = g_min(u_P, jmax * biono3 / (k1n + biono3));
-    if (SIL) u_Diat = g_min(u_Diat, jmax_Diat * biono3 / (k1n_Diat + biono3));
+    u_P = g_min(u_P, div_safe(jmax * biono3, k1n + biono3));
+    if (SIL) u_Diat = g_min(u_Diat, div_safe(jmax_Diat * biono3, k1n_Diat + biono3));
     const double u_D = g_min(avej_D, jmax_D * limP);
     const double dopupt_D_flag = dopupt_flag;
     double thetaZ = P->zprefP * biophyt + P->zprefDet * biodetr + P->zprefZ * biozoop + P->zprefDiaz * biodiaz + P->kzoo;
     if (SIL) thetaZ = thetaZ + O->zprefDiat * biodiat;
-    const double ing_P = P->zprefP / thetaZ, ing_Det = P->zprefDet / thetaZ, ing_Z = P->zprefZ / thetaZ;
-    const double ing_D = P->zprefDiaz / thetaZ;
-    const double ing_Diat = SIL ? O->zprefDiat / thetaZ : 0.;
+    const double ing_P = div_safe(P->zprefP, thetaZ), ing_Det = div_safe(P->zprefDet, thetaZ), ing_Z = div_safe(P->zprefZ, thetaZ);
+    const double ing_D = div_safe(P->zprefDiaz, thetaZ);
+    const double ing_Diat = SIL ? div_safe(O->zprefDiat, thetaZ) : 0.;
     double npp = u_P * biophyt;
     double npp_Diat = SIL ? u_Diat * biodiat : 0.;
     const double dopupt = npp * dopupt_flag; /* from the unflagged npp, mobi.F:2236 */
@@ -342,28 +343,28 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
     double fcassim = 0., fcrecy = 0., fcexcr = 0., fcnfix = 0.;
     double rtphytn15 = 0., rtdiatn15 = 0., rtzoopn15 = 0., rtdetrn15 = 0., rtdiazn15 = 0.;
     if (N15) {
-      double uno3 = npp * dtbio / biono3;
+      double uno3 = div_safe(npp * dtbio, biono3);
       uno3 = g_min(uno3, 0.999);
       uno3 = g_max(uno3, UV_TRCMIN);
       const double rno3 = g_clamp(biodin15 / (biono3 - biodin15), 2 * UV_RN15STD, UV_RN15STD / 2.);
       const double bassim = g_rayleigh(rno3, P->eps_assim, uno3);
-      fcassim = bassim / (1 + bassim);
-      double udon = recy_don * dtbio / biodon;
+      fcassim = div_safe(bassim, 1 + bassim);
+      double udon = div_safe(recy_don * dtbio, biodon);
       udon = g_min(udon, 0.999);
       udon = g_max(udon, UV_TRCMIN);
       const double rdon = g_clamp(biodon15 / (biodon - biodon15), 2 * UV_RN15STD, UV_RN15STD / 2.);
       const double brecy = g_rayleigh(rdon, P->eps_recy, udon);
-      fcrecy = brecy / (1 + brecy);
+      fcrecy = div_safe(brecy, 1 + brecy);
       const double rzoop = g_clamp(biozoopn15 / (biozoop - biozoopn15), 2. * UV_RN15STD, UV_RN15STD / 2.);
       const double bexcr = rzoop - P->eps_excr * rzoop / 1000.;
-      fcexcr = bexcr / (1 + bexcr);
+      fcexcr = div_safe(bexcr, 1 + bexcr);
       const double bnfix = UV_RN15STD - P->eps_nfix * UV_RN15STD / 1000.;
-      fcnfix = bnfix / (1 + bnfix);
-      rtphytn15 = g_clamp(biophytn15 / biophyt, rn15hi, rn15lo);
-      if (SIL) rtdiatn15 = g_clamp(biodiatn15 / biodiat, rn15hi, rn15lo);
-      rtzoopn15 = g_clamp(biozoopn15 / biozoop, rn15hi, rn15lo);
-      rtdetrn15 = g_clamp(biodetrn15 / biodetr, rn15hi, rn15lo);
-      rtdiazn15 = g_clamp(biodiazn15 / biodiaz, rn15hi, rn15lo);
+      fcnfix = div_safe(bnfix, 1 + bnfix);
+      rtphytn15 = g_clamp(div_safe(biophytn15, biophyt), rn15hi, rn15lo);
+      if (SIL) rtdiatn15 = g_clamp(div_safe(biodiatn15, biodiat), rn15hi, rn15lo);
+      rtzoopn15 = g_clamp(div_safe(biozoopn15, biozoop), rn15hi, rn15lo);
+      rtdetrn15 = g_clamp(div_safe(biodetrn15, biodetr), rn15hi, rn15lo);
+      rtdiazn15 = g_clamp(div_safe(biodiazn15, biodiaz), rn15hi, rn15lo);
     }
     /* carbon-13 fractionation, mobi.F:2637-2676 */
     double fcnpp = 0., rtdic13 = 0., rtphytc13 = 0., rtdiatc13 = 0., rtcaco3c13 = 0., rtzoopc13 = 0., rtdetrc13 = 0.;
@@ -371,15 +372,15 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
     if (C13) {
       const double rdic13 = g_clamp(biodic13 / (biodic - biodic13), 2. * UV_RC13STD, 0.5 * UV_RC13STD);
       const double bc13npp = ac13b * rdic13;
-      fcnpp = bc13npp / (1 + bc13npp);
-      rtdic13 = g_clamp(biodic13 / biodic, rc13hi, rc13lo);
-      rtphytc13 = g_clamp(biophytc13 / (biophyt * redctn), rc13hi, rc13lo);
-      if (SIL) rtdiatc13 = g_clamp(biodiatc13 / (biodiat * redctn), rc13hi, rc13lo);
-      if (CACO3) rtcaco3c13 = g_clamp(biocaco3c13 / biocaco3, rc13hi, rc13lo);
-      rtzoopc13 = g_clamp(biozoopc13 / (biozoop * redctn), rc13hi, rc13lo);
-      rtdetrc13 = g_clamp(biodetrc13 / (biodetr * redctn), rc13hi, rc13lo);
-      rtdoc13 = g_clamp(biodoc13 / (biodon * redctn), rc13hi, rc13lo);
-      rtdiazc13 = g_clamp(biodiazc13 / (biodiaz * redctn), rc13hi, rc13lo);
+      fcnpp = div_safe(bc13npp, 1 + bc13npp);
+      rtdic13 = g_clamp(div_safe(biodic13, biodic), rc13hi, rc13lo);
+      rtphytc13 = g_clamp(div_safe(biophytc13, biophyt * redctn), rc13hi, rc13lo);
+      if (SIL) rtdiatc13 = g_clamp(div_safe(biodiatc13, biodiat * redctn), rc13hi, rc13lo);
+      if (CACO3) rtcaco3c13 = g_clamp(div_safe(biocaco3c13, biocaco3), rc13hi, rc13lo);
+      rtzoopc13 = g_clamp(div_safe(biozoopc13, biozoop * redctn), rc13hi, rc13lo);
+      rtdetrc13 = g_clamp(div_safe(biodetrc13, biodetr * redctn), rc13hi, rc13lo);
+      rtdoc13 = g_clamp(div_safe(biodoc13, biodon * redctn), rc13hi, rc13lo);
+      rtdiazc13 = g_clamp(div_safe(biodiazc13, biodiaz * redctn), rc13hi, rc13lo);
     }
     double calpro;
     if (CACO3) calpro = ((sf_Z + morz) * capr + (sf_P + morp) * capr) * redctn * 1.e3;
