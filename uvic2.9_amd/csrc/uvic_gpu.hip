@@ -297,41 +297,6 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_ts(const uvic_ctx 
   colupd_body<false>(c, S, g, lds);
 }
 // ---- the T,S chain of step n and the isopyc chain of step n+1 share three launches -------------------------------
-// Both are chains of three short kernels on the same side stream (pass A, pass B, convective walk of T,S; elements,
-// mixing tensor + GM velocities, column sums of isopyc), neither reads what the other writes, and one after the other
-// they are the longest queue of a step.  Launched side by side (the first blocks of a launch do the T,S stage, the
-// rest the isopyc stage) the stream holds three kernels per step instead of seven.  `ci` is the context of the isopyc
-// part: it reads this step's t(tau) as t(tau-1) and writes the set of the next step.
-#define CELL_DECODE_ID(c, id)                               \
-  const long long gid = (id);                               \
-  const int i = (int)(gid % (c).imt) + 1;                   \
-  const int k = (int)((gid / (c).imt) % (c).km) + 1;        \
-  const int j = (int)(gid / ((long long)(c).imt * (c).km)) + 1
-__global__ void __launch_bounds__(256) k_ts_iso1(const uvic_ctx c, const double *cf, double *S, const ColGrid g, int nts, const uvic_ctx ci) {
-  if ((int)blockIdx.x < nts) { colfct_body<1, PART_ALL>(c, cf, S, g); return; }
-  if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
-  CELL_DECODE_ID(ci, (long long)(blockIdx.x - nts) * 256 + threadIdx.y * 64 + threadIdx.x);
-  if (j > ci.jmt || i < 2 || i > ci.imt - 1 || SLAB_OUT(ci, j)) return;
-  isopyc_elements_cell(ci, i, k, j);
-}
-// (blocks of 256 threads: the T,S stage, one wave per workgroup with its 20 KB of LDS, uses the first wave of its blocks;
-// eight such blocks fit on a CU, so the isopyc blocks beside them still fill every wave slot)
-__global__ void __launch_bounds__(256) k_ts_iso2(const uvic_ctx c, const double *S, const ColGrid g, int nts, const uvic_ctx ci,
-                                                 double *cfi, int ncell) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  if ((int)blockIdx.x < nts) {
-    if (threadIdx.y == 0) colupd_body<false>(c, S, g, lds);
-    return;
-  }
-  if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
-  const int b = blockIdx.x - nts;
-  const bool second = b >= ncell;   // first the mixing tensor and the folded coefficients, then the GM velocities
-  CELL_DECODE_ID(ci, (long long)(second ? b - ncell : b) * 256 + threadIdx.y * 64 + threadIdx.x);
-  if (j > ci.jmt - 1 || SLAB_OUT(ci, j)) return;
-  if (second) { isopyc_adv_cell(ci, i, k, j, cfi + CF_IDX(CF_VE, 0, (size_t)ci.imt * ci.km * ci.jmt)); return; }
-  if (i < 2 || i > ci.imt - 1) return;
-  ai_coef_cell(ci, cfi, i, k, j);
-}
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -365,24 +330,6 @@ __global__ void __launch_bounds__(64) k_convect_ts(const uvic_ctx c, const WetCo
   WET_DECODE(w, gid);
   convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64, tab);
   if (cvl && c.cv_nseg[wid_] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid_;
-}
-// third shared launch: the convective T,S walk beside the column sums of isopyc
-__global__ void __launch_bounds__(256) k_ts_iso3(const uvic_ctx c, const WetCols w, int nts, const uvic_ctx ci, int *cvl, double *cfi) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  if ((int)blockIdx.x < nts) {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (threadIdx.y != 0 || gid >= w.count) return;
-    if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
-    WET_DECODE(w, gid);
-    convect_ts_column(c, i, j, lds + threadIdx.x, lds + (size_t)c.km * 64 + threadIdx.x, 64);
-    if (cvl && c.cv_nseg[wid_] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid_;
-    return;
-  }
-  if (ci.prio & 4) __builtin_amdgcn_s_setprio(3);
-  const int gid = (blockIdx.x - nts) * 256 + threadIdx.y * 64 + threadIdx.x;
-  const int i = gid % ci.imt + 1, j = gid / ci.imt + 1;
-  if (j < 2 || j > ci.jmt - 1 || i < 2 || i > ci.imt - 1 || SLAB_OUT(ci, j)) return;
-  isopyc_column(ci, i, j, cfi + CF_IDX(CF_VB, 0, (size_t)ci.imt * ci.km * ci.jmt));
 }
 // The columns in which the walk mixed something, as a list: cvl[0] counts them, cvl[1..] holds their ids ((i-1) + imt*(j-1)).
 // Few columns convect in a step, and convect_apply over the list is a handful of waves instead of one thread per
@@ -659,7 +606,6 @@ struct uvic_gpu {
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
   bool mixing_next_guard = false;
   bool yfin;        // pass A leaves the final y flux of each row's north face, pass B reads two of them (UVIC_YFIN, default 1)
-  bool ts_in_bulk;  // T and S go through pass A with the other tracers; their pass B and the walk on the side stream (UVIC_TS_IN_BULK)
   bool b_zglobal;   // pass B parks z(k) in t(tau+1) instead of LDS (UVIC_B_ZGLOBAL, default 1)
   int a_mode;       // pass A of the bulk launch: 1 = one sweep, 2 = one sweep with two tracers per lane, 3 = two sweeps (UVIC_A_MODE)
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
@@ -699,8 +645,6 @@ struct uvic_gpu {
   // before step n waits for the chain of step n: `_pending` = recorded during this step, `_ready` = what this step waits for
   int ev_flip;
   hipEvent_t ev_src_ready, ev_src_pending;
-  hipEvent_t ev_src_consumed;   // the MOBI chain whose sources the previous step took (its last reader of t(tau-1) then)
-  bool src_consumed_valid, src_consumed_now, prev_mixing, halo_seen, iso2_used, ts_free_opt;
   hipEvent_t ev_step_end[2], ev_end_ready, ev_end_pending;   // end of a step's own work (step_end)
   bool end_ready, end_pending;
   // isopyc one step ahead on a second side stream (uvic_gpu_prefetch_isopyc): alternate set of its products
@@ -713,11 +657,6 @@ struct uvic_gpu {
   hipStream_t side_ts; // the T,S passes: an alias of side2
   hipEvent_t ev_fct_done, ev_ts_done;
   bool ts_ahead;      // this step's convect_ts was already issued on side2
-  // isopyc of the next step fused into the T,S launches of this one (k_ts_iso*): armed by uvic_gpu_step_lookahead
-  bool iso_fuse_armed, iso_fuse;
-  uvic_ctx iso_fuse_ctx;
-  double *iso_fuse_coef;
-  int iso_fuse_set;
   // resident overlay (uvic_gpu_overlay_step): uploads without host synchronisation, T,S of t(tau+1) sent to the host as soon
   // as they are final, the surface boundary condition sums of set_sbc kept on the device
   bool host_sync;               // 0: uploads are queued on the main stream and not waited for
@@ -878,9 +817,6 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_host, hipEventDisableTiming));
   h->sbc_count = 0; h->sbc_tracer = nullptr; h->sbc_acc = nullptr;
   h->src_relyr = h->src_co2ccn = 0.0;
-  h->iso_fuse_armed = false;
-  h->iso_fuse = false;   // measured: the shared launches take as long as the seven separate ones (the chip is saturated)
-  if (const char *e = getenv("UVIC_ISO_FUSE")) h->iso_fuse = atoi(e) != 0;
   h->conv_decoupled = true;
   if (const char *e = getenv("UVIC_CONV_DECOUPLED")) h->conv_decoupled = atoi(e) != 0;
   h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false; h->unmix_at_rotate = false;
@@ -897,9 +833,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->idle_until_next = false;
   h->ts_waited_begin = -1;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
-  h->ev_src_ready = h->ev_src_pending = h->ev_src_consumed = h->ev_src_next[0];
-  h->src_consumed_valid = h->src_consumed_now = h->prev_mixing = h->halo_seen = h->iso2_used = false;
-  h->ts_free_opt = getenv("UVIC_TS_FREE") && atoi(getenv("UVIC_TS_FREE")) != 0;   // measured: ties; off by default
+  h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_step_end[q], hipEventDisableTiming));
   h->ev_end_ready = h->ev_end_pending = h->ev_step_end[0];
   h->end_ready = h->end_pending = false;
@@ -943,8 +877,6 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   if (const char *e = getenv("UVIC_B_ZGLOBAL")) h->b_zglobal = atoi(e) != 0;
   h->yfin = true;
   if (const char *e = getenv("UVIC_YFIN")) h->yfin = atoi(e) != 0;
-  h->ts_in_bulk = false;
-  if (const char *e = getenv("UVIC_TS_IN_BULK")) h->ts_in_bulk = atoi(e) != 0;
   // measured (102x102x19, alone, 30 tracers): 1 = one sweep 131 us, 2 = two tracers per lane 116, 3 = two sweeps 63 + 79 (in the
   // loop these three tie), 4 = one sweep with the coefficient pairs shared through LDS by the four waves of a workgroup:
   // 100 us for 28 tracers against 117, 151 against 169 in the loop; 5 = 4 with the wave's own loads one level ahead (239 VGPRs,
@@ -1555,70 +1487,13 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     // sharding, where convection follows the exchange.
     const bool split = convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
                        h->ts_no_src;
-    if (split && h->ts_in_bulk) {
-      // T and S ride through pass A with the other tracers (no latency-bound pass A of their own); their pass B and the
-      // convective walk follow on the side stream -- behind the isopyc chain of the next step, which was queued there
-      // first and does not depend on this step -- while the main stream runs pass B of the others; convect_apply joins them
-      if (int rc = land_clean(h, c, h->stream)) return rc;
-      mark(h, "begin");
-      launch_a(c, a, S, h->stream);
-      mark(h, "colfct");
-      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
-      HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
-      uvic_ctx cts = c;
-      cts.nt_local = 2;
-      cts.prio |= 2;
-      ColGrid bts = b;
-      bts.total = bts.nwaves * 2;
-      const WetCols w = wet_range(h, c.js, c.je);
-      mark_on(h, "begin", 3);
-      launch_b(cts, bts, (const double *)S, h->side_ts, true);
-      mark_on(h, "colupd_ts", 3);
-      HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
-      if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8 + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
-      mark_on(h, "convect_ts", 3);
-      HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
-      if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
-        HIPCHK(hipMemcpyAsync(h->ts_host, c.t_taup1, (size_t)2 * c.imt * c.km * c.jmt * 8, hipMemcpyDeviceToHost, h->side_ts));
-        HIPCHK(hipEventRecord(h->ev_ts_host, h->side_ts));
-        h->ts_host_queued = true;
-      }
-      h->ts_ahead = true;
-      h->ts_apply = true;
-      if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
-      const size_t N3 = (size_t)c.imt * c.km * c.jmt;
-      uvic_ctx cr = c;
-      cr.n0 = 2; cr.nt_local = c.nt - 2;
-      cr.Rpm = c.Rpm + 2 * N3 * 2;
-      ColGrid br = b;
-      br.total = br.nwaves * cr.nt_local;
-      br.fuse_convect = 0;
-      if (h->src_from_prefetch) {
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
-        h->src_from_prefetch = false;
-      }
-      launch_b(cr, br, (const double *)(S + 2 * N3), h->stream, false);
-    } else if (split) {
+    if (split) {
       // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
       // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
-      // T and S of step n depend on T and S of step n-1 and on nothing else the main stream does: their passes may run
-      // while the main stream is still in step n-1.  What has to be kept apart (ts_free): pass B of T,S writes the buffer
-      // that was t(tau-1) of step n-1, which the MOBI chain of that step read (-> wait for that chain); the convective walk
-      // rewrites the segment records that the replay of step n-1 reads (-> wait for the main stream's step n-1 there, not
-      // before pass A).  Any step that is not plain (forward step now or before, sources or isopyc in line, halo rows
-      // arriving, the filter, a buffer whose land is not cleared yet) keeps the whole chain behind the previous step.
-      bool land_ok = false;
-      for (void *q : h->land_zeroed) land_ok = land_ok || q == (void *)c.t_taup1;
-      const bool ts_free = h->ts_free_opt && h->iso_waited && h->step_begun && !h->mixing && !h->prev_mixing && !h->halo_seen &&
-                           !h->iso2_used && land_ok && h->flt_nitems == 0 && (!h->have_mobi || h->src_consumed_valid) &&
-                           !h->iso_fuse_armed;
-      if (ts_free) {
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
-      } else if (h->iso_waited && h->step_begun) {
+      if (h->iso_waited && h->step_begun) {
         HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
-        h->ts_waited_begin = getenv("UVIC_FEWER_PACKETS") && atoi(getenv("UVIC_FEWER_PACKETS")) == 0 ? -1 : h->step_no;
-        if (h->iso_set[h->iso_cur].st != h->side_ts || h->ts_waited_begin < 0)   // (the chain ran on this very stream: nothing to wait for)
+        h->ts_waited_begin = h->step_no;
+        if (h->iso_set[h->iso_cur].st != h->side_ts)   // (the chain ran on this very stream: nothing to wait for, and a wait packet costs ~6 us)
           HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
       } else {
         HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
@@ -1633,40 +1508,18 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       mark_on(h, "begin", 3);
       const WetCols w = wet_range(h, c.js, c.je);
       const size_t cv_lds = (size_t)2 * h->d.km * 64 * 8;
-      if (h->iso_fuse_armed && !h->yfin && ats.total > 0 && bts.total > 0 && w.count > 0) {
-        // the isopyc chain of the next step rides in the same three launches (k_ts_iso*)
-        h->iso_fuse_armed = false;
-        const uvic_ctx &ci = h->iso_fuse_ctx;
-        const int n1 = (int)blocks_a(ats), n2 = (int)blocks_b(bts), n3 = (w.count + 63) / 64;
-        const int ncell256 = (int)cell_blocks(h, 256), ncol256 = (int)col_blocks(h, 256);
-        hipLaunchKernelGGL(k_ts_iso1, dim3((unsigned)(n1 + ncell256)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats, n1, ci);
-        mark_on(h, "colfct_ts", 3);
-        hipLaunchKernelGGL(k_ts_iso2, dim3((unsigned)(n2 + 2 * ncell256)), dim3(64, 4), upd_lds, h->side_ts, cts, (const double *)S, bts, n2,
-                           ci, h->iso_fuse_coef, ncell256);
-        mark_on(h, "colupd_ts", 3);
-        HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
-        hipLaunchKernelGGL(k_ts_iso3, dim3((unsigned)(n3 + ncol256)), dim3(64, 4), cv_lds, h->side_ts, cts, w, n3, ci, h->cv_list, h->iso_fuse_coef);
-        mark_on(h, "convect_ts", 3);
-        HIPCHK(hipEventRecord(h->iso_set[h->iso_fuse_set].ev, h->side_ts));
-        h->iso_set[h->iso_fuse_set].st = h->side_ts;
-        h->iso_set[h->iso_fuse_set].for_step = h->step_no + 1;
-        h->iso_set[h->iso_fuse_set].vel_stale = false;
-      } else {
-        if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
-        else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
-        mark_on(h, "colfct_ts", 3);
-        if (ts_free && h->have_mobi) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_src_consumed, 0));
-        // (the list counter of the convective walk is cleared by pass B before it: a memset node costs the chain ~10 us)
-        const bool zero_in_b = h->yfin && bts.total > 0 && !ts_free;
-        if (zero_in_b) bts.zero_word = h->cv_list;
-        launch_b(cts, bts, (const double *)S, h->side_ts, true);
-        mark_on(h, "colupd_ts", 3);
-        if (ts_free) HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
-        if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
-        if (w.count > 0)
-          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
-        mark_on(h, "convect_ts", 3);
-      }
+      if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+      else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
+      mark_on(h, "colfct_ts", 3);
+      // (the list counter of the convective walk is cleared by pass B before it: a memset node costs the chain ~10 us)
+      const bool zero_in_b = h->yfin && bts.total > 0;
+      if (zero_in_b) bts.zero_word = h->cv_list;
+      launch_b(cts, bts, (const double *)S, h->side_ts, true);
+      mark_on(h, "colupd_ts", 3);
+      if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+      if (w.count > 0)
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
+      mark_on(h, "convect_ts", 3);
       // one barrier packet less on the main stream (~8 us each): the side stream waits for the sources as well before it
       // signals, and the main stream waits for that one event
       if (h->src_from_prefetch && !h->conv_decoupled) {
@@ -1698,8 +1551,6 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
-        h->ev_src_consumed = h->ev_src_ready;
-        h->src_consumed_now = true;
       }
       static const bool dbg_nowait = getenv("UVIC_DBG_NOWAIT_TS") != nullptr;   // timing experiment only: results are wrong
       // decoupled: the mixed segments are replayed by convect_apply after this pass (launch_convect), so that the main
@@ -2015,26 +1866,7 @@ extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing
   if (!h) return fail_msg("null handle");
   if (int rc = uvic_gpu_set_mixing(h, mixing)) return rc;
   h->ctx.c2dtts = c2dtts;
-  // isopyc of the next step inside the T,S launches of this one: the context that writes the next step's set from this
-  // step's t(tau), made now (the set in use is not this step's yet: launch_isopyc switches to it)
-  h->iso_fuse_armed = false;
-  if ((iso_ahead & 1) && h->iso_fuse && !h->ctx.diff_cbt_given && !h->exact) {
-    const long long target = h->step_no + 1;
-    const int set = (int)(target % 3), cur = h->iso_cur;
-    if (h->iso_set[set].for_step != target) {
-      if (int rc = use_iso_set(h, set)) return rc;
-      h->iso_fuse_ctx = h->ctx;
-      h->iso_fuse_coef = h->coef;
-      if (int rc = use_iso_set(h, cur)) return rc;
-      h->iso_fuse_ctx.t_taum1 = h->ctx.t_tau;
-      h->iso_fuse_set = set;
-      h->iso_fuse_armed = true;
-    }
-  }
-  if (h->ts_in_bulk && (iso_ahead & 1) && !h->mixing_next_guard)
-    if (int rc = prefetch_isopyc_ahead(h, 1)) return rc;   // ahead of this step's T,S work on the same stream (launch_transport)
   if (int rc = uvic_gpu_step_async(h)) return rc;
-  h->iso_fuse_armed = false;   // not taken (no T,S launches of their own in this configuration): the chain below does it
   if (mobi_ahead && h->have_mobi)
     if (int rc = uvic_gpu_prefetch_sources_at(h, c2dtts_next, relyr_next, co2ccn_next)) return rc;
   // bit 0: the next step is a leapfrog step, bit 1: the step after next is (and no halo exchange follows)
@@ -2103,7 +1935,6 @@ static int prefetch_isopyc_ahead(uvic_gpu *h, int ahead) {
   hipStream_t st = h->side2;
   int sid = 2;
   if (ahead == 2) {
-    h->iso2_used = true;
     if (!h->ts_final_valid) return 0;                  // nothing says when T,S are final: leave it to ahead = 1 of the next step
     st = h->side_m[h->mobi_flip];
     sid = h->mobi_flip ? 4 : 1;
@@ -2190,7 +2021,6 @@ extern "C" int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north) {
 extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
   if (h) h->idle_until_next = false;   // something is queued on the main stream between two steps
   if (!h) return fail_msg("null handle");
-  h->halo_seen = true;   // rows of t(tau+1) of every tracer, T and S too, arrive on the main stream after the step
   if (south) if (int rc = halo_move(h, 2, h->ctx.js - UVIC_HALO, 1)) return rc;
   if (north) if (int rc = halo_move(h, 3, h->ctx.je + 1, 1)) return rc;
   return 0;
@@ -2198,9 +2028,6 @@ extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
 extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   h->step_begun = false;
-  h->prev_mixing = h->mixing;
-  h->src_consumed_valid = h->src_consumed_now;
-  h->src_consumed_now = false;
   if (h->unmix_at_rotate) { h->mixing = false; h->unmix_at_rotate = false; }
   h->ev_flip ^= 1;
   h->end_ready = h->end_pending;
