@@ -87,6 +87,26 @@ def test_two_latitude_slabs_on_one_gpu_equal_single_rank(tmp_path):
         assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
 
 
+@pytest.mark.parametrize("cfg", ["s37", "f18"])
+def test_two_slabs_and_two_shards_of_the_other_mobi_option_sets(tmp_path, cfg):
+    """The shipped nt=37 set and set F (general MOBI kernel, uvic_gpu_set_mobi_opt) under both decompositions: MOBI runs
+    on the slab's columns only / replicated, with the look-ahead chains, polar filter and mixing steps of the other tests."""
+    import torch.multiprocessing as mp
+    from uvic29_amd.parallel import slab_rows
+    out = str(tmp_path / "sets_slab")
+    mp.spawn(_worker, args=(2, 29611, out, "slab", (14, 14, 6), cfg), nprocs=2, join=True)
+    ref = np.load(f"{out}.single.npy")
+    assert np.isfinite(ref).all()
+    for r in range(2):
+        js, je = slab_rows(14, 2, r)
+        assert np.array_equal(np.load(f"{out}.{r}.npy")[:, :, js - 1:je], ref[:, :, js - 1:je]), f"slab rank {r}"
+    out = str(tmp_path / "sets_shard")
+    mp.spawn(_worker, args=(2, 29613, out, "tracer", (14, 14, 6), cfg), nprocs=2, join=True)
+    ref = np.load(f"{out}.single.npy")
+    for r in range(2):
+        assert np.array_equal(np.load(f"{out}.{r}.npy")[:, :, 1:-1], ref[:, :, 1:-1]), f"shard rank {r}"
+
+
 def test_four_latitude_slabs_full_grid(tmp_path):
     """The same on the 102x102x19 grid with four slabs of 25 rows (interior ranks exchange both ways)."""
     import torch.multiprocessing as mp
