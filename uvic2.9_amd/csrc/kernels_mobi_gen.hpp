@@ -621,6 +621,28 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
 #undef BOUT
 }
 
+// work planes of the general kernel (two of the MP_* planes of kernels_mobi.hpp, which it does not use otherwise)
+enum { MPG_OMEGAC = MP_BCT, MPG_AC13B = MP_AC13B };
+/* the carbonate chemistry of a cell (mobi.F:766-789: co2calc_SWS, the 13C fractionation factor of photosynthesis) -- the one
+   expensive part of a level that depends on the level's own inputs only: one thread per (ocean column, level) */
+UVIC_DEV void mobig_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
+  UV_DIMS(c);
+  mobi_params_cp P = UV_CONST_AS(M.P);
+  if (k > c.kmt[X2(i, j)]) return;
+#define TIN(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
+  const double t_in = TIN(k, P->itemp), s_in = 1.e3 * TIN(k, P->isalt) + 35.0;
+  const double dic_in = TIN(k, P->idic), alk_in = TIN(k, P->ialk);
+#undef TIN
+  const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
+  double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
+  mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3, &Omega_c,
+                   &Omega_a, M.carb_shared);
+  const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
+  const double ac13_aq_POC = -0.017 * log10(g_min(g_max(co2star * 1000., 2.), 74.)) + 1.0034;
+  M.pre[(size_t)MPG_AC13B * N3 + X3(i, k, j)] = ac13_aq_POC / ac13_DIC_aq;
+  M.pre[(size_t)MPG_OMEGAC * N3 + X3(i, k, j)] = Omega_c;
+}
+
 /* mobi_driver (mobi.F:519-1482) with the caller's column set-up, iron inputs and 14C (tracer.F:355-545, 853-867) */
 template <int TN15, int TC13, int TCACO3, int TSIL>
 UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
@@ -631,7 +653,7 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
   const size_t ij = X2(i, j), NS = (size_t)imt * jmt;
   double *src = const_cast<double *>(c.src);
   const int kmx = c.kmt[ij];
-  const double twodt = c.c2dtts, co2_in = M.co2ccn;
+  const double twodt = c.c2dtts;
   /* the caller's part, tracer.F:355-390 */
   const double ai = M.aice[ij], hi = M.hice[ij], hs = M.hsno[ij];
   double rctheta = g_max(-1.5, g_min(1.5, M.tlat[ij] / M.radian - St.declin));
@@ -675,14 +697,11 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     if (N15) rn15impo = rn15expo;
     double ac13b = 0.0;
     if (C13 || CACO3) {
-      const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
-      double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
-      mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, co2_in, atmpres, depth, &pH, &co2star, &dco2star,
-                      &pCO2, &dpco2, &CO3, &Omega_c, &Omega_a);
+      /* co2calc_SWS (mobi.F:772) needs the cell's own T, S, DIC and alkalinity only: mobig_pre_cell has solved it for every
+         cell at once and left what this loop uses of it */
+      const double Omega_c = M.pre[(size_t)MPG_OMEGAC * N3 + X3(i, k, j)];
       if (C13) {
-        const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
-        const double ac13_aq_POC = -0.017 * log10(g_min(g_max(co2star * 1000., 2.), 74.)) + 1.0034;
-        ac13b = ac13_aq_POC / ac13_DIC_aq;
+        ac13b = M.pre[(size_t)MPG_AC13B * N3 + X3(i, k, j)];
         rc13impo = rc13expo * P->dztr[k - 1];
         if (CACO3) rcaco3c13impo = rcaco3c13expo * P->dztr[k - 1];
       }

@@ -481,6 +481,13 @@ __global__ void __launch_bounds__(256) UV_TEAM_OCC k_mobi_team(const uvic_ctx c,
 }
 // any other option set (kernels_mobi_gen.hpp): one thread per ocean column, the reference's three loops.  One kernel
 // per option set of SURVEY.md 2c (own register allocation each), one with the flags at run time for anything else.
+__global__ void __launch_bounds__(128) k_mobi_gen_pre(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = gid / w.count + 1;
+  if (k > c.km) return;
+  WET_DECODE(w, gid % w.count);
+  mobig_pre_cell(c, m, i, k, j);
+}
 template <int TN15, int TC13, int TCACO3, int TSIL>
 __global__ void __launch_bounds__(64) k_mobi_gen(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1653,6 +1660,8 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
   const unsigned cells = (unsigned)(((long long)w.count * c.km + 127) / 128), cols = (unsigned)((w.count + 63) / 64);
   if (m.O) {   // an option set other than C: the general column kernel does all of it
     if (w.count > 0) {
+      hipLaunchKernelGGL(k_mobi_gen_pre, dim3(cells), dim3(128), 0, st, c, m, w);   // carbonate chemistry, cell-parallel
+      mark_on(h, "mobi_pre", sid);
       if (h->mobi_key == 4) hipLaunchKernelGGL((k_mobi_gen<0, 0, 1, 0>), dim3(cols), dim3(64), 0, st, c, m, w);         // set F
       else if (h->mobi_key == 15) hipLaunchKernelGGL((k_mobi_gen<1, 1, 1, 1>), dim3(cols), dim3(64), 0, st, c, m, w);   // run/mk.in's set
       else if (h->mobi_key == 3) hipLaunchKernelGGL((k_mobi_gen<1, 1, 0, 0>), dim3(cols), dim3(64), 0, st, c, m, w);    // set C (cross-check)
