@@ -59,8 +59,8 @@ typedef struct {
 // TN15 .. TSIL: 1/0 = the option fixed at compile time (the sets of SURVEY.md §2c are instantiated so: dead branches and
 // their state vanish), -1 = read from the flags at run time (any other combination)
 template <int TN15, int TC13, int TCACO3, int TSIL>
-UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St, double capr, double (&bioin)[X_COUNT], double gl, double bct, double impo, double dzt,
-                         double impo_phos, double dayfrac, double wwd, double nud, double impocaco3, double wwc, double dissk1,
+UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St, double capr, double (&bioin)[X_COUNT], double avej, double avej_D, double avej_Diat, double bct, double impo,
+                         double impo_phos, double wwd, double nud, double impocaco3, double wwc, double dissk1,
                          double impoopl, double wwo, double opl_disk1, double nudop, double nudon, double (&bioout)[X_COUNT], double bctz,
                          double rn15impo, double rc13impo, double ac13b, double rcaco3c13impo, double impofe, double o2,
                          double aou, gsrc_out *out) {
@@ -124,59 +124,9 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
   biodoc13 = g_max(biodoc13, UV_TRCMIN); biodiazc13 = g_max(biodiazc13, UV_TRCMIN);
   biocaco3 = g_max(biocaco3, UV_TRCMIN); biodiat = g_max(biodiat, UV_TRCMIN); biosil = g_max(biosil, UV_TRCMIN);
   bioopl = g_max(bioopl, UV_TRCMIN); biodfe = g_max(biodfe, UV_TRCMIN); biodetrfe = g_max(biodetrfe, UV_TRCMIN);
-  /* iron-dependent Chl:C and initial slope, mobi.F:1961-1996 */
-  double p1 = g_min(biophyt, P->pmax);
-  double p2 = g_max(0.0, biophyt - P->pmax);
-  double kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
-  double deffe = biodfe / (kfevar + biodfe);
-  const double thetamax = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe;
-  const double alpha_O = P->alphamin + (P->alphamax - P->alphamin) * deffe;
-  const double gl_O = gl * thetamax * alpha_O;
-  double kfevar_Diat = 0., deffe_Diat = 0., gl_Diat = 0.;
-  if (SIL) {
-    p1 = g_min(biodiat, O->pmax_Diat);
-    p2 = g_max(0.0, biodiat - O->pmax_Diat);
-    kfevar_Diat = (O->kfemin_Diat * p1 + O->kfemax_Diat * p2) / (p1 + p2);
-    deffe_Diat = biodfe / (kfevar_Diat + biodfe);
-    const double thetamax_Diat = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe_Diat;
-    const double alpha_Diat = P->alphamin + (P->alphamax - P->alphamin) * deffe_Diat;
-    gl_Diat = gl * thetamax_Diat * alpha_Diat;
-  }
-  double deffe_D = biodfe / (P->kfe_D + biodfe);
-  const double thetamax_D = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe_D;
-  const double alpha_D = P->alphamin + (P->alphamax - P->alphamin) * deffe_D;
-  const double gl_D = gl * thetamax_D * alpha_D;
-  /* light, Evans & Parslow, mobi.F:1997-2061 */
-  double psum = biophyt + biodiaz;
-  if (SIL) psum = psum + biodiat;
-  double kirr = -P->kw - P->kc * psum;
-  if (CACO3) kirr = kirr - O->kc_c * biocaco3;
-  const double f1 = exp(kirr * dzt);
-  double jmax = P->abio_P * bct * deffe;
-  const double gd = jmax * dayfrac;
-  double u1 = g_max(gl_O / gd, 1.e-6);
-  double u2 = u1 * f1;
-  double phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
-  double phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
-  const double avej = gd * (phi1 - phi2) / (-kirr * dzt);
+  /* the light-limited growth rates avej, avej_D, avej_Diat (mobi.F:1961-2061) depend on the level's inputs only: mobig_pre_cell */
+  double p1, p2, kfevar, deffe, deffe_D, jmax, jmax_D, kfevar_Diat = 0., deffe_Diat = 0., jmax_Diat = 0.;
   const double gmax = P->gbio * bctz;
-  double jmax_D = g_max(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
-  const double gd_D = g_max(1.e-14, jmax_D * dayfrac);
-  u1 = g_max(gl_D / gd_D, 1.e-6);
-  u2 = u1 * f1;
-  phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
-  phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
-  const double avej_D = gd_D * (phi1 - phi2) / (-kirr * dzt);
-  double jmax_Diat = 0., avej_Diat = 0.;
-  if (SIL) {
-    jmax_Diat = O->abiodiat * bct * deffe_Diat;
-    const double gd_Diat = jmax_Diat * dayfrac;
-    u1 = g_max(gl_Diat / gd_Diat, 1.e-6);
-    u2 = u1 * f1;
-    phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
-    phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
-    avej_Diat = gd_Diat * (phi1 - phi2) / (-kirr * dzt);
-  }
   const double nupt = P->nupt0 * bct;
   const double nupt_D = P->nupt0_D * bct;
   const double nudt = O->nudt0 * bct;
@@ -621,26 +571,132 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
 #undef BOUT
 }
 
-// work planes of the general kernel (two of the MP_* planes of kernels_mobi.hpp, which it does not use otherwise)
-enum { MPG_OMEGAC = MP_BCT, MPG_AC13B = MP_AC13B };
-/* the carbonate chemistry of a cell (mobi.F:766-789: co2calc_SWS, the 13C fractionation factor of photosynthesis) -- the one
-   expensive part of a level that depends on the level's own inputs only: one thread per (ocean column, level) */
+// work planes of the general kernel: (imt,km,jmt) each, in the space of the MP_* / MA_* planes of kernels_mobi.hpp
+enum { MPG_OMEGAC, MPG_AC13B, MPG_BCT, MPG_BCTZ, MPG_NUD, MPG_AOU, MPG_AVEJ, MPG_AVEJD, MPG_AVEJDIAT, MPG_COUNT };
+static_assert(MPG_COUNT <= MP_COUNT + MA_COUNT, "work planes of mobi_store");
+/* What a level needs that depends on the level's own inputs (or, for the light, on the inputs above it) only -- one thread
+   per (ocean column, level), as mobi_pre_cell does for set C: the carbonate chemistry (mobi.F:766-789: co2calc_SWS, the 13C
+   fractionation factor of photosynthesis), the light that reaches the level (tracer.F:381-390, mobi.F:799-820: the running
+   product over the levels above), temperature and oxygen functions (:827-848), the oxygen saturation (tracer.F:456-476) and
+   the light-limited growth rates (mobi_src, mobi.F:1961-2061). */
 UVIC_DEV void mobig_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, int j) {
   UV_DIMS(c);
   mobi_params_cp P = UV_CONST_AS(M.P);
-  if (k > c.kmt[X2(i, j)]) return;
+  mobi_options_cp O = UV_CONST_OPT(M.O);
+  const mobi_step &St = M.S;
+  const size_t ij = X2(i, j);
+  if (k > c.kmt[ij]) return;
+  const int *I = O->im;
+  const int CACO3 = O->caco3, SIL = O->silicon;
 #define TIN(k, n) c.t_taum1[X3(i, k, j) + (size_t)((n)-1) * N3]
-  const double t_in = TIN(k, P->itemp), s_in = 1.e3 * TIN(k, P->isalt) + 35.0;
+#define TNR(k, x) c.t_taum1[X3(i, k, j) + (size_t)(P->tracer_of_mobi[I[x] - 1] - 1) * N3]
+#define TN(k, x) g_max(TNR(k, x), UV_TRCMIN)
+#define PREG(q) M.pre[(size_t)(q) * N3 + X3(i, k, j)]
+  const double t_in = TIN(k, P->itemp), s_in = 1.e3 * TIN(k, P->isalt) + 35.0, o2_in = TIN(k, P->io2) * 1000.;
   const double dic_in = TIN(k, P->idic), alk_in = TIN(k, P->ialk);
+  {
+    const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
+    double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
+    mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3, &Omega_c,
+                     &Omega_a, M.carb_shared);
+    const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
+    const double ac13_aq_POC = -0.017 * log10(g_min(g_max(co2star * 1000., 2.), 74.)) + 1.0034;
+    PREG(MPG_AC13B) = ac13_aq_POC / ac13_DIC_aq;
+    PREG(MPG_OMEGAC) = Omega_c;
+  }
+  /* the caller's light geometry, tracer.F:381-390 */
+  const double ai = M.aice[ij], hi = M.hice[ij], hs = M.hsno[ij];
+  double rctheta = g_max(-1.5, g_min(1.5, M.tlat[ij] / M.radian - St.declin));
+  rctheta = P->kw / sqrt(1. - (1. - g_sq(cos(rctheta))) / g_sq(1.33));
+  double dayfrac = g_min(1., -tan(M.tlat[ij] / M.radian) * tan(St.declin));
+  dayfrac = g_max(1e-12, acos(g_max(-1., dayfrac)) / M.pi);
+  double swr = P->tap * M.dnswr[ij] * 1e-3 * (1. + ai * (exp(-P->ki * (hi + hs)) - 1.));
+  /* attenuation by what lies above: the running product of mobi_driver's level loop, mobi.F:799-816 */
+  double phin = 0.0, caco3in = 0.0;
+  for (int m = 1; m <= k; ++m) {
+    if (CACO3) swr = swr * exp(-P->kc * phin - O->kc_c * caco3in);
+    else swr = swr * exp(-P->kc * phin);
+    phin = g_max(TN(m, X_phyt), UV_TRCMIN) * P->dzt[m - 1] + g_max(TN(m, X_diaz), UV_TRCMIN) * P->dzt[m - 1];
+    if (SIL) phin = phin + g_max(TN(m, X_diat), UV_TRCMIN) * P->dzt[m - 1];
+    if (CACO3) caco3in = caco3in + TNR(m, X_caco3) * P->dzt[m - 1];
+  }
+  const double gl = swr * exp(P->ztt[k - 1] * rctheta);
+  const double bct = UV_POWP(P->bbio, P->cbio * t_in);
+  const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * UV_POWP(P->bbio, P->cbio * t_in);
+  PREG(MPG_BCT) = bct;
+  PREG(MPG_BCTZ) = bctz;
+  PREG(MPG_NUD) = P->nud0 * (0.6 + 0.4 * tanh(0.22 * g_max(o2_in, 0.)));
+  { /* oxygen saturation, tracer.F:456-476 */
+    const double f1 = log((298.15 - t_in) / (273.15 + t_in));
+    const double f2 = f1 * f1, f3 = f2 * f1, f4 = f3 * f1, f5 = f4 * f1;
+    double o2sat = exp(2.00907 + 3.22014 * f1 + 4.05010 * f2 + 4.94457 * f3 - 2.56847E-1 * f4 + 3.88767 * f5 +
+                       s_in * (-6.24523e-3 - 7.37614e-3 * f1 - 1.03410e-2 * f2 - 8.17083E-3 * f3) - 4.88682E-7 * s_in * s_in);
+    o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
+    PREG(MPG_AOU) = o2sat - o2_in;
+  }
+  /* the light-limited growth rates from the level's (clamped) pools, mobi.F:1961-2061 */
+  const double biophyt = TN(k, X_phyt), biodiaz = TN(k, X_diaz), biodfe = TN(k, X_dfe), dzt = P->dzt[k - 1];
+  const double biodiat = SIL ? TN(k, X_diat) : 0.0, biocaco3 = CACO3 ? TN(k, X_caco3) : 0.0;
+  double p1, p2, kfevar, deffe, avej, avej_D, avej_Diat = 0.0;
+  /* iron-dependent Chl:C and initial slope, mobi.F:1961-1996 */
+  p1 = g_min(biophyt, P->pmax);
+  p2 = g_max(0.0, biophyt - P->pmax);
+  kfevar = (P->kfemin * p1 + P->kfemax * p2) / (p1 + p2);
+  deffe = biodfe / (kfevar + biodfe);
+  const double thetamax = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe;
+  const double alpha_O = P->alphamin + (P->alphamax - P->alphamin) * deffe;
+  const double gl_O = gl * thetamax * alpha_O;
+  double kfevar_Diat = 0., deffe_Diat = 0., gl_Diat = 0.;
+  if (SIL) {
+    p1 = g_min(biodiat, O->pmax_Diat);
+    p2 = g_max(0.0, biodiat - O->pmax_Diat);
+    kfevar_Diat = (O->kfemin_Diat * p1 + O->kfemax_Diat * p2) / (p1 + p2);
+    deffe_Diat = biodfe / (kfevar_Diat + biodfe);
+    const double thetamax_Diat = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe_Diat;
+    const double alpha_Diat = P->alphamin + (P->alphamax - P->alphamin) * deffe_Diat;
+    gl_Diat = gl * thetamax_Diat * alpha_Diat;
+  }
+  const double deffe_D = biodfe / (P->kfe_D + biodfe);
+  const double thetamax_D = P->thetamaxlo + (P->thetamaxhi - P->thetamaxlo) * deffe_D;
+  const double alpha_D = P->alphamin + (P->alphamax - P->alphamin) * deffe_D;
+  const double gl_D = gl * thetamax_D * alpha_D;
+  /* light, Evans & Parslow, mobi.F:1997-2061 */
+  double psum = biophyt + biodiaz;
+  if (SIL) psum = psum + biodiat;
+  double kirr = -P->kw - P->kc * psum;
+  if (CACO3) kirr = kirr - O->kc_c * biocaco3;
+  const double f1 = exp(kirr * dzt);
+  const double jmax = P->abio_P * bct * deffe;
+  const double gd = jmax * dayfrac;
+  double u1 = g_max(gl_O / gd, 1.e-6);
+  double u2 = u1 * f1;
+  double phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
+  double phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
+  avej = gd * (phi1 - phi2) / (-kirr * dzt);
+  const double jmax_D = g_max(0., P->abio_P * (bct - P->dbct_D) * deffe_D) * P->jdiar;
+  const double gd_D = g_max(1.e-14, jmax_D * dayfrac);
+  u1 = g_max(gl_D / gd_D, 1.e-6);
+  u2 = u1 * f1;
+  phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
+  phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
+  avej_D = gd_D * (phi1 - phi2) / (-kirr * dzt);
+  double jmax_Diat = 0.;
+  if (SIL) {
+    jmax_Diat = O->abiodiat * bct * deffe_Diat;
+    const double gd_Diat = jmax_Diat * dayfrac;
+    u1 = g_max(gl_Diat / gd_Diat, 1.e-6);
+    u2 = u1 * f1;
+    phi1 = log(u1 + sqrt(1. + u1 * u1)) - (sqrt(1. + u1 * u1) - 1.) / u1;
+    phi2 = log(u2 + sqrt(1. + u2 * u2)) - (sqrt(1. + u2 * u2) - 1.) / u2;
+    avej_Diat = gd_Diat * (phi1 - phi2) / (-kirr * dzt);
+  }
+  PREG(MPG_AVEJ) = avej;
+  PREG(MPG_AVEJD) = avej_D;
+  PREG(MPG_AVEJDIAT) = avej_Diat;
 #undef TIN
-  const double atmpres = 1.0, depth = P->zt[k - 1] / 100.;
-  double pH, co2star, dco2star, pCO2, dpco2, CO3, Omega_c, Omega_a;
-  mobi_co2calc_SWS(t_in, s_in, dic_in, alk_in, M.co2ccn, atmpres, depth, &pH, &co2star, &dco2star, &pCO2, &dpco2, &CO3, &Omega_c,
-                   &Omega_a, M.carb_shared);
-  const double ac13_DIC_aq = -1.0512994e-4 * t_in + 1.011765;
-  const double ac13_aq_POC = -0.017 * log10(g_min(g_max(co2star * 1000., 2.), 74.)) + 1.0034;
-  M.pre[(size_t)MPG_AC13B * N3 + X3(i, k, j)] = ac13_aq_POC / ac13_DIC_aq;
-  M.pre[(size_t)MPG_OMEGAC * N3 + X3(i, k, j)] = Omega_c;
+#undef TNR
+#undef TN
+#undef PREG
 }
 
 /* mobi_driver (mobi.F:519-1482) with the caller's column set-up, iron inputs and 14C (tracer.F:355-545, 853-867) */
@@ -654,13 +710,6 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
   double *src = const_cast<double *>(c.src);
   const int kmx = c.kmt[ij];
   const double twodt = c.c2dtts;
-  /* the caller's part, tracer.F:355-390 */
-  const double ai = M.aice[ij], hi = M.hice[ij], hs = M.hsno[ij];
-  double rctheta = g_max(-1.5, g_min(1.5, M.tlat[ij] / M.radian - St.declin));
-  rctheta = P->kw / sqrt(1. - (1. - g_sq(cos(rctheta))) / g_sq(1.33));
-  double dayfrac = g_min(1., -tan(M.tlat[ij] / M.radian) * tan(St.declin));
-  dayfrac = g_max(1e-12, acos(g_max(-1., dayfrac)) / M.pi);
-  double swr = P->tap * M.dnswr[ij] * 1e-3 * (1. + ai * (exp(-P->ki * (hi + hs)) - 1.));
   const int *I = O->im, *S = O->is;
   const int N15 = TN15 < 0 ? O->n15 : TN15, C13 = TC13 < 0 ? O->c13 : TC13, CACO3 = TCACO3 < 0 ? O->caco3 : TCACO3;
   const int SIL = TSIL < 0 ? O->silicon : TSIL;
@@ -670,10 +719,11 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
 #define TNR(k, x) c.t_taum1[X3(i, k, j) + (size_t)(P->tracer_of_mobi[I[x] - 1] - 1) * N3]
 #define TN(k, x) g_max(TNR(k, x), UV_TRCMIN)
 #define SRC(k, s) src[X3(i, k, j) + (size_t)((s)-1) * N3]
+#define PREG(q) M.pre[(size_t)(q) * N3 + X3(i, k, j)]
 #define SX(k, x) SRC(k, S[x])
-  double expo = 0.0, impo, expo_phos = 0.0, impo_phos, phin = 0.0, prca = 0.0;
+  double expo = 0.0, impo, expo_phos = 0.0, impo_phos, prca = 0.0;
   double rn15impo = 0.0, rn15expo = 0.0, rc13impo = 0.0, rc13expo = 0.0, prca13 = 0.0, expofe = 0.0, impofe;
-  double rcaco3c13impo = 0.0, rcaco3c13expo = 0.0, caco3in = 0.0, impocaco3 = 0.0, expocaco3 = 0.0, dissk1 = 0.0;
+  double rcaco3c13impo = 0.0, rcaco3c13expo = 0.0, impocaco3 = 0.0, expocaco3 = 0.0, dissk1 = 0.0;
   double expoopl = 0.0, impoopl = 0.0, opl_disk1 = 0.0;
   double capr = P->capr;
   double snpzd[X_COUNT], bioin[X_COUNT];
@@ -681,17 +731,8 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     for (int k = 1; k <= km; ++k) SRC(k, s) = 0.0;
   const double redctn = P->redctn;
   for (int k = 1; k <= kmx; ++k) {
-    const double t_in = TIN(k, P->itemp), o2_in = TIN(k, P->io2) * 1000., s_in = 1.e3 * TIN(k, P->isalt) + 35.0;
-    const double dic_in = TIN(k, P->idic), alk_in = TIN(k, P->ialk);
-    double aou_in;
-    { /* oxygen saturation, tracer.F:456-476 */
-      const double f1 = log((298.15 - t_in) / (273.15 + t_in));
-      const double f2 = f1 * f1, f3 = f2 * f1, f4 = f3 * f1, f5 = f4 * f1;
-      double o2sat = exp(2.00907 + 3.22014 * f1 + 4.05010 * f2 + 4.94457 * f3 - 2.56847E-1 * f4 + 3.88767 * f5 +
-                         s_in * (-6.24523e-3 - 7.37614e-3 * f1 - 1.03410e-2 * f2 - 8.17083E-3 * f3) - 4.88682E-7 * s_in * s_in);
-      o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
-      aou_in = o2sat - o2_in;
-    }
+    const double o2_in = TIN(k, P->io2) * 1000., dic_in = TIN(k, P->idic);
+    const double aou_in = PREG(MPG_AOU), bct = PREG(MPG_BCT), bctz = PREG(MPG_BCTZ), nud = PREG(MPG_NUD);
     double rcalpro_k = 0.0, rdissl_k = 0.0, rexpocaco3_k = 0.0, rexpoopl_k = 0.0, bdeni_k = 0.0, nfix_k = 0.0;
     double dic_npzd_sms_k = 0.0, rtdic13_k = 0.0, rtcaco3c13_k = 0.0;
     if (N15) rn15impo = rn15expo;
@@ -699,9 +740,9 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
     if (C13 || CACO3) {
       /* co2calc_SWS (mobi.F:772) needs the cell's own T, S, DIC and alkalinity only: mobig_pre_cell has solved it for every
          cell at once and left what this loop uses of it */
-      const double Omega_c = M.pre[(size_t)MPG_OMEGAC * N3 + X3(i, k, j)];
+      const double Omega_c = PREG(MPG_OMEGAC);
       if (C13) {
-        ac13b = M.pre[(size_t)MPG_AC13B * N3 + X3(i, k, j)];
+        ac13b = PREG(MPG_AC13B);
         rc13impo = rc13expo * P->dztr[k - 1];
         if (CACO3) rcaco3c13impo = rcaco3c13expo * P->dztr[k - 1];
       }
@@ -711,27 +752,16 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
       }
       if (SIL) opl_disk1 = O->opl_disk0;
     }
-    if (CACO3) swr = swr * exp(-P->kc * phin - O->kc_c * caco3in);
-    else swr = swr * exp(-P->kc * phin);
-    phin = g_max(TN(k, X_phyt), UV_TRCMIN) * P->dzt[k - 1] + g_max(TN(k, X_diaz), UV_TRCMIN) * P->dzt[k - 1];
-    if (SIL) phin = phin + g_max(TN(k, X_diat), UV_TRCMIN) * P->dzt[k - 1];
-    if (CACO3) {
-      caco3in = caco3in + TNR(k, X_caco3) * P->dzt[k - 1];
-      impocaco3 = expocaco3 * P->dztr[k - 1];
-    }
-    const double gl = swr * exp(P->ztt[k - 1] * rctheta);
+    if (CACO3) impocaco3 = expocaco3 * P->dztr[k - 1];
     impo = expo * P->dztr[k - 1];
     impo_phos = expo_phos * P->dztr[k - 1];
     impofe = expofe * P->dztr[k - 1];
-    const double bct = UV_POWP(P->bbio, P->cbio * t_in);
     if (SIL) impoopl = expoopl * P->dztr[k - 1];
-    const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * UV_POWP(P->bbio, P->cbio * t_in);
-    const double nud = P->nud0 * (0.6 + 0.4 * tanh(0.22 * g_max(o2_in, 0.)));
     const double nudon = P->nudon0, nudop = P->nudop0;
     /* tnpzd(k,:) is passed as a strided section: copy in, clamp, copy out -- bioin[] holds the clamped level from here on */
     _Pragma("unroll") for (int x = 0; x < X_COUNT; ++x) bioin[x] = I[x] > 0 ? TNR(k, x) : 0.0;
     gsrc_out so;
-    mobig_src<TN15, TC13, TCACO3, TSIL>(P, O, St, capr, bioin, gl, bct, impo, P->dzt[k - 1], impo_phos, dayfrac, P->wd[k - 1], nud, impocaco3, O->wc[k - 1],
+    mobig_src<TN15, TC13, TCACO3, TSIL>(P, O, St, capr, bioin, PREG(MPG_AVEJ), PREG(MPG_AVEJD), PREG(MPG_AVEJDIAT), bct, impo, impo_phos, P->wd[k - 1], nud, impocaco3, O->wc[k - 1],
                  dissk1, impoopl, O->wo[k - 1], opl_disk1, nudop, nudon, snpzd, bctz, rn15impo, rc13impo, ac13b, rcaco3c13impo,
                  impofe, o2_in, aou_in, &so);
     expo = so.expo; expo_phos = so.expo_phos; expofe = so.expofe;
@@ -895,6 +925,7 @@ UVIC_DEV void mobig_column(const uvic_ctx &c, const mobi_dev &M, int i, int j) {
   /* carbon-14, tracer.F:853-867 */
   if (O->is_c14 > 0)
     for (int k = 1; k <= kmx; ++k) SRC(k, O->is_c14) = SRC(k, S[X_dic]) * UV_RC14STD - 3.836e-12 * TIN(k, P->ic14);
+#undef PREG
 #undef SN
 #undef TN
 #undef TNR
