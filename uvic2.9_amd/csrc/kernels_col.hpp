@@ -738,8 +738,10 @@ __device__ __forceinline__ void colfct_wave(const uvic_ctx &c, const double *__r
 // YFIN: pass A has left the final advective flux through the north face of every row (see colfct_wave): the pass reads that
 // of rows r and r-1 and none of what it would otherwise need to form them.
 template <bool ZG, bool YFIN = false>
+// keep_lds: the back substitution also leaves t(tau+1) of the column in LDS (zwork[k][lane], k = 1..km), for a caller
+// that goes on with it (the T,S launch: the convective walk of the same workgroup)
 __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__restrict__ S, double *ework, int code, int n1,
-                                            int fuse_convect) {
+                                            int fuse_convect, bool keep_lds = false) {
   UV_DIMS(c);
   const int lane = threadIdx.x;
   const int i = COL_LANE_I(code), r = COL_LANE_R(code);
@@ -920,6 +922,7 @@ __device__ __forceinline__ void colupd_wave(const uvic_ctx &c, const double *__r
     const double zk = zwork[(size_t)k * 64 + lane] - ework[(size_t)(k + 1) * 64 + lane] * znext;
     bst(b_tp, lb, OC(k, 0), zk);
     if (ic) tp[X3(ic, k, r)] = zk;
+    if (keep_lds) zwork[(size_t)k * 64 + lane] = zk;
     znext = zk;
   }
 #ifdef UV_COL_TIMING

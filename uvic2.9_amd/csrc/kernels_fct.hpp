@@ -593,7 +593,9 @@ UVIC_DEV void convect_column(const uvic_ctx &c, int i, int j) {
 // `tab` (optional): the per-level tables of the walk -- c(km,9), to, so, dztxcl, in this order -- where the caller has staged
 // them (LDS): the walk evaluates two densities per step with the level depending on the data, and every evaluation
 // through global memory is a round trip on a chain others wait for
-UVIC_DEV void convect_ts_column(const uvic_ctx &c, int i, int j, double *colT, double *colS, int stride, const double *tab = nullptr) {
+// `preloaded`: colT/colS hold the column already (pass B of the same workgroup has left it there)
+UVIC_DEV void convect_ts_column(const uvic_ctx &c, int i, int j, double *colT, double *colS, int stride, const double *tab = nullptr,
+                                bool preloaded = false) {
   UV_DIMS(c);
   double *ts = c.t_taup1;
   const double *eosc = tab ? tab : c.c;
@@ -603,6 +605,7 @@ UVIC_DEV void convect_ts_column(const uvic_ctx &c, int i, int j, double *colT, d
   const double *to = tab ? tab + (size_t)9 * km : c.to, *so = tab ? tab + (size_t)10 * km : c.so;
   const double *dz = tab ? tab + (size_t)11 * km : c.dztxcl;
   const int kbo = c.kmt[X2(i, j)];
+  if (!preloaded)
   for (int k0 = 1; k0 <= km; k0 += 8) {   // (eight levels per memory round trip, not one)
     double a[8], b[8];
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {

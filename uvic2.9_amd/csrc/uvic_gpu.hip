@@ -251,7 +251,10 @@ __global__ void __launch_bounds__(256) k_colfct_sha(const uvic_ctx c, const doub
   colfct_sh_body<true>(c, cf, S, g, lds);
 }
 // the forms that leave the final y flux of the north face to pass B instead of the limiter ratios (kernels_col.hpp: YFIN)
-__global__ void __launch_bounds__(256) k_colfct_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL, false, true>(c, cf, S, g); }
+__global__ void __launch_bounds__(256) k_colfct_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  if (g.zero_word && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *g.zero_word = 0;   // (a counter a later kernel of the stream wants cleared)
+  colfct_body<1, PART_ALL, false, true>(c, cf, S, g);
+}
 __global__ void __launch_bounds__(256) k_colfct_sh_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   colfct_sh_body<false, true>(c, cf, S, g, lds);
@@ -296,7 +299,34 @@ __global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_ts(const uvic_ctx 
   extern __shared__ __attribute__((aligned(16))) double lds[];
   colupd_body<false>(c, S, g, lds);
 }
-// ---- the T,S chain of step n and the isopyc chain of step n+1 share three launches -------------------------------
+// Pass B of T and S and the convective walk in one launch: a workgroup is two waves, T and S of the same 64 ocean columns;
+// each solves its column (t(tau+1) stored, and kept in its LDS), then the first wave walks the columns as convect_ts_column
+// does -- from LDS, no reload.  One kernel boundary less on the chain every step waits for.
+__global__ void __launch_bounds__(128) k_colupd_conv_ts(const uvic_ctx c, const double *S, const ColGrid g, int *cvl) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int nblk = g.nwaves;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const size_t per_wave = (size_t)2 * (c.km + 1) * 64;
+  double *tab = lds + 2 * per_wave;
+  for (int q = threadIdx.y * 64 + threadIdx.x; q < 12 * c.km; q += 128) {   // the per-level tables of the walk
+    const int a = q / c.km, k = q % c.km;
+    tab[q] = a < 9 ? c.c[q] : (a == 9 ? c.to[k] : (a == 10 ? c.so[k] : c.dztxcl[k]));
+  }
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
+  int code = 0;
+  if (blk < nblk) {
+    code = g.lanes[(size_t)blk * 64 + threadIdx.x];
+    colupd_wave<false, true>(c, S, lds + (size_t)wv * per_wave, code, c.n0 + wv + 1, 0, true);
+  }
+  __syncthreads();
+  if (blk >= nblk || wv != 0 || !COL_LANE_OWNED(code)) return;
+  const int i = COL_LANE_I(code), j = COL_LANE_R(code);
+  double *zT = lds + (size_t)(c.km + 1) * 64, *zS = lds + per_wave + (size_t)(c.km + 1) * 64;   // zwork[k][lane], k = 1..km
+  convect_ts_column(c, i, j, zT + 64 + threadIdx.x, zS + 64 + threadIdx.x, 64, tab, true);
+  const int wid = (i - 1) + c.imt * (j - 1);
+  if (cvl && c.cv_nseg[wid] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid;
+}
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -1515,18 +1545,29 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       mark_on(h, "begin", 3);
       const WetCols w = wet_range(h, c.js, c.je);
       const size_t cv_lds = (size_t)2 * h->d.km * 64 * 8;
+      // pass B of T,S and the convective walk share a launch when nothing stands between them (the replay fused into pass B
+      // of the others, UVIC_CONV_DECOUPLED=0, also works from the walk's records: same launch)
+      static const bool fuse_env = !getenv("UVIC_TS_FUSE") || atoi(getenv("UVIC_TS_FUSE")) != 0;
+      const bool ts_fuse = fuse_env && h->yfin && ats.total > 0 && bts.total > 0 && w.count > 0 && c.nt_local >= 2;
+      if (ts_fuse) ats.zero_word = h->cv_list;
       if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       mark_on(h, "colfct_ts", 3);
-      // (the list counter of the convective walk is cleared by pass B before it: a memset node costs the chain ~10 us)
-      const bool zero_in_b = h->yfin && bts.total > 0;
-      if (zero_in_b) bts.zero_word = h->cv_list;
-      launch_b(cts, bts, (const double *)S, h->side_ts, true);
-      mark_on(h, "colupd_ts", 3);
-      if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
-      if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
-      mark_on(h, "convect_ts", 3);
+      if (ts_fuse) {
+        const size_t lds_b = ((size_t)2 * 2 * (c.km + 1) * 64 + (size_t)12 * c.km) * 8;
+        hipLaunchKernelGGL(k_colupd_conv_ts, dim3((unsigned)(((bts.nwaves + 7) / 8) * 8)), dim3(64, 2), lds_b, h->side_ts, cts, (const double *)S, bts, h->cv_list);
+        mark_on(h, "colupd_conv_ts", 3);
+      } else {
+        // (the list counter of the convective walk is cleared by pass B before it: a memset node costs the chain ~10 us)
+        const bool zero_in_b = h->yfin && bts.total > 0;
+        if (zero_in_b) bts.zero_word = h->cv_list;
+        launch_b(cts, bts, (const double *)S, h->side_ts, true);
+        mark_on(h, "colupd_ts", 3);
+        if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+        if (w.count > 0)
+          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
+        mark_on(h, "convect_ts", 3);
+      }
       // one barrier packet less on the main stream (~8 us each): the side stream waits for the sources as well before it
       // signals, and the main stream waits for that one event
       if (h->src_from_prefetch && !h->conv_decoupled) {
