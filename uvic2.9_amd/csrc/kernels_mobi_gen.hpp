@@ -193,7 +193,7 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
     double graz_D = g_D * biozoop;
     double morpt_D = nupt_D * biodiaz;
     double morp_D = P->nup_D * biodiaz * biodiaz;
-    double no3upt_D = (0.5 + 0.5 * tanh(biono3 - 5.)) * npp_D;
+    double no3upt_D = UV_HALF_TANH(biono3 - 5.) * npp_D;
     const double dopupt_D = npp_D * dopupt_D_flag;
     const double g_P = gmax * ing_P * biophyt;
     double graz = g_P * biozoop;
