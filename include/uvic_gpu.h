@@ -67,6 +67,25 @@ enum uvic_field {
   UVIC_F_ZW,                                  /* (km) coord.h: depth of T-cell bottoms */
   UVIC_F_TLAT,                                /* S, grdvar.h tlat(imt,jmt) */
   UVIC_F_EDRM2, UVIC_F_EDRS2, UVIC_F_EDRK1, UVIC_F_EDRO1, /* C, u09/mom/tidal_kv.h edr*(imt,km,jmt) */
+  /* baroclinic momentum step, uvic_gpu_state / uvic_gpu_clinic */
+  UVIC_F_RHO,                                 /* C, mw.h rho(imt,km,jsmw:jmw): product of uvic_gpu_state */
+  UVIC_F_UM1, UVIC_F_UM2,                     /* C, u(:,:,:,1:2,taum1) */
+  UVIC_F_UP1, UVIC_F_UP2,                     /* C, u(:,:,:,1:2,taup1): internal-mode velocities, product of uvic_gpu_clinic */
+  UVIC_F_ZU,                                  /* (imt,jmt,2) emode.h zu: vertically averaged forcing, product */
+  UVIC_F_GRAD_P,                              /* (imt,km,jmt,2) mw.h grad_p, product */
+  UVIC_F_SMF,                                 /* (imt,jmt,2) mw.h smf: wind stress (setvbc.F:163-164) */
+  UVIC_F_KMU,                                 /* int32 (imt,jmt) levind.h */
+  UVIC_F_HR,                                  /* S, emode.h hr: reciprocal depth of U columns */
+  UVIC_F_CORI,                                /* (imt,jmt,2) grdvar.h */
+  UVIC_F_VISC_CEU, UVIC_F_AMC_NORTH, UVIC_F_AMC_SOUTH, /* C, u09/common/hmixc.h (O_anisotropic_viscosity; a model without
+                                               * that option fills them with am, amc_north(jrow), amc_south(jrow)) */
+  UVIC_F_DXU2R, UVIC_F_DXMETR, UVIC_F_DUW, UVIC_F_DUE,                 /* (imt) grdvar.h */
+  UVIC_F_DYU2R, UVIC_F_DYU4R, UVIC_F_CSUR, UVIC_F_DUS, UVIC_F_DUN, UVIC_F_CSUDYU2R, /* (jmt) grdvar.h */
+  UVIC_F_ADVMET,                              /* (jmt,2) grdvar.h */
+  UVIC_F_AM3, UVIC_F_AM4,                     /* (jmt), (jmt,2) hmixc.h */
+  UVIC_F_SBC_GU, UVIC_F_SBC_GV, UVIC_F_SBC_SU, UVIC_F_SBC_SV, /* S: the sbc planes igu, igv (isbcu) and isu, isv (asbcu) */
+  UVIC_F_SPSIN, UVIC_F_SPCOS,                 /* (imt) cpolar.h: rotation to polar-stereographic components in filuv */
+  UVIC_F_PHI,                                 /* (jmt) coord.h: latitude of the U rows in radians (its sign, filuv.F:66-67) */
   UVIC_F_COUNT
 };
 
@@ -308,6 +327,30 @@ int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p);
  * bottom level, the previous value elsewhere, plus K33.  Call after uvic_gpu_isopyc of the same step with
  * uvic_params.diff_cbt_has_k33 = 1 (isopyc then leaves diff_cbt to this call). */
 int uvic_gpu_vmixc(uvic_gpu *h);
+
+/* ---- baroclinic momentum step -------------------------------------------
+ * scalars of `clinic`: scalar.h c2dtuv, grav, rho0r, cdbot; vmixc.h kappa_m (O_constvmix: visc_cbu = kappa_m,
+ * u09/mom/vmixc.F:85) */
+typedef struct uvic_clinic_params {
+  double c2dtuv, grav, rho0r, kappa_m, cdbot;
+} uvic_clinic_params;
+int uvic_gpu_set_clinic_params(uvic_gpu *h, const uvic_clinic_params *p);
+/* replaces `call state (t(1,1,1,1,tau), t(1,1,1,2,tau), rho(1,1,jsmw), max(jsmw,js), je, istrt-1, iend+1)`
+ * (u09/mom/loadmw.F:154; source/mom/state.F:1-41): UVIC_F_RHO on rows 2..jmt from T and S of UVIC_F_T_TAU */
+int uvic_gpu_state(uvic_gpu *h);
+/* replaces `call clinic (joff, js, je, is, ie)` (source/mom/mom.F:395; u09/mom/clinic.F:24-560 with fdifm.h,
+ * options O_consthmix O_constvmix O_anisotropic_viscosity O_stream_function O_cyclic O_fourfil O_ice_evp) for one
+ * memory window, rows 2..jmt-1: UVIC_F_UP1/UP2 (internal-mode velocities at tau+1, vertical mean removed, polar
+ * filter applied when uvic_gpu_set_filter_u was called) and UVIC_F_ZU from UVIC_F_RHO, UVIC_F_U1/U2 (tau),
+ * UVIC_F_UM1/UM2 (tau-1), UVIC_F_ADV_VET/VNT/VBT and UVIC_F_SMF.  What `clinic` reads from its neighbours in mom.F's
+ * loop is evaluated inside: the U-cell advective velocities (source/mom/adv_vel.F:150-231) and the bottom drag
+ * (u09/mom/setvbc.F:170-194).  sbc_flags: bit 0 = accumulate the ice/atmosphere surface velocities (isbcu, asbcu,
+ * clinic.F:729-895; `eots`), bit 1 = osegs, bit 2 = osege; rts = 1/ntspos. */
+int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts);
+/* polar filter of the velocities: replaces `call filuv (joff, js, je)` (clinic.F:500; source/common/filuv.F with
+ * O_fourfil O_cyclic).  Strips come from UVIC_F_KMU by findex's rule, rows jfrst..jfu1 and jfu2..jmt-1, reference
+ * row jfu0 (index.h; u09/common/setcom.F:80-86).  jfrst > jmt switches it off. */
+int uvic_gpu_set_filter_u(uvic_gpu *h, double pi, int jfrst, int jfu0, int jfu1, int jfu2, int lsegf);
 
 /* ---- polar Fourier filter of the tracers ---------------------------------
  * replaces `call filt (joff, js, je)` inside tracer (u09/mom/tracer.F:1245; source/common/filt.F,

@@ -61,6 +61,14 @@ CONFIGS = {
     "s37": BASE + ("O_mobi O_carbon O_mobi_alk O_mobi_o2 O_mobi_nitrogen O_mobi_caco3 "
                    "O_mobi_iron O_mobi_silicon O_mobi_nitrogen_15 O_carbon_13 "
                    "O_carbon_14").split(),
+    # momentum row: physics only, nt=2, with the three options of run/mk.in that shape
+    # `clinic` (explicit Coriolis term, 3-D viscosity coefficients, surface velocities handed to the ice model)
+    "m2": BASE + "O_stream_function O_anisotropic_viscosity O_ice_evp".split(),
+}
+
+# sources compiled for some configurations only
+EXTRA_SOURCES = {
+    "m2": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F"],
 }
 
 HDR_DIRS = ["source/common", "source/mom", "source/embm", "source/ice",
@@ -122,7 +130,7 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
     for d in reversed(HDR_DIRS):
         incs += ["-I", str(REF / d)]
     objs = []
-    for s in SOURCES:
+    for s in SOURCES + EXTRA_SOURCES.get(cfg, []):
         src = REF / s
         r = run(["cpp", "-traditional", "-P", *incs, *defs, str(src)])
         text = patch(r.stdout)

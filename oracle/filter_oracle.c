@@ -301,3 +301,112 @@ int orc_filt(double *t, int imt, int km, int jmt, int nt, const int *kmt, const 
   filtr_free(f);
   return rc;
 }
+
+/* ---- filuv.F:1-196 on u(:,:,:,1:2,taup1), rows js..je (joff = 0), O_fourfil O_cyclic ---------------
+ * u1, u2 (imt,km,jmt) in place.  isuf, ieuf (jmtfil,lsegf,km) from orc_findex on kmu with jfu1, jfu2. */
+int orc_filuv(double *u1, double *u2, int imt, int km, int jmt, const int *kmu, const double *csu, const double *csur,
+              const double *phi, const double *spsin, const double *spcos, const double *dzt, const double *hr, double pi,
+              int jfrst, int jfu0, int jfu1, int jfu2, int lsegf, int jmtfil, const int *isuf, const int *ieuf, int js,
+              int je) {
+#define U1(i, k, j) u1[(size_t)((i)-1) + (size_t)imt * ((size_t)((k)-1) + (size_t)km * ((j)-1))]
+#define U2(i, k, j) u2[(size_t)((i)-1) + (size_t)imt * ((size_t)((k)-1) + (size_t)km * ((j)-1))]
+#define ISUF(jj, l, k) isuf[(size_t)((jj)-1) + (size_t)jmtfil * ((size_t)((l)-1) + (size_t)lsegf * ((k)-1))]
+#define IEUF(jj, l, k) ieuf[(size_t)((jj)-1) + (size_t)jmtfil * ((size_t)((l)-1) + (size_t)lsegf * ((k)-1))]
+  const int imtm1 = imt - 1, imtm2 = imt - 2, jskpu = jfu2 - jfu1;
+  filtr_state *f = filtr_new(imt, pi);
+  double *t1 = (double *)calloc(imt + 2, 8), *t2 = (double *)calloc(imt + 2, 8);
+  int rc = 0;
+  /* filuv.F:45-49 */
+  for (int j = js; j <= je; ++j)
+    for (int k = 1; k <= km; ++k) {
+      U1(1, k, j) = U1(imtm1, k, j); U1(imt, k, j) = U1(2, k, j);
+      U2(1, k, j) = U2(imtm1, k, j); U2(imt, k, j) = U2(2, k, j);
+    }
+  int m = 2, n = 0;
+  for (int j = js; j <= je && !rc; ++j) {
+    const int jrow = j;
+    if ((jrow > jfu1 && jrow < jfu2) || jrow < jfrst) continue;
+    int jj = jrow - jfrst + 1;
+    if (jrow >= jfu2) jj = jj - jskpu + 1;
+    double fx = -1.0;
+    if (phi[jrow - 1] > 0.0) fx = 1.0;
+    int isave = 0, ieave = 0;
+    for (int l = 1; l <= lsegf && !rc; ++l)
+      for (int k = 1; k <= km && !rc; ++k) {
+        if (ISUF(jj, l, k) == 0) continue;
+        const int is = ISUF(jj, l, k), ie = IEUF(jj, l, k);
+        int iredo = 1;
+        const int im = ie - is + 1;
+        if (is != isave || ie != ieave) {
+          iredo = 0;
+          isave = is;
+          ieave = ie;
+          if (im != imtm2) {
+            m = 2;
+            n = (int)lround(im * csu[jrow - 1] * csur[jfu0 - 1]);
+          } else {
+            m = 3;
+            n = (int)lround(im * csu[jrow - 1] * csur[jfu0 - 1] * 0.5);
+          }
+        }
+        const int ism1 = is - 1;
+        int iea = ie;
+        if (ie >= imt) iea = imtm1;
+        for (int i = is; i <= iea; ++i) {
+          t1[i - ism1] = -fx * U1(i, k, j) * spsin[i - 1] - U2(i, k, j) * spcos[i - 1];
+          t2[i - ism1] = fx * U1(i, k, j) * spcos[i - 1] - U2(i, k, j) * spsin[i - 1];
+        }
+        int ieb = 0, ii = 0;
+        if (ie >= imt) {
+          ieb = ie - imtm2;
+          ii = imtm1 - is;
+          for (int i = 2; i <= ieb; ++i) {
+            t1[i + ii] = -fx * U1(i, k, j) * spsin[i - 1] - U2(i, k, j) * spcos[i - 1];
+            t2[i + ii] = fx * U1(i, k, j) * spcos[i - 1] - U2(i, k, j) * spsin[i - 1];
+          }
+        }
+        if (filtr(f, t1, im, m, n, iredo) || filtr(f, t2, im, m, n, 1)) { rc = 1; break; }
+        for (int i = is; i <= iea; ++i) {
+          U1(i, k, j) = fx * (-t1[i - ism1] * spsin[i - 1] + t2[i - ism1] * spcos[i - 1]);
+          U2(i, k, j) = -t1[i - ism1] * spcos[i - 1] - t2[i - ism1] * spsin[i - 1];
+        }
+        if (ie >= imt)
+          for (int i = 2; i <= ieb; ++i) {
+            U1(i, k, j) = fx * (-t1[i + ii] * spsin[i - 1] + t2[i + ii] * spcos[i - 1]);
+            U2(i, k, j) = -t1[i + ii] * spcos[i - 1] - t2[i + ii] * spsin[i - 1];
+          }
+      }
+    if (isave != 0 && ieave != 0) { /* filuv.F:155-181: the vertical mean again, then the mask */
+      for (int i = 1; i <= imt; ++i) { t1[i] = 0.0; t2[i] = 0.0; }
+      for (int k = 1; k <= km; ++k)
+        for (int i = 1; i <= imt; ++i) {
+          t1[i] = t1[i] + U1(i, k, j) * dzt[k - 1];
+          t2[i] = t2[i] + U2(i, k, j) * dzt[k - 1];
+        }
+      for (int i = 1; i <= imt; ++i) {
+        t1[i] = t1[i] * hr[(size_t)(i - 1) + (size_t)imt * (jrow - 1)];
+        t2[i] = t2[i] * hr[(size_t)(i - 1) + (size_t)imt * (jrow - 1)];
+      }
+      for (int k = 1; k <= km; ++k)
+        for (int i = 1; i <= imt; ++i) {
+          U1(i, k, j) = U1(i, k, j) - t1[i];
+          U2(i, k, j) = U2(i, k, j) - t2[i];
+        }
+      for (int k = 1; k <= km; ++k)
+        for (int i = 1; i <= imt; ++i) {
+          const double mask = (kmu[(size_t)(i - 1) + (size_t)imt * (jrow - 1)] >= k) ? 1.0 : 0.0;
+          U1(i, k, j) = U1(i, k, j) * mask;
+          U2(i, k, j) = U2(i, k, j) * mask;
+        }
+    }
+  }
+  /* clinic.F:506-509 */
+  for (int j = js; j <= je; ++j)
+    for (int k = 1; k <= km; ++k) {
+      U1(1, k, j) = U1(imtm1, k, j); U1(imt, k, j) = U1(2, k, j);
+      U2(1, k, j) = U2(imtm1, k, j); U2(imt, k, j) = U2(2, k, j);
+    }
+  free(t1); free(t2);
+  filtr_free(f);
+  return rc;
+}

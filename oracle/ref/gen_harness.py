@@ -25,7 +25,7 @@ HEADERS = [
     "mw.h", "isopyc.h", "grdvar.h", "coord.h", "levind.h", "vmixc.h",
     "hmixc.h", "accel.h", "scalar.h", "switch.h", "state.h", "tmngr.h",
     "csbc.h", "diaga.h", "ice.h", "atm.h", "cembm.h", "mobi.h", "emode.h",
-    "cregin.h", "timeavgs.h", "index.h", "cfilt.h", "calendar.h", "tidal_kv.h",
+    "cregin.h", "timeavgs.h", "index.h", "cfilt.h", "calendar.h", "tidal_kv.h", "cpolar.h",
 ]
 
 TYPECODE = {"real": 1, "integer": 2, "logical": 3}

@@ -224,6 +224,77 @@ class RefOcean:
         out[:, :, 1:g.jmt - 1] = self.v["diff_cbt"]
         return out
 
+    # -- baroclinic momentum step (configuration "m2" of build_ref.py) ----------
+    def set_momentum(self, mom):
+        """COMMON data of `clinic` that the tracer path does not use: u(tau-1), wind stress (through sbc, as
+        setvbc reads it), the factors setmom.F computes once and the coefficients hmixc.F leaves on its first call."""
+        g, v, S = self.ocean.grid, self.v, self.ref.set
+        for n in ("dxmetr", "duw", "due", "dus", "dun"):
+            v[n][...] = getattr(g, n)
+        for n in ("cori", "am3", "am4", "advmet", "hr", "visc_ceu", "amc_north", "amc_south"):
+            v[n][...] = getattr(mom, n)
+        S("am", mom.am); S("kappa_m", mom.kappa_m); S("cdbot", mom.cdbot)
+        S("dtuv", mom.dtuv); S("c2dtuv", 2.0 * mom.dtuv); S("acor", 0.0)
+        v["visc_cbu"][...] = mom.kappa_m        # u09/mom/vmixc.F:85 (O_constvmix)
+        v["u"][:, :, :, :, 0] = mom.u_taum1
+        if int(self.ref.get("itaux")) == 0:      # no coupler initialisation here: give the stresses two free sbc planes
+            S("itaux", v["sbc"].shape[2] - 1); S("itauy", v["sbc"].shape[2])
+        v["sbc"][:, :, int(self.ref.get("itaux")) - 1] = mom.smf[..., 0]
+        v["sbc"][:, :, int(self.ref.get("itauy")) - 1] = mom.smf[..., 1]
+        self.mom = mom
+
+    def set_filter_u(self, flt):
+        """Switch `filuv` inside clinic on: U rows as setcom.F computes them, strips by the reference's findex on kmu
+        (setmom.F:730), rotation factors of setcom.F:55-70."""
+        S, v = self.ref.set, self.v
+        if flt.jmtfil != v["isuf"].shape[0] or flt.lsegf != v["isuf"].shape[1]:
+            raise ValueError("filter dimensions differ from the reference build (index.h: jmtfil=50, lsegf=20)")
+        S("jfrst", flt.jfrst); S("jfu0", flt.jfu0); S("jfu1", flt.jfu1); S("jfu2", flt.jfu2); S("jskpu", flt.jskpu)
+        S("njtbfu", flt.njtbfu)
+        v["spsin"][...] = flt.spsin
+        v["spcos"][...] = flt.spcos
+        v["isuf"][...] = 0
+        v["ieuf"][...] = 0
+        g = self.ocean.grid
+        self.ref.call("findex", v["kmu"], flt.jmtfil, g.km, flt.jfu1, flt.jfu2, g.imt, v["isuf"], v["ieuf"])
+        return np.array(v["isuf"], order="F"), np.array(v["ieuf"], order="F")
+
+    def state(self):
+        """rho as loadmw.F:154 computes it: rows 2..jmt, all columns; returned over all jmt rows (row 1 zero)."""
+        g, v = self.ocean.grid, self.v
+        t = v["t"]
+        T = np.array(t[:, :, :, 0, 1], order="F"); Sa = np.array(t[:, :, :, 1, 1], order="F")
+        self.ref.call("state", T, Sa, v["rho"], 2, g.jmt, 1, g.imt)
+        rho = np.zeros((g.imt, g.km, g.jmt), order="F"); rho[:, :, 1:] = v["rho"]
+        return rho
+
+    def adv_vel_u(self):
+        """adv_vel.F (all of it) as called at mom.F:332; returns adv_veu, adv_vnu, adv_vbu over all jmt rows."""
+        g, v = self.ocean.grid, self.v
+        self.ref.call("adv_vel", 0, 1, g.jmt, 2, g.imt - 1)
+        veu = np.zeros((g.imt, g.km, g.jmt), order="F"); veu[:, :, 1:g.jmt - 1] = v["adv_veu"]
+        vnu = np.zeros((g.imt, g.km, g.jmt), order="F"); vnu[:, :, :g.jmt - 1] = v["adv_vnu"]
+        vbu = np.zeros((g.imt, g.km + 1, g.jmt), order="F"); vbu[:, :, 1:g.jmt - 1] = v["adv_vbu"]
+        return veu, vnu, vbu
+
+    def setvbc(self):
+        """u09/mom/setvbc.F as called at mom.F:375: smf from sbc, bmf from u(tau-1); both (imt,jmt,2)."""
+        g = self.ocean.grid
+        self.ref.call("setvbc", 0, 2, g.jmt - 1, 2, g.imt - 1)
+        return np.array(self.v["smf"], order="F"), np.array(self.v["bmf"], order="F")
+
+    def clinic(self):
+        """u09/mom/clinic.F as called at mom.F:395.  Returns u(tau+1) (imt,km,jmt,2), zu (imt,jmt,2) and
+        grad_p (imt,km,jmt,2; rows 1 and jmt zero)."""
+        g, v = self.ocean.grid, self.v
+        saved = self._silence()
+        try:
+            self.ref.call("clinic", 0, 2, g.jmt - 1, 2, g.imt - 1)
+        finally:
+            self._restore(saved)
+        gp = np.zeros((g.imt, g.km, g.jmt, 2), order="F"); gp[:, :, 1:g.jmt - 1] = v["grad_p"]
+        return np.array(v["u"][..., 2], order="F"), np.array(v["zu"], order="F"), gp
+
     def step(self, c2dtts=None):
         if c2dtts is not None:
             self.ref.set("c2dtts", c2dtts)

@@ -15,6 +15,8 @@ Fixtures
                                        K33 and the GM velocities
   tests/golden/run_<cfg>_<grid>.npz    t after N leapfrog steps (mixing step every
                                        nmix-th) and the tbar/travar integrals
+  tests/golden/clinic_m2_<grid>.npz    rho of the reference's state; grad_p, zu and u(tau+1) of its clinic, without
+                                       and with the polar filter filuv (momentum step)
   tests/golden/prep_<cfg>_<grid>.npz   outputs of the reference's adv_vel, vmixc (tidal
                                        mixing + K33 after isopyc), findex and of one
                                        isopyc+tracer step with the polar filter on
@@ -151,7 +153,25 @@ def prep_fixture(cfg, imt, jmt, km):
     print("wrote prep", cfg, imt, jmt, km)
 
 
+def clinic_fixture(imt, jmt, km):
+    """Outputs of the reference's state, clinic (with and without filuv) on the synthetic ocean, configuration "m2"."""
+    oc = synthetic.make_ocean("m2", imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u)
+    flt = synthetic.make_filter_u(oc.grid, km)
+    ro = refdriver.RefOcean(oc)
+    ro.set_momentum(mom)
+    rho = ro.state()
+    ro.adv_vel_u()
+    ro.setvbc()
+    up, zu, gp = ro.clinic()
+    ro.set_filter_u(flt)
+    upf, _, _ = ro.clinic()
+    np.savez_compressed(HERE / f"clinic_m2_{imt}x{jmt}x{km}.npz", rho=rho, grad_p=gp, zu=zu, u_taup1=up, u_taup1_filtered=upf)
+    print("wrote clinic", imt, jmt, km, "filter changed", int((up != upf).sum()), "values")
+
+
 if __name__ == "__main__":
+    clinic_fixture(14, 14, 6)
     prep_fixture("p2", 14, 14, 6)
     eos_fixture()
     mobi_fixture()

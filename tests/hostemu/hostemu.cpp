@@ -17,6 +17,7 @@
 #include "../../uvic2.9_amd/csrc/kernels_isopyc.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_mobi.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_prep.hpp"
+#include "../../uvic2.9_amd/csrc/kernels_clinic.hpp"
 #include "../../uvic2.9_amd/csrc/kernels_filter.hpp"
 #include "../../uvic2.9_amd/csrc/filter_host.hpp"
 
@@ -223,4 +224,48 @@ extern "C" void emu_mobi_team(const uvic_ctx *cp, const uvic_mobi_params *P, con
   for (int j = c.js; j <= c.je; ++j)
     for (int k = 1; k <= c.km; ++k)
       for (int i = 2; i <= c.imt - 1; ++i) mobi_post_cell(c, M, i, k, j);
+}
+
+// baroclinic momentum step (kernels_clinic.hpp): the launch order of uvic_gpu_state / uvic_gpu_clinic
+extern "C" int emu_mom_ctx_size(void) { return (int)sizeof(uvic_mom_ctx); }
+extern "C" void emu_state(const uvic_mom_ctx *mp) {
+  const uvic_mom_ctx &m = *mp;
+  for (int j = 2; j <= m.jmt; ++j)
+    for (int k = 1; k <= m.km; ++k)
+      for (int i = 1; i <= m.imt; ++i) state_cell(m, i, k, j);
+}
+extern "C" void emu_clinic(const uvic_mom_ctx *mp) {
+  const uvic_mom_ctx &m = *mp;
+  for (int j = m.js; j <= m.je; ++j)
+    for (int i = 2; i <= m.imt - 1; ++i) clinic_gradp_column(m, i, j);
+  for (int j = m.js; j <= m.je; ++j)
+    for (int k = 1; k <= m.km; ++k)
+      for (int i = 2; i <= m.imt - 1; ++i) clinic_tend_cell(m, i, k, j);
+  for (int j = m.js; j <= m.je; ++j)
+    for (int i = 2; i <= m.imt - 1; ++i) clinic_finish_column(m, i, j);
+}
+extern "C" void emu_sbcu(const uvic_mom_ctx *mp, int flags, double rts) {
+  const uvic_mom_ctx &m = *mp;
+  for (int j = m.js; j <= m.je; ++j)
+    for (int i = 2; i <= m.imt - 1; ++i) clinic_sbcu_cell(m, i, j, flags, rts);
+}
+
+// polar filter of the velocities: the host-side set-up of the library and its two kernels
+extern "C" int emu_filuv(const uvic_mom_ctx *mp, const double *csu, const double *phi, const double *spsin, const double *spcos, double pi,
+                         int jfrst, int jfu0, int jfu1, int jfu2, int lsegf, int nthreads) {
+  const uvic_mom_ctx &m = *mp;
+  FilterSetup fs;
+  std::vector<int> rows;
+  std::string err;
+  if (int rc = filter_build_u(m.imt, m.jmt, m.km, m.kmu, csu, m.csur, phi, pi, jfrst, jfu0, jfu1, jfu2, lsegf, fs, rows, err)) return rc;
+  std::vector<double> lds((size_t)3 * nthreads + 4);
+  HostEnv env{nthreads};
+  for (auto &it : fs.items) {
+    if (it.im > nthreads) return 3;
+    std::fill(lds.begin(), lds.end(), -7.0e33);
+    filuv_block(env, m.imt, m.km, it, fs.mats.data(), spsin, spcos, m.up1, m.up2, lds.data());
+  }
+  for (int j : rows)
+    for (int i = 2; i <= m.imt - 1; ++i) filuv_mean_column(m.imt, m.km, i, j, m.kmu, m.hr, m.dzt, m.up1, m.up2);
+  return 0;
 }

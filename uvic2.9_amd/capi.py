@@ -47,11 +47,17 @@ EXPORTS = [
     "uvic_gpu_step_lookahead", "uvic_gpu_download_level", "uvic_gpu_set_mobi_step", "uvic_gpu_pin_host", "uvic_gpu_halo_elems", "uvic_gpu_halo_buffer", "uvic_gpu_halo_pack", "uvic_gpu_halo_unpack",
     "uvic_gpu_step_lookahead_at", "uvic_gpu_prefetch_sources_at", "uvic_gpu_set_host_sync", "uvic_gpu_sbc_config",
     "uvic_gpu_sbc_transfer", "uvic_gpu_overlay_step",
+    "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
 ]
 
 
 class Dims(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("imt", "jmt", "km", "nt", "nsrc", "ntnpzd")]
+
+
+class ClinicParams(ctypes.Structure):
+    """uvic_clinic_params (include/uvic_gpu.h)."""
+    _fields_ = [(n, ctypes.c_double) for n in ("c2dtuv", "grav", "rho0r", "kappa_m", "cdbot")]
 
 
 class Params(ctypes.Structure):
@@ -115,6 +121,10 @@ def load():
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     lib.uvic_gpu_set_vmix_params.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_set_filter.argtypes = [ctypes.c_void_p, ctypes.c_double] + [ctypes.c_int] * 5
+    lib.uvic_gpu_set_filter_u.argtypes = [ctypes.c_void_p, ctypes.c_double] + [ctypes.c_int] * 5
+    lib.uvic_gpu_set_clinic_params.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.uvic_gpu_state.argtypes = [ctypes.c_void_p]
+    lib.uvic_gpu_clinic.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
     lib.uvic_gpu_profile_live.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_download_level.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.uvic_gpu_set_mobi_step.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 4

@@ -149,6 +149,8 @@ def _build(name, opts):
 OPTION_SETS = {
     # BASELINE config 1: physics only
     "p2": _build("p2", []),
+    # the same two tracers; names the oracle/_ref build that also holds the momentum routines (`clinic`, §8f rank 4)
+    "m2": _build("m2", []),
     # BASELINE config 4 == SURVEY option set C (nt=30, nsrc=28, ntnpzd=25)
     "c30": _build("c30", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen",
                           "carbon_13", "carbon_14", "mobi_nitrogen_15"]),

@@ -53,11 +53,11 @@ struct Tables {
   }
 };
 
-// filtr.F:226-390 for mm = 1 or 3; F is compact: F[(i-1)*im + (j-1)] = ftarr((i-1)*imt + j)
+// filtr.F:226-390 for mm = 1, 2 or 3; F is compact: F[(i-1)*im + (j-1)] = ftarr((i-1)*imt + j)
 inline bool build_operator(const Tables &T, int im, int mm, int n, std::vector<double> &F) {
   const int nmax = (mm == 1) ? n - 1 : n, nmaxp1 = nmax + 1;
   const double cc1 = 0.5 * (double)nmax + 0.25, cc2 = (double)nmax + 0.5;
-  const int lcy = 2 * im, lh = lcy / 2, lhm1 = lh - 1, lqm = (lh - 1) / 2, lcyp1 = lcy + 1, imx4 = im * 4, imx8 = im * 8;
+  const int lcy = (mm == 2) ? 2 * (im + 1) : 2 * im, lh = lcy / 2, lhm1 = lh - 1, lqm = (lh - 1) / 2, lcyp1 = lcy + 1, imx4 = im * 4, imx8 = im * 8;
   std::vector<double> cosine(imx8 + 2, 0.0), denom(imx4 + 2, 0.0), temp(imx4 + 2, 0.0), cof(imx8 + 2, 0.0);
   std::vector<int> indx(imx8 + 2, 0);
   const int jbase = T.icbase[lh];
@@ -105,6 +105,11 @@ inline bool build_operator(const Tables &T, int im, int mm, int n, std::vector<d
         FT(j, i) = (cof[i - j + ioff1] - cof[i - j + ioff2]) * denom[i - j + ioff1] +
                    (cof[i + j - 1] - cof[imx4 + i + j - 1]) * denom[i + j - 1] - 0.5;
     for (int j = 1; j <= im; ++j) FT(j, j) = FT(j, j) + cc1;
+  } else if (mm == 2) {
+    for (int j = 1; j <= im; ++j)
+      for (int i = 1; i <= im; ++i)
+        FT(j, i) = (cof[i - j + ioff1] - cof[i - j + ioff2]) * denom[i - j + ioff1] - (cof[i + j] - cof[imx4 + i + j]) * denom[i + j];
+    for (int j = 1; j <= im; ++j) FT(j, j) = FT(j, j) + cc1;
   } else {
     const double genadj = (2 * n == im) ? 0.5 : 0.0;
     for (int j = 1; j <= im; ++j)
@@ -118,6 +123,116 @@ inline bool build_operator(const Tables &T, int im, int mm, int n, std::vector<d
 }
 
 }  // namespace uvic_filter
+
+// findex.F:22-66 (O_cyclic) for one row: ocean strips of every level, kept per (l,k); kxx = kmt or kmu
+inline bool find_strips(int imt, int km, const int *kxx, int jrow, int lsegf, std::vector<int> &isf, std::vector<int> &ief) {
+#define KXX(i, j) kxx[(size_t)((i)-1) + (size_t)imt * ((j)-1)]
+  const int imax = imt;
+  std::vector<int> iis(lsegf + 2), iie(lsegf + 2);
+  isf.assign((size_t)lsegf * km, 0);
+  ief.assign((size_t)lsegf * km, 0);
+  for (int k = 1; k <= km; ++k) {
+    for (int l = 1; l <= lsegf + 1; ++l) { iis[l] = 0; iie[l] = 0; }
+    int l = 1;
+    if (KXX(2, jrow) >= k) iis[1] = 2;
+    for (int i = 2; i <= imax - 1; ++i) {
+      if (l > lsegf + 1) return false;
+      if (KXX(i - 1, jrow) < k && KXX(i, jrow) >= k) iis[l] = i;
+      if (KXX(i, jrow) >= k && KXX(i + 1, jrow) < k) {
+        if (i != iis[l] || (i == 2 && KXX(1, jrow) >= k)) {
+          iie[l] = i;
+          l = l + 1;
+        } else {
+          iis[l] = 0;
+        }
+      }
+    }
+    if (KXX(imax - 1, jrow) >= k && KXX(imax, jrow) >= k) {
+      if (l > lsegf + 1) return false;
+      iie[l] = imax - 1;
+      l = l + 1;
+    }
+    int lm = l - 1;
+    if (lm > 1 && iis[1] == 2 && iie[lm] == imax - 1 && KXX(1, jrow) >= k) {
+      iis[1] = iis[lm];
+      iie[1] = iie[1] + imax - 2;
+      iis[lm] = 0;
+      iie[lm] = 0;
+      lm = lm - 1;
+    }
+    if (lm > lsegf) return false;
+    for (l = 1; l <= lsegf; ++l) {
+      isf[(size_t)(l - 1) * km + (k - 1)] = iis[l];
+      ief[(size_t)(l - 1) * km + (k - 1)] = iie[l];
+    }
+  }
+#undef KXX
+  return true;
+}
+
+// the velocity filter: strips of kmu for rows jfrst..jmt-1 outside (jfu1, jfu2), filter type and wavenumber as
+// filuv.F:69-98 (type 2 for a strip between coasts, type 3 for a full circle), operators, and the rows that hold a strip
+inline int filter_build_u(int imt, int jmt, int km, const int *kmu, const double *csu, const double *csur, const double *phi,
+                          double pi, int jfrst, int jfu0, int jfu1, int jfu2, int lsegf, FilterSetup &out, std::vector<int> &rows,
+                          std::string &err) {
+  using namespace uvic_filter;
+  if (jfrst < 2 || jfu0 < 1 || jfu0 > jmt || jfu1 >= jfu2 || jfu2 > jmt) { err = "uvic_gpu_set_filter_u: rows out of range"; return 2; }
+  const int imtm2 = imt - 2;
+  Tables T(imt, pi);
+  std::map<std::tuple<int, int, int>, int> known;
+  out.items.clear();
+  out.mats.clear();
+  rows.clear();
+  std::vector<int> isf, ief;
+  for (int jrow = jfrst; jrow <= jmt - 1; ++jrow) {
+    if (!(jrow <= jfu1 || jrow >= jfu2)) continue;
+    if (!find_strips(imt, km, kmu, jrow, lsegf, isf, ief)) { err = "uvic_gpu_set_filter_u: more ocean strips in a row than lsegf"; return 2; }
+    const double fx = (phi[jrow - 1] > 0.0) ? 1.0 : -1.0;
+    int isave = 0, ieave = 0, m = 2, n = 0;
+    for (int l = 1; l <= lsegf; ++l)
+      for (int k = 1; k <= km; ++k) {
+        const int is = isf[(size_t)(l - 1) * km + (k - 1)], ie = ief[(size_t)(l - 1) * km + (k - 1)];
+        if (is == 0) continue;
+        const int im = ie - is + 1;
+        if (is != isave || ie != ieave) {
+          isave = is;
+          ieave = ie;
+          if (im != imtm2) {
+            m = 2;
+            n = (int)std::lround(im * csu[jrow - 1] * csur[jfu0 - 1]);
+          } else {
+            m = 3;
+            n = (int)std::lround(im * csu[jrow - 1] * csur[jfu0 - 1] * 0.5);
+          }
+        }
+        if (im < 1 || n < 0) { err = "uvic_gpu_set_filter_u: bad strip (filtr would stop)"; return 2; }
+        FilterItem it;
+        it.j = jrow; it.k = k; it.is = is; it.im = im;
+        it.fnorm = (m == 2) ? 2.0 / (double)(im + 1) : 2.0 / (double)im;
+        it.fimr = 1.0 / (double)im;
+        it.fx = fx;
+        it.mat = 0;
+        if (m == 2 && n == 0) {
+          it.mode = 2;
+        } else {
+          it.mode = (m == 2) ? 3 : 1;
+          const auto key = std::make_tuple(im, m, n);
+          auto f = known.find(key);
+          if (f == known.end()) {
+            std::vector<double> F;
+            if (!build_operator(T, im, m, n, F)) { err = "uvic_gpu_set_filter_u: cannot build the filter operator"; return 2; }
+            const int off = (int)out.mats.size();
+            out.mats.insert(out.mats.end(), F.begin(), F.end());
+            f = known.emplace(key, off).first;
+          }
+          it.mat = f->second;
+        }
+        out.items.push_back(it);
+      }
+    if (isave != 0 && ieave != 0) rows.push_back(jrow);
+  }
+  return 0;
+}
 
 // strips (findex.F, O_cyclic), their filters (filt.F:48-83) and operators for rows jfrst..jmt-1 outside (jft1, jft2)
 inline int filter_build(int imt, int jmt, int km, const int *kmt, const double *cst, const double *cstr, double pi, int jfrst,
@@ -193,6 +308,7 @@ inline int filter_build(int imt, int jmt, int km, const int *kmt, const double *
         it.j = jrow; it.k = k; it.is = is; it.im = im;
         it.fnorm = 2.0 / (double)im;
         it.fimr = 1.0 / (double)im;
+        it.fx = 0.0;
         it.mat = 0;
         if (!(n > 1 || m != 1)) {
           it.mode = 0;

@@ -80,5 +80,101 @@ UVIC_DEV void filt_block(Env &env, const uvic_ctx &c, const FilterItem &it, int 
   });
 }
 
+// The application part of filtr.F:172-223, 392-428 on a strip that already sits in the workgroup's tile:
+// s[0..im) is replaced by its filtered values.  sp: im doubles of work space, scal: 4 doubles.
+template <class Env>
+UVIC_DEV void filt_strip(Env &env, const FilterItem &it, const double *mats, double *s, double *sp, double *scal) {
+  const int im = it.im;
+  if (it.mode == 2) {   // filter type 2 with n = 0
+    env.par([&](int tid) { if (tid < im) s[tid] = 0.0; });
+    return;
+  }
+  env.par([&](int tid) {
+    if (tid == 0) {
+      double ssum = 0.0;
+      for (int p = 0; p < im; ++p) ssum = ssum + s[p];
+      scal[0] = ssum;
+      scal[1] = ssum * it.fimr;
+    }
+  });
+  if (it.mode == 0) {
+    env.par([&](int tid) { if (tid < im) s[tid] = scal[1]; });
+    return;
+  }
+  if (it.mode == 1) env.par([&](int tid) { if (tid < im) s[tid] = s[tid] - scal[1]; });
+  const double *F = mats + it.mat;
+  env.par([&](int tid) {
+    if (tid < im) {
+      double acc = 0.0;
+      for (int q = 0; q < im; ++q) acc = acc + s[q] * F[(size_t)q * im + tid];
+      sp[tid] = it.fnorm * acc;
+    }
+  });
+  if (it.mode == 3) {
+    env.par([&](int tid) { if (tid < im) s[tid] = sp[tid]; });
+    return;
+  }
+  env.par([&](int tid) {
+    if (tid == 0) {
+      double ssm = 0.0;
+      for (int p = 0; p < im; ++p) ssm = ssm + sp[p];
+      scal[2] = (scal[0] - ssm) * it.fimr;
+    }
+  });
+  env.par([&](int tid) { if (tid < im) s[tid] = scal[2] + sp[tid]; });
+}
+
+// filuv.F:56-152 for one strip of one level of one row: rotate (u,v) to polar-stereographic components, filter both,
+// rotate back.  u1, u2 = u(:,:,:,1:2,taup1).  lds: 3*nthreads + 4 doubles.
+template <class Env>
+UVIC_DEV void filuv_block(Env &env, int imt, int km, const FilterItem &it, const double *mats, const double *spsin,
+                          const double *spcos, double *u1, double *u2, double *lds) {
+  const int NT = env.nthreads();
+  double *t1 = lds, *t2 = lds + NT, *sp = lds + 2 * NT, *scal = lds + 3 * NT;
+  const int im = it.im, j = it.j, k = it.k;
+  const double fx = it.fx;
+  auto col = [&](int p) {
+    int i = it.is + p - 1;
+    if (i > imt - 1) i -= imt - 2;
+    return i;
+  };
+  env.par([&](int tid) {
+    if (tid < im) {
+      const int i = col(tid + 1);
+      const double a = u1[X3(i, k, j)], b = u2[X3(i, k, j)];
+      t1[tid] = -fx * a * spsin[i - 1] - b * spcos[i - 1];
+      t2[tid] = fx * a * spcos[i - 1] - b * spsin[i - 1];
+    }
+  });
+  filt_strip(env, it, mats, t1, sp, scal);
+  filt_strip(env, it, mats, t2, sp, scal);
+  env.par([&](int tid) {
+    if (tid < im) {
+      const int i = col(tid + 1);
+      u1[X3(i, k, j)] = fx * (-t1[tid] * spsin[i - 1] + t2[tid] * spcos[i - 1]);
+      u2[X3(i, k, j)] = -t1[tid] * spcos[i - 1] - t2[tid] * spsin[i - 1];
+    }
+  });
+}
+
+// filuv.F:155-181 for one column of a filtered row: the vertical mean is removed again (from every level), then the
+// land mask; with the cyclic images of clinic.F:506-509
+UVIC_DEV void filuv_mean_column(int imt, int km, int i, int j, const int *kmu, const double *hr, const double *dzt, double *u1,
+                                double *u2) {
+  const int kb = kmu[X2(i, j)];
+  for (int n = 1; n <= 2; ++n) {
+    double *u = (n == 1) ? u1 : u2;
+    double acc = 0.0;
+    for (int k = 1; k <= km; ++k) acc = acc + u[X3(i, k, j)] * dzt[k - 1];
+    acc = acc * hr[X2(i, j)];
+    for (int k = 1; k <= km; ++k) {
+      const double v = (u[X3(i, k, j)] - acc) * ((k <= kb) ? 1.0 : 0.0);
+      u[X3(i, k, j)] = v;
+      if (i == 2) u[X3(imt, k, j)] = v;
+      if (i == imt - 1) u[X3(1, k, j)] = v;
+    }
+  }
+}
+
 }  // namespace uvic
 #endif

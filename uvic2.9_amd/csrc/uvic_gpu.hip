@@ -20,6 +20,7 @@
 #include "kernels_col.hpp"
 #include "kernels_prep.hpp"
 #include "kernels_filter.hpp"
+#include "kernels_clinic.hpp"
 #include "filter_host.hpp"
 #include "kernels_fct.hpp"
 #include "kernels_isopyc.hpp"
@@ -174,6 +175,53 @@ __global__ void __launch_bounds__(256) k_vmixc(const uvic_ctx c) {
   CELL_DECODE(c);
   if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
   vmixc_cell(c, i, k, j);
+}
+// ---- baroclinic momentum step (kernels_clinic.hpp) -----------------------------------
+#define COL_DECODE(m)                                                 \
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;              \
+  const int i = gid % (m).imt + 1, j = gid / (m).imt + 1
+__global__ void __launch_bounds__(256) k_state(const uvic_mom_ctx m) {
+  CELL_DECODE(m);
+  if (j < 2 || j > m.jmt) return;
+  state_cell(m, i, k, j);
+}
+__global__ void __launch_bounds__(64) k_clinic_gradp(const uvic_mom_ctx m) {
+  COL_DECODE(m);
+  if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
+  clinic_gradp_column(m, i, j);
+}
+__global__ void __launch_bounds__(256) k_clinic_tend(const uvic_mom_ctx m) {
+  CELL_DECODE(m);
+  if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
+  clinic_tend_cell(m, i, k, j);
+}
+__global__ void __launch_bounds__(64) k_clinic_finish(const uvic_mom_ctx m) {
+  COL_DECODE(m);
+  if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
+  clinic_finish_column(m, i, j);
+}
+// polar filter of u(tau+1): one workgroup per strip of a level of a row (both components)
+__global__ void __launch_bounds__(1024) k_filuv(const uvic_mom_ctx m, const FilterItem *items, const double *mats, const double *spsin,
+                                                const double *spcos, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if ((int)blockIdx.x >= nitems) return;
+  const FilterItem it = items[blockIdx.x];
+  if (it.j < m.js || it.j > m.je) return;
+  GpuEnv env;
+  filuv_block(env, m.imt, m.km, it, mats, spsin, spcos, m.up1, m.up2, lds);
+}
+__global__ void __launch_bounds__(64) k_filuv_mean(const uvic_mom_ctx m, const int *rows, int nrows) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid % m.imt + 1, r = gid / m.imt;
+  if (r >= nrows || i < 2 || i > m.imt - 1) return;
+  const int j = rows[r];
+  if (j < m.js || j > m.je) return;
+  filuv_mean_column(m.imt, m.km, i, j, m.kmu, m.hr, m.dzt, m.up1, m.up2);
+}
+__global__ void __launch_bounds__(256) k_clinic_sbcu(const uvic_mom_ctx m, int flags, double rts) {
+  COL_DECODE(m);
+  if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
+  clinic_sbcu_cell(m, i, j, flags, rts);
 }
 __global__ void __launch_bounds__(256) k_ai_coef(const uvic_ctx c, double *cf) {
   if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
@@ -620,6 +668,15 @@ static const FieldDesc FIELDS[UVIC_F_COUNT] = {
     {"u1", K_C, 1, false}, {"u2", K_C, 1, false}, {"dxt2r", K_IMT, 1, false}, {"dyt2r", K_JMT, 1, false},
     {"zw", K_KM, 1, false}, {"tlat", K_S, 1, false},
     {"edrm2", K_C, 1, false}, {"edrs2", K_C, 1, false}, {"edrk1", K_C, 1, false}, {"edro1", K_C, 1, false},
+    {"rho", K_C, 1, false}, {"um1", K_C, 1, false}, {"um2", K_C, 1, false}, {"up1", K_C, 1, false}, {"up2", K_C, 1, false},
+    {"zu", K_S, 2, false}, {"grad_p", K_C, 2, false}, {"smf", K_S, 2, false}, {"kmu", K_S, 1, true}, {"hr", K_S, 1, false},
+    {"cori", K_S, 2, false}, {"visc_ceu", K_C, 1, false}, {"amc_north", K_C, 1, false}, {"amc_south", K_C, 1, false},
+    {"dxu2r", K_IMT, 1, false}, {"dxmetr", K_IMT, 1, false}, {"duw", K_IMT, 1, false}, {"due", K_IMT, 1, false},
+    {"dyu2r", K_JMT, 1, false}, {"dyu4r", K_JMT, 1, false}, {"csur", K_JMT, 1, false}, {"dus", K_JMT, 1, false},
+    {"dun", K_JMT, 1, false}, {"csudyu2r", K_JMT, 1, false}, {"advmet", K_JMT, 2, false}, {"am3", K_JMT, 1, false},
+    {"am4", K_JMT, 2, false},
+    {"sbc_gu", K_S, 1, false}, {"sbc_gv", K_S, 1, false}, {"sbc_su", K_S, 1, false}, {"sbc_sv", K_S, 1, false},
+    {"spsin", K_IMT, 1, false}, {"spcos", K_IMT, 1, false}, {"phi", K_JMT, 1, false},
 };
 
 struct KernelStat {
@@ -667,6 +724,13 @@ struct uvic_gpu {
   int mobi_key;   // n15 | c13<<1 | caco3<<2 | silicon<<3 of the set bound by uvic_gpu_set_mobi_opt
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
+  // baroclinic momentum step (uvic_gpu_state / uvic_gpu_clinic)
+  uvic_clinic_params clinic_p;
+  bool have_clinic;
+  FilterItem *fltu_items;   // polar filter of the velocities (uvic_gpu_set_filter_u): strips, operators, filtered rows
+  double *fltu_mats;
+  int *fltu_rows;
+  int fltu_nitems, fltu_threads, fltu_nrows;
   // polar filter (uvic_gpu_set_filter): strips and operators, built once
   FilterItem *flt_items;
   double *flt_mats;
@@ -764,7 +828,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 4; }   // 4: uvic_gpu_set_mobi_opt (MOBI option sets other than C)
+extern "C" int uvic_gpu_abi_version(void) { return 5; }   // 5: uvic_gpu_state, uvic_gpu_clinic (baroclinic momentum step)
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -815,6 +879,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->profiling = false;
   h->have_mobi = false;
   h->have_vmix = false;
+  h->have_clinic = false;
+  h->fltu_items = nullptr; h->fltu_mats = nullptr; h->fltu_rows = nullptr; h->fltu_nitems = h->fltu_threads = h->fltu_nrows = 0;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
   h->wet_dev = nullptr;
   h->lanes_dev = nullptr; h->nwaves_a = h->nwaves_b = 0; h->lanes_dirty = true;
@@ -1821,6 +1887,137 @@ extern "C" int uvic_gpu_vmixc(uvic_gpu *h) {
   HIPCHK(hipSetDevice(h->device));
   if (int rc = launch_vmixc(h)) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// -- baroclinic momentum step ---------------------------------------------------------------
+static uvic_mom_ctx mom_ctx(uvic_gpu *h) {
+  uvic_mom_ctx m;
+  memset(&m, 0, sizeof m);
+  const uvic_dims &d = h->d;
+  m.imt = d.imt; m.jmt = d.jmt; m.km = d.km;
+  m.js = h->ctx.js; m.je = h->ctx.je;
+  m.c2dtuv = h->clinic_p.c2dtuv; m.grav_rho0r = h->clinic_p.grav * h->clinic_p.rho0r;
+  m.kappa_m = h->clinic_p.kappa_m; m.cdbot = h->clinic_p.cdbot;
+#define B(field, F) m.field = (decltype(m.field))h->buf[F]
+  B(dxur, UVIC_F_DXUR); B(dxu2r, UVIC_F_DXU2R); B(dxtr, UVIC_F_DXTR); B(dxmetr, UVIC_F_DXMETR); B(duw, UVIC_F_DUW); B(due, UVIC_F_DUE);
+  B(dyur, UVIC_F_DYUR); B(dyu2r, UVIC_F_DYU2R); B(dyu4r, UVIC_F_DYU4R); B(dytr, UVIC_F_DYTR); B(csur, UVIC_F_CSUR); B(cst, UVIC_F_CST);
+  B(dus, UVIC_F_DUS); B(dun, UVIC_F_DUN); B(csudyu2r, UVIC_F_CSUDYU2R);
+  B(advmet, UVIC_F_ADVMET); B(am3, UVIC_F_AM3); B(am4, UVIC_F_AM4);
+  B(dzt, UVIC_F_DZT); B(dztr, UVIC_F_DZTR); B(dzt2r, UVIC_F_DZT2R); B(dzw, UVIC_F_DZW); B(dzwr, UVIC_F_DZWR);
+  B(to, UVIC_F_TO); B(so, UVIC_F_SO); B(c, UVIC_F_C);
+  B(kmt, UVIC_F_KMT); B(kmu, UVIC_F_KMU); B(hr, UVIC_F_HR); B(cori, UVIC_F_CORI);
+  B(visc_ceu, UVIC_F_VISC_CEU); B(amc_north, UVIC_F_AMC_NORTH); B(amc_south, UVIC_F_AMC_SOUTH);
+  B(adv_vet, UVIC_F_ADV_VET); B(adv_vnt, UVIC_F_ADV_VNT); B(adv_vbt, UVIC_F_ADV_VBT);
+  B(smf, UVIC_F_SMF); B(rho, UVIC_F_RHO);
+  B(ut1, UVIC_F_U1); B(ut2, UVIC_F_U2); B(um1, UVIC_F_UM1); B(um2, UVIC_F_UM2); B(up1, UVIC_F_UP1); B(up2, UVIC_F_UP2);
+  B(zu, UVIC_F_ZU); B(grad_p, UVIC_F_GRAD_P);
+  B(sbc_gu, UVIC_F_SBC_GU); B(sbc_gv, UVIC_F_SBC_GV); B(sbc_su, UVIC_F_SBC_SU); B(sbc_sv, UVIC_F_SBC_SV);
+#undef B
+  // T and S of t(tau): the slots rotate by pointer, the tracer context knows the current one
+  m.t_tau = h->ctx.t_tau;
+  m.s_tau = h->ctx.t_tau + (size_t)d.imt * d.km * d.jmt;
+  return m;
+}
+static int launch_state(uvic_gpu *h) {
+  if (h->ctx.n0 != 0) return fail_msg("uvic_gpu_state: this rank's tracer shard does not hold T and S");
+  const uvic_mom_ctx m = mom_ctx(h);
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_state, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, m);
+  mark(h, "state");
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m);
+static int launch_clinic(uvic_gpu *h, int sbc_flags, double rts) {
+  if (!h->have_clinic) return fail_msg("uvic_gpu_clinic: call uvic_gpu_set_clinic_params first");
+  const uvic_mom_ctx m = mom_ctx(h);
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_clinic_gradp, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m);
+  mark(h, "clinic_gradp");
+  hipLaunchKernelGGL(k_clinic_tend, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, m);
+  mark(h, "clinic_tend");
+  hipLaunchKernelGGL(k_clinic_finish, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m);
+  mark(h, "clinic_finish");
+  if (int rc = launch_filuv(h, m)) return rc;
+  if (sbc_flags & 1) {
+    hipLaunchKernelGGL(k_clinic_sbcu, dim3(col_blocks(h, 256)), dim3(256), 0, h->stream, m, (sbc_flags >> 1) & 3, rts);
+    mark(h, "clinic_sbcu");
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m) {
+  if (h->fltu_nitems == 0) return 0;
+  hipLaunchKernelGGL(k_filuv, dim3((unsigned)h->fltu_nitems), dim3(h->fltu_threads), (size_t)(3 * h->fltu_threads + 4) * 8, h->stream, m,
+                     h->fltu_items, h->fltu_mats, (const double *)h->buf[UVIC_F_SPSIN], (const double *)h->buf[UVIC_F_SPCOS],
+                     h->fltu_nitems);
+  mark(h, "filuv");
+  const unsigned n = (unsigned)h->fltu_nrows * (unsigned)h->d.imt;
+  hipLaunchKernelGGL(k_filuv_mean, dim3((n + 63) / 64), dim3(64), 0, h->stream, m, h->fltu_rows, h->fltu_nrows);
+  mark(h, "filuv_mean");
+  return 0;
+}
+extern "C" int uvic_gpu_set_clinic_params(uvic_gpu *h, const uvic_clinic_params *p) {
+  if (!h || !p) return fail_msg("uvic_gpu_set_clinic_params: null argument");
+  h->clinic_p = *p;
+  h->have_clinic = true;
+  return 0;
+}
+extern "C" int uvic_gpu_state(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_state(h)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_clinic(h, sbc_flags, rts)) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+// polar Fourier filter of u(tau+1): strips of kmu and operators from the fields already uploaded (UVIC_F_KMU, CSU, CSUR, PHI)
+extern "C" int uvic_gpu_set_filter_u(uvic_gpu *h, double pi, int jfrst, int jfu0, int jfu1, int jfu2, int lsegf) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  (void)hipFree(h->fltu_items); h->fltu_items = nullptr;
+  (void)hipFree(h->fltu_mats); h->fltu_mats = nullptr;
+  (void)hipFree(h->fltu_rows); h->fltu_rows = nullptr;
+  h->fltu_nitems = h->fltu_nrows = 0;
+  if (jfrst > h->d.jmt) return 0;          // `jrow .lt. jfrst` for every row: filter off
+  if (lsegf < 1) return fail_msg("uvic_gpu_set_filter_u: lsegf < 1");
+  const uvic_dims &d = h->d;
+  std::vector<int> kmu((size_t)d.imt * d.jmt);
+  std::vector<double> csu(d.jmt), csur(d.jmt), phi(d.jmt);
+  HIPCHK(hipMemcpy(kmu.data(), h->buf[UVIC_F_KMU], kmu.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(csu.data(), h->buf[UVIC_F_CSU], csu.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(csur.data(), h->buf[UVIC_F_CSUR], csur.size() * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(phi.data(), h->buf[UVIC_F_PHI], phi.size() * 8, hipMemcpyDeviceToHost));
+  FilterSetup fs;
+  std::vector<int> rows;
+  std::string err;
+  if (int rc = filter_build_u(d.imt, d.jmt, d.km, kmu.data(), csu.data(), csur.data(), phi.data(), pi, jfrst, jfu0, jfu1, jfu2, lsegf,
+                              fs, rows, err)) {
+    g_err = err;
+    return rc;
+  }
+  if (fs.items.empty()) return 0;
+  int maxim = 0;
+  for (auto &it : fs.items) maxim = it.im > maxim ? it.im : maxim;
+  if (maxim > 1024) return fail_msg("uvic_gpu_set_filter_u: strips longer than 1024 columns are not supported");
+  h->fltu_threads = ((maxim + 63) / 64) * 64;
+  HIPCHK(hipMalloc((void **)&h->fltu_items, fs.items.size() * sizeof(FilterItem)));
+  HIPCHK(hipMemcpy(h->fltu_items, fs.items.data(), fs.items.size() * sizeof(FilterItem), hipMemcpyHostToDevice));
+  const size_t nm = fs.mats.empty() ? 1 : fs.mats.size();
+  HIPCHK(hipMalloc((void **)&h->fltu_mats, nm * 8));
+  if (!fs.mats.empty()) HIPCHK(hipMemcpy(h->fltu_mats, fs.mats.data(), fs.mats.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void **)&h->fltu_rows, rows.size() * 4));
+  HIPCHK(hipMemcpy(h->fltu_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+  h->fltu_nitems = (int)fs.items.size();
+  h->fltu_nrows = (int)rows.size();
   return 0;
 }
 

@@ -110,6 +110,17 @@ def make_grid(imt: int, jmt: int, km: int):
     dzwxcl = np.zeros(km)
     dzwxcl[:km - 1] = 1.0 / (g.dztxcl[:-1] + g.dztxcl[1:])
     g.dzwxcl = dzwxcl
+    # U-cell metrics of the momentum equations, grids.F:527-550 (cyclic)
+    g.dxmetr = np.zeros(imt)
+    g.dxmetr[1:imt - 1] = 1.0 / (g.dxt[1:imt - 1] + g.dxt[2:imt])
+    g.duw = (g.xu - g.xt) * degtcm
+    g.due = np.zeros(imt)
+    g.due[:imt - 1] = (g.xt[1:] - g.xu[:imt - 1]) * degtcm
+    g.due[imt - 1] = g.due[1]
+    g.dus = (g.yu - g.yt) * degtcm
+    g.dun = np.zeros(jmt)
+    g.dun[:jmt - 1] = (g.yt[1:] - g.yu[:jmt - 1]) * degtcm
+    g.dun[jmt - 1] = g.dun[jmt - 2]
     g.tlat = F((imt, jmt))
     g.tlat[:, :] = g.yt[None, :]
     g.tlon = F((imt, jmt))
@@ -242,6 +253,58 @@ def make_velocity(g, topo):
     return u
 
 
+def make_momentum(g, topo, u_tau):
+    """Inputs of the baroclinic momentum step (`clinic`) that the tracer step does not
+    have: u(tau-1), wind stress, the static factors of setmom.F:770-803, 1104-1114 and the viscosity
+    coefficients hmixc.F leaves on its first call (O_anisotropic_viscosity: three 3-D fields; here a smooth
+    synthetic pattern in place of hmixc.F:49-103's western-boundary rule, amc_* from it as hmixc.F:120-131)."""
+    imt, jmt, km = g.imt, g.jmt, g.km
+    m = SimpleNamespace()
+    lam = 2.0 * np.pi * (np.arange(1, imt + 1) - 1.0) / (imt - 2)
+    # u(tau-1): the tau field, slightly rotated and damped
+    um = F((imt, km, jmt, 2))
+    um[..., 0] = 0.97 * u_tau[..., 0] - 0.05 * u_tau[..., 1]
+    um[..., 1] = 0.97 * u_tau[..., 1] + 0.05 * u_tau[..., 0]
+    um *= topo.umask[..., None]
+    um[0] = um[imt - 2]
+    um[imt - 1] = um[1]
+    m.u_taum1 = um
+    m.smf = F((imt, jmt, 2))
+    m.smf[..., 0] = 0.8 * np.cos(3.0 * g.phi)[None, :] * (1.0 + 0.2 * np.sin(lam))[:, None] * topo.umask[:, 0, :]
+    m.smf[..., 1] = 0.1 * np.sin(2.0 * lam + 1.0)[:, None] * np.cos(g.phi)[None, :] * topo.umask[:, 0, :]
+    m.smf[0] = m.smf[imt - 2]
+    m.smf[imt - 1] = m.smf[1]
+    omega = g.pi / 43082.0
+    radius = RADIUS
+    ulat = F((imt, jmt)); ulat[:, :] = g.yu[None, :]
+    m.cori = F((imt, jmt, 2))
+    m.cori[..., 0] = 2.0 * omega * np.sin(ulat / g.radian)
+    m.cori[..., 1] = -m.cori[..., 0]
+    m.am = 1.5e9
+    m.am3 = m.am * (1.0 - g.tng * g.tng) / (radius ** 2)
+    m.am4 = F((jmt, 2))
+    m.am4[:, 0] = -m.am * 2.0 * g.sine / (radius * g.csu * g.csu)
+    m.am4[:, 1] = -m.am4[:, 0]
+    m.advmet = F((jmt, 2))
+    m.advmet[:, 0] = g.tng / radius
+    m.advmet[:, 1] = -m.advmet[:, 0]
+    m.hr = F((imt, jmt))
+    wet = topo.kmu > 0
+    m.hr[wet] = 1.0 / g.zw[topo.kmu[wet] - 1]
+    trop = (np.abs(g.yu) <= 20.0)[None, None, :] & (g.zw <= 55000.0)[None, :, None]
+    visc_cnu = F((imt, km, jmt)); visc_cnu[:] = m.am
+    visc_cnu[:] = np.where(trop, m.am * (1.0 + 2.0 * np.cos(lam)[:, None, None] ** 2), m.am)
+    m.visc_ceu = F((imt, km, jmt))
+    m.visc_ceu[:] = np.where(trop, m.am * (0.4 + 0.3 * np.sin(lam)[:, None, None] ** 2), m.am)
+    jp1 = np.minimum(np.arange(jmt) + 1, jmt - 1)
+    m.amc_north = F((imt, km, jmt)); m.amc_south = F((imt, km, jmt))
+    m.amc_north[:] = visc_cnu * (g.cst[jp1] * g.dytr[jp1] * g.csur * g.dyur)[None, None, :]
+    m.amc_south[:] = visc_cnu * (g.cst * g.dytr * g.csur * g.dyur)[None, None, :]
+    m.kappa_m, m.cdbot, m.dtuv = 10.0, 1.3e-3, 1125.0
+    m.grav, m.rho0r = 980.6, 1.0 / 1.035
+    return m
+
+
 def advective_velocities(g, u):
     """adv_vet, adv_vnt (imt,km,jmt) and adv_vbt (imt,km+1,jmt) from `u`
     exactly as /root/reference/source/mom/adv_vel.F:63-131 (rigid lid)."""
@@ -310,6 +373,31 @@ def make_filter(g, km, lsegf=20, jmtfil=50):
     f.njtbft = (f.jft1 - f.jfrst + 1) + (g.jmt - 1 - f.jft2 + 1)
     if f.njtbft > jmtfil:
         f.jmtfil = f.njtbft
+    return f
+
+
+def make_filter_u(g, km, lsegf=20, jmtfil=50):
+    """Rows of the polar Fourier filter of the velocities (`filuv`): latitudes of
+    /root/reference/updates/09/source/common/setcom.F:38-44, 76-86 (rjfrst=-87.3 on the T grid; rjfu0=-68.4,
+    rjfu1=-70.2, rjfu2=70.2 on the U grid) and the rotation factors of source/common/setcom.F:55-70."""
+    f = SimpleNamespace(jfrst=indp(-87.3, g.yt), jfu0=indp(-68.4, g.yu), jfu1=indp(-70.2, g.yu), jfu2=indp(70.2, g.yu),
+                        lsegf=lsegf, jmtfil=jmtfil, km=km)
+    if g.jmt < 30:     # the small test grids have land poleward of 70 degrees: move the bounds to rows with ocean
+        f.jfu1, f.jfu2 = max(f.jfu1, 4), min(f.jfu2, g.jmt - 4)
+        f.jfu0 = f.jfu1 + 1
+    f.jskpu = f.jfu2 - f.jfu1
+    f.njtbfu = (f.jfu1 - f.jfrst + 1) + (g.jmt - 1 - f.jfu2 + 1)
+    if f.njtbfu > jmtfil:
+        f.jmtfil = f.njtbfu
+    imt = g.imt
+    fxa = g.dxt[0] / RADIUS
+    fxb = fxa * (np.arange(1, imt + 1, dtype=np.float64) - 2.0)
+    f.spsin, f.spcos = np.sin(fxb), np.cos(fxb)
+    f.spsin[np.abs(f.spsin) < 1.0e-10] = 0.0
+    f.spcos[np.abs(f.spcos) < 1.0e-10] = 0.0
+    for a in (f.spsin, f.spcos):
+        a[0] = 0.0
+        a[imt - 1] = 0.0
     return f
 
 

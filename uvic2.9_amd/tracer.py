@@ -61,6 +61,10 @@ class TracerModel:
             "ai_bx": C + (2, 2), "ai_by": C + (2, 2), "k11": C, "k22": C, "k33": C, "adv_vetiso": C,
             "adv_vntiso": C, "adv_vbtiso": Fc, "diff_cbt": C, "to": (km,), "so": (km,), "c": (km, 9),
             "u1": C, "u2": C, "tlat": S, "edrm2": C, "edrs2": C, "edrk1": C, "edro1": C, "dxt2r": (imt,), "zw": (km,),
+            "rho": C, "um1": C, "um2": C, "up1": C, "up2": C, "zu": S + (2,), "grad_p": C + (2,), "smf": S + (2,), "kmu": S,
+            "hr": S, "cori": S + (2,), "visc_ceu": C, "amc_north": C, "amc_south": C, "dxu2r": (imt,), "dxmetr": (imt,),
+            "duw": (imt,), "due": (imt,), "advmet": (jmt, 2), "am4": (jmt, 2), "sbc_gu": S, "sbc_gv": S, "sbc_su": S,
+            "sbc_sv": S, "spsin": (imt,), "spcos": (imt,),
         }
         if name in table:
             return table[name]
@@ -74,7 +78,7 @@ class TracerModel:
 
     def upload(self, name, array):
         f = FIELD[name.lower()]
-        dt = np.int32 if name.lower() in ("kmt", "itrc") else np.float64
+        dt = np.int32 if name.lower() in ("kmt", "itrc", "kmu") else np.float64
         a = np.asfortranarray(array, dtype=dt)
         if a.shape != self.shape(name.lower()):
             raise UvicGpuError(f"upload({name}): shape {a.shape} != {self.shape(name.lower())}")
@@ -82,7 +86,7 @@ class TracerModel:
 
     def download(self, name):
         f = FIELD[name.lower()]
-        dt = np.int32 if name.lower() in ("kmt", "itrc") else np.float64
+        dt = np.int32 if name.lower() in ("kmt", "itrc", "kmu") else np.float64
         a = np.zeros(self.shape(name.lower()), dtype=dt, order="F")
         check(self.lib.uvic_gpu_download(self.h, f, a.ctypes.data_as(ctypes.c_void_p), 0, a.size), f"download({name})")
         return a
@@ -146,6 +150,46 @@ class TracerModel:
         """diff_cbt = tidal mixing + K33 on the device (updates/09/source/mom/vmixc.F:62-190); call after
         isopyc() with set_params(diff_cbt_has_k33=1)."""
         check(self.lib.uvic_gpu_vmixc(self.h), "vmixc")
+
+    # baroclinic momentum step (SURVEY.md §8f rank 4) ------------------------------------------
+    def load_momentum(self, ocean, mom):
+        """Upload what `clinic` reads and the tracer step does not: u(tau), u(tau-1), wind stress, the U-grid metrics,
+        the factors of setmom.F and the viscosity coefficients of hmixc.F (`mom` as synthetic.make_momentum)."""
+        from .capi import ClinicParams
+        g, topo = ocean.grid, ocean.topo
+        self.upload("u1", np.asfortranarray(ocean.u[..., 0]))
+        self.upload("u2", np.asfortranarray(ocean.u[..., 1]))
+        self.upload("um1", np.asfortranarray(mom.u_taum1[..., 0]))
+        self.upload("um2", np.asfortranarray(mom.u_taum1[..., 1]))
+        self.upload("kmu", topo.kmu)
+        for n in ("dxu2r", "dxmetr", "duw", "due", "dyu2r", "dyu4r", "csur", "dus", "dun", "csudyu2r"):
+            self.upload(n, getattr(g, n))
+        for n in ("smf", "hr", "cori", "visc_ceu", "amc_north", "amc_south", "advmet", "am3", "am4"):
+            self.upload(n, getattr(mom, n))
+        p = ClinicParams(2.0 * mom.dtuv, mom.grav, mom.rho0r, mom.kappa_m, mom.cdbot)
+        check(self.lib.uvic_gpu_set_clinic_params(self.h, ctypes.byref(p)), "set_clinic_params")
+
+    def state(self):
+        """rho from T and S of t(tau) (source/mom/state.F as called at loadmw.F:154)."""
+        check(self.lib.uvic_gpu_state(self.h), "state")
+
+    def clinic(self, accumulate_sbc=False, osegs=False, osege=False, rts=1.0):
+        """Internal-mode velocities at tau+1 and zu (updates/09/source/mom/clinic.F); returns u(tau+1) as
+        (imt,km,jmt,2) and zu (imt,jmt,2)."""
+        flags = (1 if accumulate_sbc else 0) | (2 if osegs else 0) | (4 if osege else 0)
+        check(self.lib.uvic_gpu_clinic(self.h, flags, float(rts)), "clinic")
+        return np.stack([self.download("up1"), self.download("up2")], axis=-1), self.download("zu")
+
+    def set_filter_u(self, ocean, flt):
+        """Polar Fourier filter of u(tau+1) inside clinic (source/common/filuv.F); `flt` as synthetic.make_filter_u."""
+        if flt is None:
+            check(self.lib.uvic_gpu_set_filter_u(self.h, float(ocean.grid.pi), self.jmt + 1, 1, 1, 2, 1), "set_filter_u")
+        else:
+            self.upload("spsin", flt.spsin)
+            self.upload("spcos", flt.spcos)
+            self.upload("phi", ocean.grid.phi)
+            check(self.lib.uvic_gpu_set_filter_u(self.h, float(ocean.grid.pi), flt.jfrst, flt.jfu0, flt.jfu1, flt.jfu2, flt.lsegf),
+                  "set_filter_u")
 
     def set_filter(self, ocean, flt):
         """Polar Fourier filter of t(tau+1) after convection (source/common/filt.F); `flt` as
