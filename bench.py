@@ -344,6 +344,22 @@ def main():
             if "filt" in pf:
                 nxt["filt"] = round(pf["filt"], 5)
             m.set_filter(ocean, None)
+            # §8(f) rank 4: baroclinic momentum step (state + clinic with the polar filter filuv and the sbc accumulation)
+            mom = synthetic.make_momentum(ocean.grid, ocean.topo, ocean.u)
+            m.load_momentum(ocean, mom)
+            m.set_filter_u(ocean, synthetic.make_filter_u(ocean.grid, km))
+            m.state(); m.clinic_only(True)
+            m.profile_live(True)
+            tq = time.perf_counter()
+            for _ in range(20):
+                m.state_async(); m.clinic_async(True)
+            m.sync()
+            nxt["state_clinic_ms_per_call"] = round((time.perf_counter() - tq) / 20 * 1e3, 5)
+            pr = m.profile_read()
+            for k in ("state", "clinic_gradp", "clinic_tend", "clinic_finish", "filuv", "filuv_mean", "clinic_sbcu"):
+                if k in pr:
+                    nxt[k] = round(pr[k], 5)
+            m.set_filter_u(ocean, None)
         except Exception as e:   # never let the side measurement break the bench line
             nxt = {"error": str(e)}
         prof = live

@@ -347,6 +347,10 @@ int uvic_gpu_state(uvic_gpu *h);
  * (u09/mom/setvbc.F:170-194).  sbc_flags: bit 0 = accumulate the ice/atmosphere surface velocities (isbcu, asbcu,
  * clinic.F:729-895; `eots`), bit 1 = osegs, bit 2 = osege; rts = 1/ntspos. */
 int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts);
+/* the same two, queued on the handle's main stream without waiting (uvic_gpu_sync waits): for a caller that keeps
+ * the momentum step device-resident between the tracer steps */
+int uvic_gpu_state_async(uvic_gpu *h);
+int uvic_gpu_clinic_async(uvic_gpu *h, int sbc_flags, double rts);
 /* polar filter of the velocities: replaces `call filuv (joff, js, je)` (clinic.F:500; source/common/filuv.F with
  * O_fourfil O_cyclic).  Strips come from UVIC_F_KMU by findex's rule, rows jfrst..jfu1 and jfu2..jmt-1, reference
  * row jfu0 (index.h; u09/common/setcom.F:80-86).  jfrst > jmt switches it off. */

@@ -142,7 +142,8 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
     if shim:
         # the drop-in test: the package's Fortran overlay (uvic2.9_amd/fortran) provides `tracer`;
         # it is preprocessed like any model source (it #includes the reference's headers)
-        for f in ("tracer_gpu.F",):
+        shim_files = ["tracer_gpu.F"] + (["clinic_gpu.F"] if any(x.endswith("/clinic.F") for x in EXTRA_SOURCES.get(cfg, [])) else [])
+        for f in shim_files:
             r = run(["cpp", "-traditional", "-P", *incs, *defs, str(SHIM_DIR / f)])
             (work / (Path(f).stem + ".f")).write_text(patch(r.stdout), encoding="latin-1")
     # 3. generated registration harness (includes only; no reference text)
@@ -169,9 +170,10 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
         if verbose:
             print("  compiled", f.name)
         objs.append(str(o))
-        if shim and f.name == "tracer.f":
-            # keep the reference routine reachable as `tracer_cpu` (diagnostic time steps)
-            rr = run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--redefine-sym", "tracer_=tracer_cpu_", str(o)])
+        if shim and f.name in ("tracer.f", "clinic.f"):
+            # keep the reference routine reachable as `tracer_cpu` / `clinic_cpu` (diagnostic time steps)
+            nm = f.stem
+            rr = run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--redefine-sym", f"{nm}_={nm}_cpu_", str(o)])
             if rr.returncode != 0:
                 raise SystemExit(rr.stderr)
     r = run(["gcc", "-O2", "-fPIC", "-c", str(HERE / "ref" / "harness.c"), "-o", str(work / "harness.o")])
@@ -199,10 +201,12 @@ DEFAULT_BUILDS = [
     ("p2", 14, 14, 6), ("c30", 14, 14, 6),
     ("p2", 102, 102, 19), ("c30", 102, 102, 19),
     ("f18", 14, 14, 6), ("s37", 14, 14, 6),       # MOBI option sets F and run/mk.in's (tests/test_mobi_sets.py)
+    ("m2", 14, 14, 6), ("m2", 102, 102, 19),      # momentum step: clinic, filuv, setvbc (tests/test_clinic.py)
 ]
 
 
-SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f18", 14, 14, 6), ("s37", 14, 14, 6)]
+SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f18", 14, 14, 6), ("s37", 14, 14, 6),
+               ("m2", 14, 14, 6), ("m2", 102, 102, 19)]
 
 
 def build_default(force: bool = False, verbose: bool = False):
@@ -210,7 +214,7 @@ def build_default(force: bool = False, verbose: bool = False):
     if (GPU_LIB_DIR / "libuvic_gpu.so").exists():
         for cfg, imt, jmt, km in SHIM_BUILDS:
             t = shim_lib_name(cfg, imt, jmt, km)
-            srcs = [SHIM_DIR / "tracer_gpu.F", SHIM_DIR / "uvic_gpu_mod.F90"]
+            srcs = [SHIM_DIR / "tracer_gpu.F", SHIM_DIR / "clinic_gpu.F", SHIM_DIR / "uvic_gpu_mod.F90"]
             if t.exists() and not force and all(t.stat().st_mtime >= s_.stat().st_mtime for s_ in srcs):
                 built.append(t)
                 continue

@@ -198,3 +198,54 @@ def test_resident_overlay_through_an_euler_backward_step(exact, monkeypatch):
         for n, name in enumerate(oc.cfg.tracers):
             x, y = a[:, :, 1:jmt - 1, n], b[:, :, 1:jmt - 1, n]
             assert np.abs(x - y).max() <= (0.0 if exact and n < 2 else PROD_TOL) * np.abs(y).max(), (slot, name)
+
+
+@pytest.mark.parametrize("dims", [(14, 14, 6), (102, 102, 19)])
+def test_overlay_clinic_matches_reference_clinic(dims, monkeypatch):
+    """The momentum row's boundary end to end: `clinic(joff,js,je,is,ie)` of the package's
+    overlay (uvic2.9_amd/fortran/clinic_gpu.F) against the reference's own routine, through the reference's COMMON
+    blocks: u(tau+1), zu and the four sbc planes of isbcu/asbcu, bit for bit, with the polar filter filuv on.  The
+    overlay shares the device instance of the `tracer` overlay, which runs first as in mom.F:389-395."""
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    cfg = "m2"
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u)
+    flt = synthetic.make_filter_u(oc.grid, dims[2])
+    rng = np.random.default_rng(3)
+    planes = rng.standard_normal((dims[0], dims[1], 4))
+
+    def prepare(R):
+        R.set_momentum(mom)
+        R.set_filter(synthetic.make_filter(oc.grid, dims[2]))     # index.h holds the rows of both filters (setcom.F:75-86)
+        R.set_filter_u(flt)
+        S, v = R.ref.set, R.v
+        S("igu", 11); S("igv", 12); S("isu", 13); S("isv", 14); S("ntspos", 3)
+        v["sbc"][:, :, 10:14] = planes
+        R.state()
+        R.adv_vel_u()
+        R.setvbc()
+
+    ref = refdriver.RefOcean(oc)
+    prepare(ref)
+    shim = refdriver.RefOcean(oc, shim=True)
+    prepare(shim)
+    shim.step()                      # isopyc, "+K33", tracer (overlay): creates the device instance, sends adv_v?t
+    for itt, (osegs, osege) in enumerate(((1, 0), (0, 0), (0, 1))):
+        for R in (ref, shim):
+            R.ref.set("osegs", osegs); R.ref.set("osege", osege)
+            R.ref.set("itt", itt)    # from the second pass on the overlay sends the advective velocities itself
+        want_u, want_zu, _ = ref.clinic()
+        got_u, got_zu, _ = shim.clinic()
+        assert np.array_equal(got_u[:, :, 1:-1], want_u[:, :, 1:-1])
+        assert np.array_equal(got_zu, want_zu)
+        assert np.array_equal(shim.v["sbc"][:, :, 10:14], ref.v["sbc"][:, :, 10:14])
+    assert np.abs(want_u).max() > 0.1
+    # a diagnostic time step goes through the reference routine, kept as clinic_cpu
+    for R in (ref, shim):
+        R.ref.set("tsiperts", 1)
+    want_u, want_zu, _ = ref.clinic()
+    got_u, got_zu, _ = shim.clinic()
+    assert np.array_equal(got_u, want_u) and np.array_equal(got_zu, want_zu)

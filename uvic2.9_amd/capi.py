@@ -48,6 +48,7 @@ EXPORTS = [
     "uvic_gpu_step_lookahead_at", "uvic_gpu_prefetch_sources_at", "uvic_gpu_set_host_sync", "uvic_gpu_sbc_config",
     "uvic_gpu_sbc_transfer", "uvic_gpu_overlay_step",
     "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
+    "uvic_gpu_state_async", "uvic_gpu_clinic_async",
 ]
 
 
@@ -124,7 +125,9 @@ def load():
     lib.uvic_gpu_set_filter_u.argtypes = [ctypes.c_void_p, ctypes.c_double] + [ctypes.c_int] * 5
     lib.uvic_gpu_set_clinic_params.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_state.argtypes = [ctypes.c_void_p]
+    lib.uvic_gpu_state_async.argtypes = [ctypes.c_void_p]
     lib.uvic_gpu_clinic.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
+    lib.uvic_gpu_clinic_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]
     lib.uvic_gpu_profile_live.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_download_level.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.uvic_gpu_set_mobi_step.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 4

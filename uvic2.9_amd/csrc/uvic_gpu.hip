@@ -1971,6 +1971,16 @@ extern "C" int uvic_gpu_state(uvic_gpu *h) {
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
+extern "C" int uvic_gpu_state_async(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  return launch_state(h);
+}
+extern "C" int uvic_gpu_clinic_async(uvic_gpu *h, int sbc_flags, double rts) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  return launch_clinic(h, sbc_flags, rts);
+}
 extern "C" int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));

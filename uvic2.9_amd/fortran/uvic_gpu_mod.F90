@@ -44,6 +44,25 @@
       integer(c_int), parameter :: F_DIFF_CBT_BG=38, F_STF=39, F_BTF=40
       integer(c_int), parameter :: F_SRC=41, F_ITRC=42
       integer(c_int), parameter :: F_DIFF_CBT=58
+!     baroclinic momentum step (clinic_gpu.F)
+      integer(c_int), parameter :: F_U1=59, F_U2=60, F_RHO=69
+      integer(c_int), parameter :: F_UM1=70, F_UM2=71, F_UP1=72, F_UP2=73
+      integer(c_int), parameter :: F_ZU=74, F_GRAD_P=75, F_SMF=76
+      integer(c_int), parameter :: F_KMU=77, F_HR=78, F_CORI=79
+      integer(c_int), parameter :: F_VISC_CEU=80, F_AMC_NORTH=81
+      integer(c_int), parameter :: F_AMC_SOUTH=82, F_DXU2R=83
+      integer(c_int), parameter :: F_DXMETR=84, F_DUW=85, F_DUE=86
+      integer(c_int), parameter :: F_DYU2R=87, F_DYU4R=88, F_CSUR=89
+      integer(c_int), parameter :: F_DUS=90, F_DUN=91, F_CSUDYU2R=92
+      integer(c_int), parameter :: F_ADVMET=93, F_AM3=94, F_AM4=95
+      integer(c_int), parameter :: F_SBC_GU=96, F_SBC_GV=97, F_SBC_SU=98
+      integer(c_int), parameter :: F_SBC_SV=99, F_SPSIN=100, F_SPCOS=101
+      integer(c_int), parameter :: F_PHI=102
+
+!     scalars of clinic (include/uvic_gpu.h: uvic_clinic_params)
+      type, bind(C) :: uvic_clinic_params
+        real(c_double) :: c2dtuv, grav, rho0r, kappa_m, cdbot
+      end type uvic_clinic_params
 
       interface
         function uvic_gpu_create(h, dims, device) bind(C,name='uvic_gpu_create') result(rc)
@@ -207,6 +226,26 @@
           type(c_ptr), value :: p1, p2, p3, p4
           integer(c_int) :: rc
         end function
+        function uvic_gpu_set_clinic_params(h, p) bind(C,name='uvic_gpu_set_clinic_params') result(rc)
+          import
+          type(c_ptr), value :: h
+          type(uvic_clinic_params) :: p
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_clinic(h, sbc_flags, rts) bind(C,name='uvic_gpu_clinic') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: sbc_flags
+          real(c_double), value :: rts
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_filter_u(h, pi, jfrst, jfu0, jfu1, jfu2, lsegf) bind(C,name='uvic_gpu_set_filter_u') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double), value :: pi
+          integer(c_int), value :: jfrst, jfu0, jfu1, jfu2, lsegf
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_sync(h) bind(C,name='uvic_gpu_sync') result(rc)
           import
           type(c_ptr), value :: h
@@ -219,6 +258,9 @@
       end interface
 
       type(c_ptr), save :: uvic_handle = c_null_ptr
+!     time step (itt) whose adv_vet/adv_vnt/adv_vbt the tracer overlay has put on the device: clinic_gpu.F, called
+!     later in the same step (source/mom/mom.F:389-395), need not send them again
+      integer, save :: uvic_adv_itt = -1
 !     resident mode (environment UVIC_RESIDENT=1, read at the first call of the overlay): every tracer stays on
 !     the device from step to step; uvic_dev_state says that the device holds t(tau-1), t(tau) of the coming step
       logical, save :: uvic_resident = .false.

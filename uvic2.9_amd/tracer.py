@@ -180,6 +180,19 @@ class TracerModel:
         check(self.lib.uvic_gpu_clinic(self.h, flags, float(rts)), "clinic")
         return np.stack([self.download("up1"), self.download("up2")], axis=-1), self.download("zu")
 
+    def clinic_only(self, accumulate_sbc=False, osegs=False, osege=False, rts=1.0):
+        """clinic() without the downloads."""
+        flags = (1 if accumulate_sbc else 0) | (2 if osegs else 0) | (4 if osege else 0)
+        check(self.lib.uvic_gpu_clinic(self.h, flags, float(rts)), "clinic")
+
+    def state_async(self):
+        """Queue `state` on the main stream and return (sync() waits)."""
+        check(self.lib.uvic_gpu_state_async(self.h), "state_async")
+
+    def clinic_async(self, accumulate_sbc=False, osegs=False, osege=False, rts=1.0):
+        flags = (1 if accumulate_sbc else 0) | (2 if osegs else 0) | (4 if osege else 0)
+        check(self.lib.uvic_gpu_clinic_async(self.h, flags, float(rts)), "clinic_async")
+
     def set_filter_u(self, ocean, flt):
         """Polar Fourier filter of u(tau+1) inside clinic (source/common/filuv.F); `flt` as synthetic.make_filter_u."""
         if flt is None:
