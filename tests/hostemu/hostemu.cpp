@@ -258,8 +258,8 @@ extern "C" int emu_filuv(const uvic_mom_ctx *mp, const double *csu, const double
   std::vector<int> rows;
   std::string err;
   if (int rc = filter_build_u(m.imt, m.jmt, m.km, m.kmu, csu, m.csur, phi, pi, jfrst, jfu0, jfu1, jfu2, lsegf, fs, rows, err)) return rc;
-  std::vector<double> lds((size_t)3 * nthreads + 4);
-  HostEnv env{nthreads};
+  std::vector<double> lds((size_t)4 * nthreads + 8);
+  HostEnv env{2 * nthreads};
   for (auto &it : fs.items) {
     if (it.im > nthreads) return 3;
     std::fill(lds.begin(), lds.end(), -7.0e33);

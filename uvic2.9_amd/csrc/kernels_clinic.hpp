@@ -25,6 +25,10 @@
 
 namespace uvic {
 
+// the column marches read UV_KB levels at a time: the loads of a batch are independent, the sums that use them keep
+// the reference's order
+#define UV_KB 8
+
 // rho(i,k,j), state.F:22-28; rows 2..jmt, all columns
 UVIC_DEV void state_cell(const uvic_mom_ctx &m, int i, int k, int j) {
   UV_DIMS(m);
@@ -84,21 +88,34 @@ UVIC_DEV void clinic_gradp_column(const uvic_mom_ctx &m, int i, int j) {
   }
   const double fxa = m.grav_rho0r * m.csur[j - 1] * p5;
   const double fxb = m.grav_rho0r * m.dyu4r[j - 1];
-  // tempik(.,k,.) = rho(.,k-1,.) + rho(.,k,.) at the four corners
+  // tempik(.,k,.) = rho(.,k-1,.) + rho(.,k,.) at the four corners; the loads of UV_KB levels are issued together
   double r00 = rho[X3(i, 1, j)], r10 = rho[X3(i + 1, 1, j)], r01 = rho[X3(i, 1, j + 1)], r11 = rho[X3(i + 1, 1, j + 1)];
-  for (int k = 1; k <= km; ++k) {
-    if (k > 1) {
-      const double n00 = rho[X3(i, k, j)], n10 = rho[X3(i + 1, k, j)], n01 = rho[X3(i, k, j + 1)], n11 = rho[X3(i + 1, k, j + 1)];
-      const double t1 = (r11 + n11) - (r00 + n00);
-      const double t2 = (r01 + n01) - (r10 + n10);
-      g1 = g1 + fxa * (t1 - t2) * m.dzw[k - 1] * m.dxu2r[i - 1];
-      g2 = g2 + fxb * (t1 + t2) * m.dzw[k - 1];
-      r00 = n00; r10 = n10; r01 = n01; r11 = n11;
-    }
+  auto put = [&](int k) {
     gp[X3(i, k, j)] = g1;
     gp[X3(i, k, j) + N3] = g2;
     if (i == 2) { gp[X3(imt, k, j)] = g1; gp[X3(imt, k, j) + N3] = g2; }
     if (i == imt - 1) { gp[X3(1, k, j)] = g1; gp[X3(1, k, j) + N3] = g2; }
+  };
+  put(1);
+  for (int k0 = 2; k0 <= km; k0 += UV_KB) {
+    double n00[UV_KB], n10[UV_KB], n01[UV_KB], n11[UV_KB];
+#pragma unroll
+    for (int q = 0; q < UV_KB; ++q) {
+      const int k = (k0 + q <= km) ? k0 + q : km;
+      n00[q] = rho[X3(i, k, j)]; n10[q] = rho[X3(i + 1, k, j)]; n01[q] = rho[X3(i, k, j + 1)]; n11[q] = rho[X3(i + 1, k, j + 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < UV_KB; ++q) {
+      const int k = k0 + q;
+      if (k <= km) {
+        const double t1 = (r11 + n11[q]) - (r00 + n00[q]);
+        const double t2 = (r01 + n01[q]) - (r10 + n10[q]);
+        g1 = g1 + fxa * (t1 - t2) * m.dzw[k - 1] * m.dxu2r[i - 1];
+        g2 = g2 + fxb * (t1 + t2) * m.dzw[k - 1];
+        r00 = n00[q]; r10 = n10[q]; r01 = n01[q]; r11 = n11[q];
+        put(k);
+      }
+    }
   }
 }
 
@@ -176,21 +193,42 @@ UVIC_DEV void clinic_finish_column(const uvic_mom_ctx &m, int i, int j) {
     double *up = (n == 1) ? m.up1 : m.up2;
     const double *um = (n == 1) ? m.um1 : m.um2;
     double zu = 0.0, baru = 0.0;
-    for (int k = 1; k <= km; ++k) {
-      const double tend = up[X3(i, k, j)];
-      zu = zu + tend * m.dzt[k - 1];
-      const double v = um[X3(i, k, j)] + m.c2dtuv * tend;
-      baru = baru + v * m.dzt[k - 1];
-      up[X3(i, k, j)] = v;
+    for (int k0 = 1; k0 <= km; k0 += UV_KB) {
+      double td[UV_KB], u0[UV_KB];
+#pragma unroll
+      for (int q = 0; q < UV_KB; ++q) {
+        const int k = (k0 + q <= km) ? k0 + q : km;
+        td[q] = up[X3(i, k, j)];
+        u0[q] = um[X3(i, k, j)];
+      }
+#pragma unroll
+      for (int q = 0; q < UV_KB; ++q) {
+        const int k = k0 + q;
+        if (k <= km) {
+          zu = zu + td[q] * m.dzt[k - 1];
+          const double v = u0[q] + m.c2dtuv * td[q];
+          baru = baru + v * m.dzt[k - 1];
+          up[X3(i, k, j)] = v;
+        }
+      }
     }
     m.zu[X2(i, j) + (size_t)(n - 1) * N2] = zu * hr;
     baru = baru * hr;
-    for (int k = 1; k <= km; ++k) {
-      const double mask = (k <= kb) ? 1.0 : 0.0;
-      const double v = up[X3(i, k, j)] - mask * baru;
-      up[X3(i, k, j)] = v;
-      if (i == 2) up[X3(imt, k, j)] = v;
-      if (i == imt - 1) up[X3(1, k, j)] = v;
+    for (int k0 = 1; k0 <= km; k0 += UV_KB) {
+      double vv[UV_KB];
+#pragma unroll
+      for (int q = 0; q < UV_KB; ++q) vv[q] = up[X3(i, (k0 + q <= km) ? k0 + q : km, j)];
+#pragma unroll
+      for (int q = 0; q < UV_KB; ++q) {
+        const int k = k0 + q;
+        if (k <= km) {
+          const double mask = (k <= kb) ? 1.0 : 0.0;
+          const double v = vv[q] - mask * baru;
+          up[X3(i, k, j)] = v;
+          if (i == 2) up[X3(imt, k, j)] = v;
+          if (i == imt - 1) up[X3(1, k, j)] = v;
+        }
+      }
     }
   }
 }

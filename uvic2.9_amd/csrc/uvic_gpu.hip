@@ -195,10 +195,12 @@ __global__ void __launch_bounds__(256) k_clinic_tend(const uvic_mom_ctx m) {
   if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
   clinic_tend_cell(m, i, k, j);
 }
-__global__ void __launch_bounds__(64) k_clinic_finish(const uvic_mom_ctx m) {
+// sbc_flags bit 0: also isbcu/asbcu of this column (they read u(tau) only, so their place in the sequence is free)
+__global__ void __launch_bounds__(64) k_clinic_finish(const uvic_mom_ctx m, int sbc_flags, double rts) {
   COL_DECODE(m);
   if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
   clinic_finish_column(m, i, j);
+  if (sbc_flags & 1) clinic_sbcu_cell(m, i, j, (sbc_flags >> 1) & 3, rts);
 }
 // polar filter of u(tau+1): one workgroup per strip of a level of a row (both components)
 __global__ void __launch_bounds__(1024) k_filuv(const uvic_mom_ctx m, const FilterItem *items, const double *mats, const double *spsin,
@@ -217,11 +219,6 @@ __global__ void __launch_bounds__(64) k_filuv_mean(const uvic_mom_ctx m, const i
   const int j = rows[r];
   if (j < m.js || j > m.je) return;
   filuv_mean_column(m.imt, m.km, i, j, m.kmu, m.hr, m.dzt, m.up1, m.up2);
-}
-__global__ void __launch_bounds__(256) k_clinic_sbcu(const uvic_mom_ctx m, int flags, double rts) {
-  COL_DECODE(m);
-  if (j < m.js || j > m.je || i < 2 || i > m.imt - 1) return;
-  clinic_sbcu_cell(m, i, j, flags, rts);
 }
 __global__ void __launch_bounds__(256) k_ai_coef(const uvic_ctx c, double *cf) {
   if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
@@ -1937,19 +1934,16 @@ static int launch_clinic(uvic_gpu *h, int sbc_flags, double rts) {
   mark(h, "clinic_gradp");
   hipLaunchKernelGGL(k_clinic_tend, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, m);
   mark(h, "clinic_tend");
-  hipLaunchKernelGGL(k_clinic_finish, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m);
+  hipLaunchKernelGGL(k_clinic_finish, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m, sbc_flags, rts);
   mark(h, "clinic_finish");
   if (int rc = launch_filuv(h, m)) return rc;
-  if (sbc_flags & 1) {
-    hipLaunchKernelGGL(k_clinic_sbcu, dim3(col_blocks(h, 256)), dim3(256), 0, h->stream, m, (sbc_flags >> 1) & 3, rts);
-    mark(h, "clinic_sbcu");
-  }
   HIPCHK(hipGetLastError());
   return 0;
 }
 static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m) {
   if (h->fltu_nitems == 0) return 0;
-  hipLaunchKernelGGL(k_filuv, dim3((unsigned)h->fltu_nitems), dim3(h->fltu_threads), (size_t)(3 * h->fltu_threads + 4) * 8, h->stream, m,
+  // 2*H threads per strip (H = strip length rounded up to a wave): the two components are filtered side by side
+  hipLaunchKernelGGL(k_filuv, dim3((unsigned)h->fltu_nitems), dim3(2 * h->fltu_threads), (size_t)(4 * h->fltu_threads + 8) * 8, h->stream, m,
                      h->fltu_items, h->fltu_mats, (const double *)h->buf[UVIC_F_SPSIN], (const double *)h->buf[UVIC_F_SPCOS],
                      h->fltu_nitems);
   mark(h, "filuv");
@@ -2017,7 +2011,7 @@ extern "C" int uvic_gpu_set_filter_u(uvic_gpu *h, double pi, int jfrst, int jfu0
   if (fs.items.empty()) return 0;
   int maxim = 0;
   for (auto &it : fs.items) maxim = it.im > maxim ? it.im : maxim;
-  if (maxim > 1024) return fail_msg("uvic_gpu_set_filter_u: strips longer than 1024 columns are not supported");
+  if (maxim > 512) return fail_msg("uvic_gpu_set_filter_u: strips longer than 512 columns are not supported");
   h->fltu_threads = ((maxim + 63) / 64) * 64;
   HIPCHK(hipMalloc((void **)&h->fltu_items, fs.items.size() * sizeof(FilterItem)));
   HIPCHK(hipMemcpy(h->fltu_items, fs.items.data(), fs.items.size() * sizeof(FilterItem), hipMemcpyHostToDevice));
