@@ -183,51 +183,58 @@ UVIC_DEV void clinic_tend_cell(const uvic_mom_ctx &m, int i, int k, int j) {
   }
 }
 
-// clinic.F:376-485 for one column: zu, u(tau+1) = u(tau-1) + c2dtuv*tendency, minus its vertical mean, cyclic images
+// clinic.F:376-485 for one column: zu, u(tau+1) = u(tau-1) + c2dtuv*tendency, minus its vertical mean, cyclic images.
+// Both components march together (their loads share a batch); each sum keeps the reference's order.
 UVIC_DEV void clinic_finish_column(const uvic_mom_ctx &m, int i, int j) {
   UV_DIMS(m);
   const size_t N2 = (size_t)imt * jmt;
   const int kb = m.kmu[X2(i, j)];
   const double hr = m.hr[X2(i, j)];
-  for (int n = 1; n <= 2; ++n) {
-    double *up = (n == 1) ? m.up1 : m.up2;
-    const double *um = (n == 1) ? m.um1 : m.um2;
-    double zu = 0.0, baru = 0.0;
-    for (int k0 = 1; k0 <= km; k0 += UV_KB) {
-      double td[UV_KB], u0[UV_KB];
+  double zu1 = 0.0, zu2 = 0.0, baru1 = 0.0, baru2 = 0.0;
+  for (int k0 = 1; k0 <= km; k0 += UV_KB) {
+    double td1[UV_KB], td2[UV_KB], a1[UV_KB], a2[UV_KB];
 #pragma unroll
-      for (int q = 0; q < UV_KB; ++q) {
-        const int k = (k0 + q <= km) ? k0 + q : km;
-        td[q] = up[X3(i, k, j)];
-        u0[q] = um[X3(i, k, j)];
-      }
+    for (int q = 0; q < UV_KB; ++q) {
+      const size_t x = X3(i, (k0 + q <= km) ? k0 + q : km, j);
+      td1[q] = m.up1[x]; td2[q] = m.up2[x];
+      a1[q] = m.um1[x]; a2[q] = m.um2[x];
+    }
 #pragma unroll
-      for (int q = 0; q < UV_KB; ++q) {
-        const int k = k0 + q;
-        if (k <= km) {
-          zu = zu + td[q] * m.dzt[k - 1];
-          const double v = u0[q] + m.c2dtuv * td[q];
-          baru = baru + v * m.dzt[k - 1];
-          up[X3(i, k, j)] = v;
-        }
+    for (int q = 0; q < UV_KB; ++q) {
+      const int k = k0 + q;
+      if (k <= km) {
+        const double dz = m.dzt[k - 1];
+        zu1 = zu1 + td1[q] * dz;
+        zu2 = zu2 + td2[q] * dz;
+        const double v1 = a1[q] + m.c2dtuv * td1[q], v2 = a2[q] + m.c2dtuv * td2[q];
+        baru1 = baru1 + v1 * dz;
+        baru2 = baru2 + v2 * dz;
+        m.up1[X3(i, k, j)] = v1;
+        m.up2[X3(i, k, j)] = v2;
       }
     }
-    m.zu[X2(i, j) + (size_t)(n - 1) * N2] = zu * hr;
-    baru = baru * hr;
-    for (int k0 = 1; k0 <= km; k0 += UV_KB) {
-      double vv[UV_KB];
+  }
+  m.zu[X2(i, j)] = zu1 * hr;
+  m.zu[X2(i, j) + N2] = zu2 * hr;
+  baru1 = baru1 * hr;
+  baru2 = baru2 * hr;
+  for (int k0 = 1; k0 <= km; k0 += UV_KB) {
+    double w1[UV_KB], w2[UV_KB];
 #pragma unroll
-      for (int q = 0; q < UV_KB; ++q) vv[q] = up[X3(i, (k0 + q <= km) ? k0 + q : km, j)];
+    for (int q = 0; q < UV_KB; ++q) {
+      const size_t x = X3(i, (k0 + q <= km) ? k0 + q : km, j);
+      w1[q] = m.up1[x]; w2[q] = m.up2[x];
+    }
 #pragma unroll
-      for (int q = 0; q < UV_KB; ++q) {
-        const int k = k0 + q;
-        if (k <= km) {
-          const double mask = (k <= kb) ? 1.0 : 0.0;
-          const double v = vv[q] - mask * baru;
-          up[X3(i, k, j)] = v;
-          if (i == 2) up[X3(imt, k, j)] = v;
-          if (i == imt - 1) up[X3(1, k, j)] = v;
-        }
+    for (int q = 0; q < UV_KB; ++q) {
+      const int k = k0 + q;
+      if (k <= km) {
+        const double mask = (k <= kb) ? 1.0 : 0.0;
+        const double v1 = w1[q] - mask * baru1, v2 = w2[q] - mask * baru2;
+        m.up1[X3(i, k, j)] = v1;
+        m.up2[X3(i, k, j)] = v2;
+        if (i == 2) { m.up1[X3(imt, k, j)] = v1; m.up2[X3(imt, k, j)] = v2; }
+        if (i == imt - 1) { m.up1[X3(1, k, j)] = v1; m.up2[X3(1, k, j)] = v2; }
       }
     }
   }

@@ -159,35 +159,43 @@ UVIC_DEV void filuv_block(Env &env, int imt, int km, const FilterItem &it, const
 }
 
 // filuv.F:155-181 for one column of a filtered row: the vertical mean is removed again (from every level), then the
-// land mask; with the cyclic images of clinic.F:506-509
+// land mask; with the cyclic images of clinic.F:506-509.  Both components march together, eight levels per batch.
 UVIC_DEV void filuv_mean_column(int imt, int km, int i, int j, const int *kmu, const double *hr, const double *dzt, double *u1,
                                 double *u2) {
   const int kb = kmu[X2(i, j)];
-  for (int n = 1; n <= 2; ++n) {
-    double *u = (n == 1) ? u1 : u2;
-    double acc = 0.0;
-    for (int k0 = 1; k0 <= km; k0 += 8) {
-      double a[8];
+  double acc1 = 0.0, acc2 = 0.0;
+  for (int k0 = 1; k0 <= km; k0 += 8) {
+    double a[8], b[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] = u[X3(i, (k0 + q <= km) ? k0 + q : km, j)];
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (k0 + q <= km) acc = acc + a[q] * dzt[k0 + q - 1];
+    for (int q = 0; q < 8; ++q) {
+      const size_t x = X3(i, (k0 + q <= km) ? k0 + q : km, j);
+      a[q] = u1[x]; b[q] = u2[x];
     }
-    acc = acc * hr[X2(i, j)];
-    for (int k0 = 1; k0 <= km; k0 += 8) {
-      double a[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) a[q] = u[X3(i, (k0 + q <= km) ? k0 + q : km, j)];
+    for (int q = 0; q < 8; ++q)
+      if (k0 + q <= km) {
+        acc1 = acc1 + a[q] * dzt[k0 + q - 1];
+        acc2 = acc2 + b[q] * dzt[k0 + q - 1];
+      }
+  }
+  acc1 = acc1 * hr[X2(i, j)];
+  acc2 = acc2 * hr[X2(i, j)];
+  for (int k0 = 1; k0 <= km; k0 += 8) {
+    double a[8], b[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int k = k0 + q;
-        if (k <= km) {
-          const double v = (a[q] - acc) * ((k <= kb) ? 1.0 : 0.0);
-          u[X3(i, k, j)] = v;
-          if (i == 2) u[X3(imt, k, j)] = v;
-          if (i == imt - 1) u[X3(1, k, j)] = v;
-        }
+    for (int q = 0; q < 8; ++q) {
+      const size_t x = X3(i, (k0 + q <= km) ? k0 + q : km, j);
+      a[q] = u1[x]; b[q] = u2[x];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + q;
+      if (k <= km) {
+        const double mask = (k <= kb) ? 1.0 : 0.0;
+        const double v1 = (a[q] - acc1) * mask, v2 = (b[q] - acc2) * mask;
+        u1[X3(i, k, j)] = v1; u2[X3(i, k, j)] = v2;
+        if (i == 2) { u1[X3(imt, k, j)] = v1; u2[X3(imt, k, j)] = v2; }
+        if (i == imt - 1) { u1[X3(1, k, j)] = v1; u2[X3(1, k, j)] = v2; }
       }
     }
   }
