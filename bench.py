@@ -280,6 +280,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # The HBM denominator is measured first, on every rank: it also brings the card from its idle power
+    # state to its operating clocks, which otherwise takes the first ~60 steps of the loop (tools/step_trace.py: blocks
+    # of 8 steps from a cold start run 0.41, 0.34, 0.32, 0.32, 0.31, 0.31, 0.30, ... ms per step); a time loop of hours
+    # runs in the steady state, and that is what W warm-up + K timed steps should see whatever W is.
+    try:
+        hbm = hbm_probe(torch)
+    except Exception as e:   # never let the side measurement break the bench line
+        hbm = {"error": str(e)}
     for _ in range(a.warmup):
         one_step()
     barrier()
@@ -378,10 +386,6 @@ def main():
         ach = kernel_alg_bytes(dom, nt_launch, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
         step_gbs = b_alg(nt, nsrc) * value / 1e9
         traffic, traffic_src = pmc_traffic(dom, world == 1 and a.cfg == "c30" and a.grid == "102x102x19", split="colfct_ts" in prof)
-        try:
-            hbm = hbm_probe(torch) if world == 1 else None
-        except Exception as e:   # never let the side measurement break the bench line
-            hbm = {"error": str(e)}
         hbm_meas = max(hbm.get("copy_GBs", 0.0), hbm.get("triad_GBs", 0.0)) if hbm else 0.0
         out = {
             "metric": "tracer-cell updates/s (imt*jmt*km*nt)", "value": value, "unit": "cell-updates/s",
