@@ -328,6 +328,24 @@ int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p);
  * uvic_params.diff_cbt_has_k33 = 1 (isopyc then leaves diff_cbt to this call). */
 int uvic_gpu_vmixc(uvic_gpu *h);
 
+/* ---- the reference's second, coarser boundary: the O_TMM column-batch source operator --------
+ * With -DO_TMM u09/common/size.h:26-30 makes imt the batch size and jmt = 1, and `tracer` keeps only the MOBI source
+ * loop and the 14C source (u09/mom/tracer.F:109-124, 214/304, 894/1288): the external Transport-Matrix-Method driver
+ * fills t(1:imt,:,1,:,taum1), kmt(1:imt,1) and the forcing of the batch, calls `tracer (0, 1, 1, 1, imt)` and reads
+ * src(imt,km,1,nsrc) from COMMON /mobicomm/.  These three calls are that operator: columns in, sources out, no
+ * horizontal structure.  (The handle is an ordinary one whose grid holds the batch in one row; only the calls below
+ * and uvic_gpu_destroy are meant for it.)
+ *   kmt (ncols); forcing `f` with per-column arrays: tlat, dnswr, aice, hice, hsno (ncols), sg_bathy and fe_hydr
+ *   (ncols,km), fe_atmdep (ncols,12) -- the reference's (imt,1,..) arrays as they lie in memory;
+ *   `o` null = option set C (uvic_gpu_set_mobi), else as uvic_gpu_set_mobi_opt. */
+int uvic_gpu_tmm_create(uvic_gpu **h, int ncols, int km, int nt, int nsrc, int ntnpzd, int device);
+int uvic_gpu_tmm_set_mobi(uvic_gpu *h, const int32_t *kmt, const uvic_mobi_params *p, const uvic_mobi_options *o,
+                          const uvic_mobi_forcing *f);
+/* one call of the O_TMM `tracer`: t_taum1 (ncols,km,nt) in, src (ncols,km,nsrc) out; c2dtts, relyr, co2ccn as the
+ * reference reads them from COMMON (scalar.h, tmngr.h, cembm.h); the four forcing fields (ncols) may be null = unchanged */
+int uvic_gpu_tmm_sources(uvic_gpu *h, double c2dtts, double relyr, double co2ccn, const double *t_taum1, const double *dnswr,
+                         const double *aice, const double *hice, const double *hsno, double *src);
+
 /* ---- baroclinic momentum step -------------------------------------------
  * scalars of `clinic`: scalar.h c2dtuv, grav, rho0r, cdbot; vmixc.h kappa_m (O_constvmix: visc_cbu = kappa_m,
  * u09/mom/vmixc.F:85) */

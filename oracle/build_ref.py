@@ -66,6 +66,17 @@ CONFIGS = {
     "m2": BASE + "O_stream_function O_anisotropic_viscosity O_ice_evp".split(),
 }
 
+# the reference's second boundary: -DO_TMM turns `tracer` into the column-batch source operator of the
+# Transport-Matrix-Method driver: imt = batch size, jmt = 1 (u09/common/size.h:26-30)
+CONFIGS["tmm30"] = CONFIGS["c30"] + ["O_TMM"]
+
+# ... and compiles without the transport routines (their row arithmetic has no meaning with jmt = 1)
+ONLY_SOURCES = {
+    "tmm30": ["updates/09/source/mom/tracer.F", "updates/09/source/mom/mobi.F", "updates/09/source/common/co2calc.F",
+              "source/common/util.F", "updates/09/source/common/iomngr.F", "updates/09/source/common/file_names.F",
+              "updates/09/source/common/UVic_ESCM.F", "source/mom/denscoef.F"],
+}
+
 # sources compiled for some configurations only
 EXTRA_SOURCES = {
     "m2": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F"],
@@ -87,6 +98,7 @@ SOURCES = [
 ]
 
 SIZE_RE = re.compile(r"parameter \(imt=\s*102, jmt=\s*102, km=\s*19\)")
+TMM_SIZE_RE = re.compile(r"parameter \(imt=\s*2000, jmt=\s*1, km=\s*19\)")
 
 
 def run(cmd, **kw):
@@ -118,7 +130,7 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
     size_line = f"parameter (imt={imt}, jmt={jmt}, km={km})"
 
     def patch(text: str) -> str:
-        return SIZE_RE.sub(size_line, text)
+        return TMM_SIZE_RE.sub(size_line, SIZE_RE.sub(size_line, text))
 
     # 1. headers, overlay order
     for d in HDR_DIRS:
@@ -130,7 +142,7 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
     for d in reversed(HDR_DIRS):
         incs += ["-I", str(REF / d)]
     objs = []
-    for s in SOURCES + EXTRA_SOURCES.get(cfg, []):
+    for s in ONLY_SOURCES.get(cfg, SOURCES + EXTRA_SOURCES.get(cfg, [])):
         src = REF / s
         r = run(["cpp", "-traditional", "-P", *incs, *defs, str(src)])
         text = patch(r.stdout)
@@ -202,6 +214,7 @@ DEFAULT_BUILDS = [
     ("p2", 102, 102, 19), ("c30", 102, 102, 19),
     ("f18", 14, 14, 6), ("s37", 14, 14, 6),       # MOBI option sets F and run/mk.in's (tests/test_mobi_sets.py)
     ("m2", 14, 14, 6), ("m2", 102, 102, 19),      # momentum step: clinic, filuv, setvbc (tests/test_clinic.py)
+    ("tmm30", 64, 1, 6),                          # `tracer` as the O_TMM column-batch operator (tests/test_tmm.py)
 ]
 
 

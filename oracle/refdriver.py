@@ -322,3 +322,58 @@ class RefOcean:
     def flush(self):
         """Resident overlay only: the device's t(tau-1), t(tau) into the host's slots."""
         self.ref.call("tracer_gpu_flush")
+
+
+# ---- the reference's second boundary: `tracer` built with -DO_TMM (SURVEY.md §3.5) -----------------------------
+def tmm_reference_sources(ocean, cols, c2dtts=None, quiet=True):
+    """Source terms of a batch of columns from the reference compiled with O_TMM (build "tmm30": imt = batch size,
+    jmt = 1; `tracer` is then only the MOBI source loop + the 14C source and publishes src in COMMON /mobicomm/,
+    updates/09/source/mom/tracer.F:109-124).  `cols`: list of 1-based (i, j) of the synthetic ocean; returns
+    src (ncols, km, nsrc)."""
+    import ctypes
+    g, cfg, prm, f, topo = ocean.grid, ocean.cfg, ocean.params, ocean.forcing, ocean.topo
+    ncols, km = len(cols), g.km
+    ref = RefLib("tmm30", ncols, 1, km)
+    v, S = ref.v, ref.set
+    ii = np.array([c[0] - 1 for c in cols]); jj = np.array([c[1] - 1 for c in cols])
+    S("pi", g.pi); S("radian", g.radian); S("daylen", 86400.0)
+    S("dtts", prm.dtts); S("c2dtts", 2.0 * prm.dtts if c2dtts is None else c2dtts)
+    S("taum1", -1); S("tau", 0); S("taup1", 1)
+    S("eots", 1); S("relyr", f.relyr)
+    for n in ("zw", "zt", "dzt", "dzw", "dztr", "dzt2r", "dzwr"):
+        v[n][...] = getattr(g, n)
+    v["kmt"][:, 0] = topo.kmt[ii, jj]
+    v["sg_bathy"][:, 0, :] = topo.sg_bathy[ii, jj, :]
+    v["tlat"][:, 0] = g.tlat[ii, jj]
+    saved = None
+    if quiet:
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 1); os.close(devnull)
+    try:
+        ref.call("tracer_init")
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                Path("control.in").write_text(trimmed_control_in(cfg.options))
+                ref.call("mobi_init")
+            finally:
+                os.chdir(cwd)
+    finally:
+        if saved is not None:
+            ref.lib.orc_flush_()
+            os.dup2(saved, 1); os.close(saved)
+    v["t"][:, :, 0, :, 0] = ocean.t_taum1[ii, :, jj, :]
+    v["dnswr"][:, 0] = f.dnswr[ii, jj]
+    v["aice"][:, 0, 1] = f.aice[ii, jj]
+    v["hice"][:, 0, 1] = f.hice[ii, jj]
+    v["hsno"][:, 0, 1] = f.hsno[ii, jj]
+    S("co2ccn", f.co2ccn)
+    v["fe_atmdep"][:, 0, 0, :] = f.fe_atmdep[ii, jj, :]
+    v["fe_hydr"][:, 0, :] = f.fe_hydr[ii, jj, :]
+    ref.call("tracer", 0, 1, 1, 1, ncols)
+    n = ncols * km * cfg.nsrc
+    buf = (ctypes.c_double * n).in_dll(ref.lib, "mobicomm_")
+    return np.frombuffer(buf, dtype=np.float64, count=n).reshape((ncols, km, cfg.nsrc), order="F").copy()

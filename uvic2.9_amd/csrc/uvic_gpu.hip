@@ -721,6 +721,7 @@ struct uvic_gpu {
   int mobi_key;   // n15 | c13<<1 | caco3<<2 | silicon<<3 of the set bound by uvic_gpu_set_mobi_opt
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
+  int tmm_ncols;    // > 0: a column-batch handle (uvic_gpu_tmm_create); the batch is row 2, columns 2..ncols+1
   // baroclinic momentum step (uvic_gpu_state / uvic_gpu_clinic)
   uvic_clinic_params clinic_p;
   bool have_clinic;
@@ -825,7 +826,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 5; }   // 5: uvic_gpu_state, uvic_gpu_clinic (baroclinic momentum step)
+extern "C" int uvic_gpu_abi_version(void) { return 6; }   // 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -876,6 +877,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->profiling = false;
   h->have_mobi = false;
   h->have_vmix = false;
+  h->tmm_ncols = 0;
   h->have_clinic = false;
   h->fltu_items = nullptr; h->fltu_mats = nullptr; h->fltu_rows = nullptr; h->fltu_nitems = h->fltu_threads = h->fltu_nrows = 0;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
@@ -1884,6 +1886,74 @@ extern "C" int uvic_gpu_vmixc(uvic_gpu *h) {
   HIPCHK(hipSetDevice(h->device));
   if (int rc = launch_vmixc(h)) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// -- O_TMM column-batch source operator: host-side packing around the calls above ------------------------------
+extern "C" int uvic_gpu_tmm_create(uvic_gpu **out, int ncols, int km, int nt, int nsrc, int ntnpzd, int device) {
+  if (ncols < 4) return fail_msg("uvic_gpu_tmm_create: a batch needs at least 4 columns");
+  uvic_dims d;
+  d.imt = ncols + 2; d.jmt = 6; d.km = km; d.nt = nt; d.nsrc = nsrc; d.ntnpzd = ntnpzd;
+  if (int rc = uvic_gpu_create(out, &d, device)) return rc;
+  (*out)->tmm_ncols = ncols;
+  return 0;
+}
+// per-column array with `x` values per column, (ncols, x) -> the (imt, jmt, x) array of the handle's grid, row 2
+static std::vector<double> tmm_pad(const uvic_gpu *h, const double *cols, int x) {
+  const int imt = h->d.imt, jmt = h->d.jmt, nc = h->tmm_ncols;
+  std::vector<double> a((size_t)imt * jmt * x, 0.0);
+  if (cols)
+    for (int q = 0; q < x; ++q)
+      for (int c = 0; c < nc; ++c) a[(size_t)(c + 1) + (size_t)imt * (1 + (size_t)jmt * q)] = cols[(size_t)c + (size_t)nc * q];
+  return a;
+}
+extern "C" int uvic_gpu_tmm_set_mobi(uvic_gpu *h, const int32_t *kmt, const uvic_mobi_params *p, const uvic_mobi_options *o,
+                                     const uvic_mobi_forcing *f) {
+  if (!h || !kmt || !p || !f) return fail_msg("uvic_gpu_tmm_set_mobi: null argument");
+  if (h->tmm_ncols <= 0) return fail_msg("uvic_gpu_tmm_set_mobi: not a column-batch handle (uvic_gpu_tmm_create)");
+  const int imt = h->d.imt, jmt = h->d.jmt, km = h->d.km, nc = h->tmm_ncols;
+  std::vector<int32_t> k2((size_t)imt * jmt, 0);
+  for (int c = 0; c < nc; ++c) {
+    if (kmt[c] < 0 || kmt[c] > km) return fail_msg("uvic_gpu_tmm_set_mobi: kmt out of range");
+    k2[(size_t)(c + 1) + (size_t)imt] = kmt[c];
+  }
+  if (int rc = uvic_gpu_upload(h, UVIC_F_KMT, k2.data(), 0, (int64_t)k2.size())) return rc;
+  std::vector<int32_t> itrc((size_t)h->d.nt, 0);   // sources are read where they lie: no tracer takes one here
+  if (int rc = uvic_gpu_upload(h, UVIC_F_ITRC, itrc.data(), 0, (int64_t)itrc.size())) return rc;
+  const std::vector<double> tlat = tmm_pad(h, f->tlat, 1), dnswr = tmm_pad(h, f->dnswr, 1), aice = tmm_pad(h, f->aice, 1),
+                            hice = tmm_pad(h, f->hice, 1), hsno = tmm_pad(h, f->hsno, 1), sgb = tmm_pad(h, f->sg_bathy, km),
+                            dep = tmm_pad(h, f->fe_atmdep, 12), hyd = tmm_pad(h, f->fe_hydr, km);
+  uvic_mobi_forcing g = *f;
+  g.tlat = tlat.data(); g.dnswr = dnswr.data(); g.aice = aice.data(); g.hice = hice.data(); g.hsno = hsno.data();
+  g.sg_bathy = sgb.data(); g.fe_atmdep = dep.data(); g.fe_hydr = hyd.data();
+  return o ? uvic_gpu_set_mobi_opt(h, p, o, &g) : uvic_gpu_set_mobi(h, p, &g);
+}
+extern "C" int uvic_gpu_tmm_sources(uvic_gpu *h, double c2dtts, double relyr, double co2ccn, const double *t_taum1, const double *dnswr,
+                                    const double *aice, const double *hice, const double *hsno, double *src) {
+  if (!h || !t_taum1 || !src) return fail_msg("uvic_gpu_tmm_sources: null argument");
+  if (h->tmm_ncols <= 0) return fail_msg("uvic_gpu_tmm_sources: not a column-batch handle (uvic_gpu_tmm_create)");
+  if (!h->have_mobi) return fail_msg("uvic_gpu_tmm_sources: call uvic_gpu_tmm_set_mobi first");
+  const int imt = h->d.imt, km = h->d.km, nt = h->d.nt, nsrc = h->d.nsrc, nc = h->tmm_ncols;
+  // t(1:ncols,:,1,:,taum1) -> row 2 of the handle's grid, one column of padding either side
+  std::vector<double> st((size_t)imt * km * (nt > nsrc ? nt : nsrc), 0.0);
+  for (int n = 0; n < nt; ++n)
+    for (int k = 0; k < km; ++k)
+      memcpy(&st[(size_t)1 + (size_t)imt * (k + (size_t)km * n)], t_taum1 + (size_t)nc * (k + (size_t)km * n), (size_t)nc * 8);
+  if (int rc = uvic_gpu_upload_rows(h, UVIC_F_T_TAUM1, st.data(), 2, 2)) return rc;
+  h->ctx.c2dtts = c2dtts;
+  if (dnswr || aice || hice || hsno) {
+    if (!(dnswr && aice && hice && hsno)) return fail_msg("uvic_gpu_tmm_sources: give all four forcing fields or none");
+    const std::vector<double> a = tmm_pad(h, dnswr, 1), b = tmm_pad(h, aice, 1), c = tmm_pad(h, hice, 1), d = tmm_pad(h, hsno, 1);
+    if (int rc = uvic_gpu_set_mobi_step(h, relyr, co2ccn, a.data(), b.data(), c.data(), d.data())) return rc;
+  } else if (int rc = uvic_gpu_set_mobi_step(h, relyr, co2ccn, nullptr, nullptr, nullptr, nullptr)) {
+    return rc;
+  }
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = launch_mobi(h)) return rc;
+  if (int rc = uvic_gpu_download_rows(h, UVIC_F_SRC, st.data(), 2, 2)) return rc;
+  for (int n = 0; n < nsrc; ++n)
+    for (int k = 0; k < km; ++k)
+      memcpy(src + (size_t)nc * (k + (size_t)km * n), &st[(size_t)1 + (size_t)imt * (k + (size_t)km * n)], (size_t)nc * 8);
   return 0;
 }
 
