@@ -143,6 +143,26 @@ def cpu_baseline(ocean, to, so, c, src, budget_s=20.0):
                       f"oracle (gcc -O2 -ffp-contract=off), {cfg.name} {g.imt}x{g.jmt}x{g.km}"}
 
 
+def clinic_cpu_baseline(imt, jmt, km, ncall=5):
+    """The reference's own state + clinic (with filuv) on one host core (oracle/_ref build "m2"), ms per call."""
+    import refmodel
+    if not refmodel.available("m2", imt, jmt, km):
+        return None
+    import refdriver
+    from uvic29_amd import synthetic
+    oc = synthetic.make_ocean("m2", imt, jmt, km)
+    ro = refdriver.RefOcean(oc)
+    ro.set_momentum(synthetic.make_momentum(oc.grid, oc.topo, oc.u))
+    ro.set_filter_u(synthetic.make_filter_u(oc.grid, km))
+    ro.adv_vel_u(); ro.setvbc()
+    ro.state(); ro.clinic()
+    g = oc.grid
+    t0 = time.perf_counter()
+    for _ in range(ncall):
+        ro.ref.call("clinic", 0, 2, g.jmt - 1, 2, g.imt - 1)
+    return (time.perf_counter() - t0) / ncall * 1e3
+
+
 def overlay_baseline(ocean, steps=40, segment=4):
     """The path the north star names: the reference's own call sequence with `tracer` replaced by the Fortran overlay
     (uvic2.9_amd/fortran/tracer_gpu.F -> ISO_C_BINDING -> libuvic_gpu.so), resident mode, driven through the compiled
@@ -372,6 +392,10 @@ def main():
                 if k in pr:
                     nxt[k] = round(pr[k], 5)
             m.set_filter_u(ocean, None)
+            if not a.no_cpu_baseline:
+                cms = clinic_cpu_baseline(imt, jmt, km)
+                if cms is not None:
+                    nxt["clinic_cpu_reference_ms_per_call"] = round(cms, 3)     # 1 core, compiled reference Fortran
         except Exception as e:   # never let the side measurement break the bench line
             nxt = {"error": str(e)}
         prof = live

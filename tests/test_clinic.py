@@ -162,6 +162,29 @@ def test_gpu_state_and_clinic_equal_oracle(imt, jmt, km):
 
 
 @pytest.mark.gpu
+def test_gpu_clinic_on_the_refined_grid_and_in_two_slabs():
+    """BASELINE config 5's grid (202x202x32): state + clinic bit-identical to the oracle, computed whole and as two
+    latitude slabs (uvic_gpu_set_shard js..je: each call fills its own U rows, the inputs around them are present)."""
+    oc, mom, eos, flt = _setup(202, 202, 32)
+    rho, M, up, zu = _oracle_step(oc, mom, eos, flt)
+    m = _gpu_model(oc, mom, eos)
+    m.set_filter_u(oc, flt)
+    m.state()
+    got_u, got_zu = m.clinic()
+    assert np.array_equal(got_zu, zu) and np.array_equal(got_u, up)
+    for n in ("up1", "up2"):
+        m.upload(n, np.zeros(m.shape(n), order="F"))
+    m.upload("zu", np.zeros(m.shape("zu"), order="F"))
+    for js, je in ((2, 101), (102, 201)):
+        m.set_shard(js=js, je=je)
+        m.clinic_only()
+    m.set_shard(js=2, je=201)
+    got_u = np.stack([m.download("up1"), m.download("up2")], axis=-1)
+    assert np.array_equal(m.download("zu"), zu) and np.array_equal(got_u, up)
+    m.close()
+
+
+@pytest.mark.gpu
 def test_gpu_clinic_matches_golden_fixture():
     gold = np.load(ROOT / "tests" / "golden" / "clinic_m2_14x14x6.npz")
     oc, mom, eos, flt = _setup(14, 14, 6)
