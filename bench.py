@@ -391,6 +391,21 @@ def main():
             for k in ("state", "clinic_gradp", "clinic_tend", "clinic_finish", "filuv", "filuv_mean"):
                 if k in pr:
                     nxt[k] = round(pr[k], 5)
+            # the whole memory-window loop of mom.F on the device (everything but tropic): tracer step with its look-ahead
+            # chains + add_ext_mode, state, adv_vel, clinic; one wait per step (zu back to the host, psi up)
+            from uvic29_amd.tracer import OceanLoop
+            m.load_ocean(ocean, to, so, c, src=src)
+            m.load_velocity(ocean)
+            m.load_momentum(ocean, mom)
+            oloop = OceanLoop(m, ocean.params.dtts, mom.dtuv)
+            psi0 = np.zeros((imt, jmt), order="F")
+            for _ in range(8):
+                oloop.step(psi0)
+            tq = time.perf_counter()
+            for _ in range(40):
+                zu_last = oloop.step(psi0)
+            nxt["ocean_loop_ms_per_step"] = round((time.perf_counter() - tq) / 40 * 1e3, 5)
+            nxt["ocean_loop_finite"] = bool(np.isfinite(zu_last).all() and np.isfinite(m.download("u1")).all())
             m.set_filter_u(ocean, None)
             if not a.no_cpu_baseline:
                 cms = clinic_cpu_baseline(imt, jmt, km)

@@ -86,6 +86,7 @@ enum uvic_field {
   UVIC_F_SBC_GU, UVIC_F_SBC_GV, UVIC_F_SBC_SU, UVIC_F_SBC_SV, /* S: the sbc planes igu, igv (isbcu) and isu, isv (asbcu) */
   UVIC_F_SPSIN, UVIC_F_SPCOS,                 /* (imt) cpolar.h: rotation to polar-stereographic components in filuv */
   UVIC_F_PHI,                                 /* (jmt) coord.h: latitude of the U rows in radians (its sign, filuv.F:66-67) */
+  UVIC_F_PSI,                                 /* (imt,jmt,2) emode.h psi: stream function at tau (,,1) and tau-1 (,,2) from `tropic` */
   UVIC_F_COUNT
 };
 
@@ -321,6 +322,7 @@ int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north);
  * replaces `call adv_vel (joff, js, je, is, ie)` (source/mom/mom.F:332; source/mom/adv_vel.F:63-131, the
  * T-cell part, rigid lid): UVIC_F_ADV_VET/VNT/VBT from UVIC_F_U1/U2 */
 int uvic_gpu_adv_vel(uvic_gpu *h);
+int uvic_gpu_adv_vel_async(uvic_gpu *h);   /* queued on the main stream, no wait */
 int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p);
 /* replaces the tracer part of `call vmixc (joff, js, je, is, ie)` (mom.F:347; u09/mom/vmixc.F:62-190 with
  * O_constvmix O_tidal_kv O_isopycmix): UVIC_F_DIFF_CBT = max(kappa_h, min(100, tidal + kappa_h)) above the
@@ -369,6 +371,14 @@ int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts);
  * the momentum step device-resident between the tracer steps */
 int uvic_gpu_state_async(uvic_gpu *h);
 int uvic_gpu_clinic_async(uvic_gpu *h, int sbc_flags, double rts);
+/* device-resident velocities: what u09/mom/loadmw.F does to u at the start of a time step with the memory window wide
+ * open (:86-99): the time levels rotate (tau-1 <- tau <- tau+1, by pointer: UVIC_F_UM1/UM2, U1/U2, UP1/UP2) ... */
+int uvic_gpu_rotate_u(uvic_gpu *h);
+/* ... and `call add_ext_mode (joff, js, je, istrt, iend, 'tau')` (loadmw.F:590-714, O_stream_function) adds the external
+ * mode from UVIC_F_PSI to the internal-mode velocities `clinic` left: level 0 = tau (from psi(,,1)), -1 = tau-1 (from
+ * psi(,,2); the reference does that on the first time step only).  Rows 1..jmt-1, land masked, cyclic images. */
+int uvic_gpu_add_ext_mode(uvic_gpu *h, int level);
+
 /* polar filter of the velocities: replaces `call filuv (joff, js, je)` (clinic.F:500; source/common/filuv.F with
  * O_fourfil O_cyclic).  Strips come from UVIC_F_KMU by findex's rule, rows jfrst..jfu1 and jfu2..jmt-1, reference
  * row jfu0 (index.h; u09/common/setcom.F:80-86).  jfrst > jmt switches it off. */

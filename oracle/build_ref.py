@@ -79,7 +79,8 @@ ONLY_SOURCES = {
 
 # sources compiled for some configurations only
 EXTRA_SOURCES = {
-    "m2": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F"],
+    "m2": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F",
+           "updates/09/source/mom/loadmw.F"],
 }
 
 HDR_DIRS = ["source/common", "source/mom", "source/embm", "source/ice",

@@ -253,6 +253,29 @@ void orc_clinic(orc_mom *m) {
   free(adv_fe); free(diff_fe); free(adv_fb); free(diff_fb); free(baru);
 }
 
+/* u09/mom/loadmw.F:627-667 (add_ext_mode, O_stream_function, one time level): psi (imt,jmt), u1/u2 in place, rows 1..jmt-1 */
+void orc_add_ext_mode(const orc_mom *m, const double *psi, double *u1, double *u2) {
+  const int imt = m->imt, jmt = m->jmt, km = m->km;
+  const int is = 2, ie = imt - 1;
+  double *ext1 = calloc(imt + 1, 8), *ext2 = calloc(imt + 1, 8);
+  for (int j = 1; j <= jmt - 1; ++j) {
+    for (int i = is; i <= ie; ++i) {
+      const double diag1 = psi[X2(i + 1, j + 1)] - psi[X2(i, j)];
+      const double diag0 = psi[X2(i, j + 1)] - psi[X2(i + 1, j)];
+      ext1[i] = -(diag1 + diag0) * m->dyu2r[j - 1] * m->hr[X2(i, j)];
+      ext2[i] = (diag1 - diag0) * m->dxu2r[i - 1] * m->hr[X2(i, j)] * m->csur[j - 1];
+    }
+    for (int k = 1; k <= km; ++k)
+      for (int i = is; i <= ie; ++i) {
+        u1[X3(i, k, j)] = (u1[X3(i, k, j)] + ext1[i]) * m->umask[X3(i, k, j)];
+        u2[X3(i, k, j)] = (u2[X3(i, k, j)] + ext2[i]) * m->umask[X3(i, k, j)];
+      }
+    setbcx(u1 + X3(1, 1, j), imt, km);
+    setbcx(u2 + X3(1, 1, j), imt, km);
+  }
+  free(ext1); free(ext2);
+}
+
 /* clinic.F:853-892: geostrophic (level 2) currents for the ice model */
 void orc_isbcu(const orc_mom *m, double *sbc_u, double *sbc_v, int osegs, int osege, double rts, const int *kmt) {
   const int imt = m->imt, jmt = m->jmt, km = m->km;

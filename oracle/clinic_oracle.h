@@ -54,6 +54,8 @@ void orc_adv_vel_u(orc_mom *m);
 void orc_bmf(orc_mom *m);
 /* u09/mom/clinic.F:24-560 for the option set of build_ref.py's "m2" without the polar filter */
 void orc_clinic(orc_mom *m);
+/* u09/mom/loadmw.F:590-667 add_ext_mode for one time level: psi (imt,jmt); u1, u2 (imt,km,jmt) in place */
+void orc_add_ext_mode(const orc_mom *m, const double *psi, double *u1, double *u2);
 /* u09/mom/clinic.F:816-895 (isbcu) and :729-811 (asbcu): accumulate u(tau) into two sbc planes (imt,jmt) each */
 void orc_isbcu(const orc_mom *m, double *sbc_u, double *sbc_v, int osegs, int osege, double rts, const int *kmt);
 void orc_asbcu(const orc_mom *m, double *sbc_u, double *sbc_v, int osegs, int osege, double rts, const int *kmt);

@@ -335,6 +335,13 @@ class Momentum:
         self.bmf()
         return self.clinic()
 
+    def add_ext_mode(self, psi, u):
+        """loadmw.F's add_ext_mode for one time level: psi (imt,jmt), u (imt,km,jmt,2); returns a new array."""
+        u1, u2 = np.array(u[..., 0], order="F"), np.array(u[..., 1], order="F")
+        ps = np.asfortranarray(psi, dtype=np.float64)
+        lib().orc_add_ext_mode(ctypes.byref(self.ctx), _p(ps), _p(u1), _p(u2))
+        return np.stack([u1, u2], axis=-1)
+
     def sbcu(self, which, sbc_u, sbc_v, osegs, osege, rts):
         """isbcu ("i") / asbcu ("a") in place on two (imt,jmt) planes."""
         f = lib().orc_isbcu if which == "i" else lib().orc_asbcu

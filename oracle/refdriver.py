@@ -259,6 +259,18 @@ class RefOcean:
         self.ref.call("findex", v["kmu"], flt.jmtfil, g.km, flt.jfu1, flt.jfu2, g.imt, v["isuf"], v["ieuf"])
         return np.array(v["isuf"], order="F"), np.array(v["ieuf"], order="F")
 
+    def add_ext_mode(self, psi, level="tau"):
+        """loadmw.F's add_ext_mode on u(tau) / u(tau-1) with psi (imt,jmt) as the stream function of that level."""
+        g, v = self.ocean.grid, self.v
+        v["psi"][:, :, 0 if level == "tau" else 1] = psi
+        lev = level.encode()
+        import ctypes
+        # character(*) dummy: the length follows the arguments, by value (flang / gfortran convention)
+        fn = getattr(self.ref.lib, "add_ext_mode_")
+        I = lambda x: ctypes.byref(ctypes.c_int(x))
+        fn(I(0), I(1), I(g.jmt), I(2), I(g.imt - 1), ctypes.c_char_p(lev), ctypes.c_size_t(len(lev)))
+        return np.array(v["u"][..., 1 if level == "tau" else 0], order="F")
+
     def state(self):
         """rho as loadmw.F:154 computes it: rows 2..jmt, all columns; returned over all jmt rows (row 1 zero)."""
         g, v = self.ocean.grid, self.v

@@ -244,6 +244,11 @@ extern "C" void emu_clinic(const uvic_mom_ctx *mp) {
   for (int j = m.js; j <= m.je; ++j)
     for (int i = 2; i <= m.imt - 1; ++i) clinic_finish_column(m, i, j);
 }
+extern "C" void emu_add_ext_mode(const uvic_mom_ctx *mp, const double *psi, double *u1, double *u2) {
+  const uvic_mom_ctx &m = *mp;
+  for (int j = 1; j <= m.jmt - 1; ++j)
+    for (int i = 2; i <= m.imt - 1; ++i) add_ext_mode_column(m, i, j, psi, u1, u2);
+}
 extern "C" void emu_sbcu(const uvic_mom_ctx *mp, int flags, double rts) {
   const uvic_mom_ctx &m = *mp;
   for (int j = m.js; j <= m.je; ++j)

@@ -66,6 +66,10 @@ def test_oracle_equals_reference(imt, jmt, km, filtered):
     assert np.array_equal(zu, zu_ref)
     assert np.array_equal(up, up_ref)
     assert np.abs(up).max() > 0.1 and np.abs(zu).max() > 1e-5
+    if not filtered:    # loadmw's add_ext_mode, both time levels
+        psi = _psi(oc.grid, 1)
+        assert np.array_equal(M.add_ext_mode(psi, oc.u), R.add_ext_mode(psi, "tau"))
+        assert np.array_equal(M.add_ext_mode(psi, mom.u_taum1), R.add_ext_mode(psi, "tau-1"))
 
 
 def test_oracle_sbc_accumulation_equals_reference():
@@ -119,6 +123,8 @@ def test_hostemu_equals_oracle(imt, jmt, km):
     assert np.array_equal(got_zu, zu) and np.array_equal(got_u, up)
     _, _, upf, _ = _oracle_step(oc, mom, eos, flt)
     assert np.array_equal(E.filuv(oc.grid, flt), upf) and not np.array_equal(upf, up)
+    psi = _psi(oc.grid, 1)
+    assert np.array_equal(E.add_ext_mode(psi, oc.u), M.add_ext_mode(psi, oc.u))
     # the surface-velocity accumulators, all four phases of a coupling segment
     rng = np.random.default_rng(1)
     planes = [np.asfortranarray(rng.standard_normal((imt, jmt))) for _ in range(4)]
@@ -235,4 +241,95 @@ def test_gpu_clinic_properties_at_full_size():
         assert np.all(u[..., n][topo.umask == 0.0][...] == 0.0) or np.all((u[..., n] * (1 - topo.umask))[1:-1, :, 1:-1] == 0.0)
         assert np.array_equal(u[0, :, 1:-1, n], u[-2, :, 1:-1, n]) and np.array_equal(u[-1, :, 1:-1, n], u[1, :, 1:-1, n])
     assert np.all(zu[topo.kmu == 0] == 0.0)
+    m.close()
+
+
+# ---- the whole memory-window loop on the device (mom.F:289-408 without tropic) -------------------------------------------
+def _psi(g, n):
+    """A smooth stream function that changes from step to step (stands in for tropic's solution), zero on the rim."""
+    lam = 2.0 * np.pi * (np.arange(1, g.imt + 1) - 1.0) / (g.imt - 2)
+    p = 2.0e11 * np.sin(g.phi * 2.0)[None, :] * (1.0 + 0.3 * np.sin(lam + 0.4 * n))[:, None] * np.cos(0.3 * n)
+    p = np.asfortranarray(p)
+    p[0] = p[-2]
+    p[-1] = p[1]
+    return p
+
+
+def _reference_loop(oc, mom, nsteps, filters):
+    """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
+    isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does."""
+    import refdriver
+    g = oc.grid
+    R = refdriver.RefOcean(oc)
+    R.set_momentum(mom)
+    if filters:
+        from uvic29_amd import synthetic
+        R.set_filter(synthetic.make_filter(g, g.km))
+        R.set_filter_u(synthetic.make_filter_u(g, g.km))
+    S, v = R.ref.set, R.v
+    # setvbc takes the surface tracer fluxes from sbc: give it the synthetic stf there (btf is zero without O_gthflx)
+    np_ = v["sbc"].shape[2]
+    S("ihflx", np_ - 3); S("isflx", np_ - 2)
+    v["sbc"][:, :, np_ - 4] = oc.stf[:, :, 0]
+    v["sbc"][:, :, np_ - 3] = oc.stf[:, :, 1]
+    zus = []
+    for n in range(1, nsteps + 1):
+        R.add_ext_mode(_psi(g, n), "tau")
+        if n == 1:
+            R.add_ext_mode(_psi(g, 0), "tau-1")
+        R.state()
+        R.ref.call("adv_vel", 0, 1, g.jmt, 2, g.imt - 1)
+        R.isopyc(); R.add_k33()
+        R.setvbc()
+        R.tracer()
+        _, zu, _ = R.clinic()
+        zus.append(zu)
+        R.rotate()
+        u = v["u"]
+        u[..., 0] = u[..., 1]
+        u[..., 1] = u[..., 2]
+    return np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus
+
+
+@pytest.mark.parametrize("imt,jmt,km,nsteps", [(14, 14, 6, 6), (102, 102, 19, 3)])
+def test_reference_loop_is_reproducible(imt, jmt, km, nsteps):
+    """The driver of the loop test itself: two runs of the reference loop agree (guards the fixture below)."""
+    import refmodel
+    if not refmodel.available("m2", imt, jmt, km):
+        pytest.skip("oracle/_ref build m2 not present")
+    oc, mom, _, _ = _setup(imt, jmt, km)
+    a = _reference_loop(oc, mom, 2, True)
+    b = _reference_loop(oc, mom, 2, True)
+    assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3]))
+    assert np.abs(a[1]).max() > 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("imt,jmt,km,nsteps", [(14, 14, 6, 6), (102, 102, 19, 3)])
+def test_gpu_memory_window_loop_equals_reference(imt, jmt, km, nsteps):
+    """Everything of mom.F's loop but `tropic` on the device, several steps, tracers and velocities resident: T, S, u at
+    both time levels and zu of every step bit-identical to the reference's own routines (exact transport kernels: T and
+    S are pure transport; the momentum kernels have one formulation)."""
+    import refmodel
+    from uvic29_amd import synthetic
+    from uvic29_amd.tracer import OceanLoop
+    if not refmodel.available("m2", imt, jmt, km):
+        pytest.skip("oracle/_ref build m2 did not travel with the tree")
+    oc, mom, eos, flt_u = _setup(imt, jmt, km)
+    t_ref, u_ref, um_ref, zus = _reference_loop(oc, mom, nsteps, True)
+    oc.btf[...] = 0.0
+    m = _gpu_model(oc, mom, eos)
+    m.set_exact(True)
+    m.load_velocity(oc)
+    m.set_filter(oc, synthetic.make_filter(oc.grid, km))
+    m.set_filter_u(oc, flt_u)
+    loop = OceanLoop(m, oc.params.dtts, mom.dtuv)
+    for n in range(1, nsteps + 1):
+        zu = loop.step(_psi(oc.grid, n), _psi(oc.grid, 0) if n == 1 else None)
+        assert np.array_equal(zu, zus[n - 1]), n
+    t = m.download("t_tau")
+    assert np.array_equal(t[:, :, 1:-1], t_ref[:, :, 1:-1])
+    u = np.stack([m.download("u1"), m.download("u2")], axis=-1)
+    um = np.stack([m.download("um1"), m.download("um2")], axis=-1)
+    assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
     m.close()

@@ -240,6 +240,37 @@ UVIC_DEV void clinic_finish_column(const uvic_mom_ctx &m, int i, int j) {
   }
 }
 
+// add_ext_mode, u09/mom/loadmw.F:627-667 (O_stream_function): the external mode of one U column from the stream function
+// around it, added to every level, land masked, cyclic images (setbcx, :664-666).  Rows 1..jmt-1.
+UVIC_DEV void add_ext_mode_column(const uvic_mom_ctx &m, int i, int j, const double *psi, double *u1, double *u2) {
+  UV_DIMS(m);
+  const double diag1 = psi[X2(i + 1, j + 1)] - psi[X2(i, j)];
+  const double diag0 = psi[X2(i, j + 1)] - psi[X2(i + 1, j)];
+  const double hr = m.hr[X2(i, j)];
+  const double ext1 = -(diag1 + diag0) * m.dyu2r[j - 1] * hr;
+  const double ext2 = (diag1 - diag0) * m.dxu2r[i - 1] * hr * m.csur[j - 1];
+  const int kb = m.kmu[X2(i, j)];
+  for (int k0 = 1; k0 <= km; k0 += UV_KB) {
+    double a[UV_KB], b[UV_KB];
+#pragma unroll
+    for (int q = 0; q < UV_KB; ++q) {
+      const size_t x = X3(i, (k0 + q <= km) ? k0 + q : km, j);
+      a[q] = u1[x]; b[q] = u2[x];
+    }
+#pragma unroll
+    for (int q = 0; q < UV_KB; ++q) {
+      const int k = k0 + q;
+      if (k <= km) {
+        const double mask = (k <= kb) ? 1.0 : 0.0;
+        const double v1 = (a[q] + ext1) * mask, v2 = (b[q] + ext2) * mask;
+        u1[X3(i, k, j)] = v1; u2[X3(i, k, j)] = v2;
+        if (i == 2) { u1[X3(imt, k, j)] = v1; u2[X3(imt, k, j)] = v2; }
+        if (i == imt - 1) { u1[X3(1, k, j)] = v1; u2[X3(1, k, j)] = v2; }
+      }
+    }
+  }
+}
+
 // isbcu (clinic.F:853-892) and asbcu (:765-810) for one column of one row; flags: bit 0 osegs, bit 1 osege
 UVIC_DEV void clinic_sbcu_cell(const uvic_mom_ctx &m, int i, int j, int flags, double rts) {
   UV_DIMS(m);

@@ -202,6 +202,11 @@ __global__ void __launch_bounds__(64) k_clinic_finish(const uvic_mom_ctx m, int 
   clinic_finish_column(m, i, j);
   if (sbc_flags & 1) clinic_sbcu_cell(m, i, j, (sbc_flags >> 1) & 3, rts);
 }
+__global__ void __launch_bounds__(64) k_add_ext_mode(const uvic_mom_ctx m, const double *psi, double *u1, double *u2) {
+  COL_DECODE(m);
+  if (j < 1 || j > m.jmt - 1 || i < 2 || i > m.imt - 1) return;
+  add_ext_mode_column(m, i, j, psi, u1, u2);
+}
 // polar filter of u(tau+1): one workgroup per strip of a level of a row (both components)
 __global__ void __launch_bounds__(1024) k_filuv(const uvic_mom_ctx m, const FilterItem *items, const double *mats, const double *spsin,
                                                 const double *spcos, int nitems) {
@@ -674,6 +679,7 @@ static const FieldDesc FIELDS[UVIC_F_COUNT] = {
     {"am4", K_JMT, 2, false},
     {"sbc_gu", K_S, 1, false}, {"sbc_gv", K_S, 1, false}, {"sbc_su", K_S, 1, false}, {"sbc_sv", K_S, 1, false},
     {"spsin", K_IMT, 1, false}, {"spcos", K_IMT, 1, false}, {"phi", K_JMT, 1, false},
+    {"psi", K_S, 2, false},
 };
 
 struct KernelStat {
@@ -826,7 +832,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 6; }   // 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 7; }   // 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -1811,6 +1817,7 @@ static int launch_mobi(uvic_gpu *h) {
 
 // -- producers of the shared inputs (kernels_prep.hpp) ---------------------------------
 static int launch_adv_vel(uvic_gpu *h) {
+  velocity_touched(h, UVIC_F_ADV_VET);   // a look-ahead chain formed its total velocities from the old ones: redo them
   mark(h, "begin");
   hipLaunchKernelGGL(k_adv_vel_hor, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
   mark(h, "adv_vel_hor");
@@ -1874,6 +1881,11 @@ extern "C" int uvic_gpu_adv_vel(uvic_gpu *h) {
   if (int rc = launch_adv_vel(h)) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
+}
+extern "C" int uvic_gpu_adv_vel_async(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  return launch_adv_vel(h);
 }
 extern "C" int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p) {
   if (!h || !p) return fail_msg("uvic_gpu_set_vmix_params: null argument");
@@ -2020,6 +2032,31 @@ static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m) {
   const unsigned n = (unsigned)h->fltu_nrows * (unsigned)h->d.imt;
   hipLaunchKernelGGL(k_filuv_mean, dim3((n + 63) / 64), dim3(64), 0, h->stream, m, h->fltu_rows, h->fltu_nrows);
   mark(h, "filuv_mean");
+  return 0;
+}
+extern "C" int uvic_gpu_rotate_u(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  // (pointer rotation only: kernels already queued hold the old pointers in their arguments)
+  void *m1 = h->buf[UVIC_F_UM1], *m2 = h->buf[UVIC_F_UM2];
+  h->buf[UVIC_F_UM1] = h->buf[UVIC_F_U1]; h->buf[UVIC_F_UM2] = h->buf[UVIC_F_U2];
+  h->buf[UVIC_F_U1] = h->buf[UVIC_F_UP1]; h->buf[UVIC_F_U2] = h->buf[UVIC_F_UP2];
+  h->buf[UVIC_F_UP1] = m1; h->buf[UVIC_F_UP2] = m2;
+  bind_ctx(h);
+  return 0;
+}
+extern "C" int uvic_gpu_add_ext_mode(uvic_gpu *h, int level) {
+  if (!h) return fail_msg("null handle");
+  if (level != 0 && level != -1) return fail_msg("uvic_gpu_add_ext_mode: level is 0 (tau) or -1 (tau-1)");
+  HIPCHK(hipSetDevice(h->device));
+  const uvic_mom_ctx m = mom_ctx(h);
+  const double *psi = (const double *)h->buf[UVIC_F_PSI] + (level == 0 ? 0 : (size_t)h->d.imt * h->d.jmt);
+  double *u1 = (double *)h->buf[level == 0 ? UVIC_F_U1 : UVIC_F_UM1], *u2 = (double *)h->buf[level == 0 ? UVIC_F_U2 : UVIC_F_UM2];
+  mark(h, "begin");
+  hipLaunchKernelGGL(k_add_ext_mode, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m, psi, u1, u2);
+  mark(h, "add_ext_mode");
+  HIPCHK(hipGetLastError());
+  if (h->host_sync) HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 extern "C" int uvic_gpu_set_clinic_params(uvic_gpu *h, const uvic_clinic_params *p) {

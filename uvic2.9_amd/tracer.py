@@ -64,7 +64,7 @@ class TracerModel:
             "rho": C, "um1": C, "um2": C, "up1": C, "up2": C, "zu": S + (2,), "grad_p": C + (2,), "smf": S + (2,), "kmu": S,
             "hr": S, "cori": S + (2,), "visc_ceu": C, "amc_north": C, "amc_south": C, "dxu2r": (imt,), "dxmetr": (imt,),
             "duw": (imt,), "due": (imt,), "advmet": (jmt, 2), "am4": (jmt, 2), "sbc_gu": S, "sbc_gv": S, "sbc_su": S,
-            "sbc_sv": S, "spsin": (imt,), "spcos": (imt,),
+            "sbc_sv": S, "spsin": (imt,), "spcos": (imt,), "psi": S + (2,),
         }
         if name in table:
             return table[name]
@@ -193,6 +193,14 @@ class TracerModel:
         flags = (1 if accumulate_sbc else 0) | (2 if osegs else 0) | (4 if osege else 0)
         check(self.lib.uvic_gpu_clinic_async(self.h, flags, float(rts)), "clinic_async")
 
+    def rotate_u(self):
+        """tau-1 <- tau <- tau+1 of the velocities, by pointer (what loadmw does with the memory-window slots)."""
+        check(self.lib.uvic_gpu_rotate_u(self.h), "rotate_u")
+
+    def add_ext_mode(self, level=0):
+        """u(tau) (level 0) or u(tau-1) (level -1) += the external mode of UVIC_F_PSI (loadmw.F add_ext_mode)."""
+        check(self.lib.uvic_gpu_add_ext_mode(self.h, int(level)), "add_ext_mode")
+
     def set_filter_u(self, ocean, flt):
         """Polar Fourier filter of u(tau+1) inside clinic (source/common/filuv.F); `flt` as synthetic.make_filter_u."""
         if flt is None:
@@ -313,6 +321,46 @@ class TracerModel:
         n = ctypes.c_int()
         check(self.lib.uvic_gpu_profile_read(self.h, 32, names, ms, ctypes.byref(n)), "profile_read")
         return {names[i].decode(): ms[i] for i in range(n.value)}
+
+
+class OceanLoop:
+    """The memory-window loop of `mom` (/root/reference/source/mom/mom.F:289-408) with everything but `tropic` on the
+    device: per time step the stream function goes up (one plane) and the vertically averaged forcing zu comes back (two
+    planes); tracers and velocities stay and rotate there.
+
+        loadmw   -> add_ext_mode (u(tau) += external mode of psi), state (rho from T,S at tau)
+        adv_vel, isopyc (+K33), [setvbc: bottom drag inside clinic], tracer, clinic
+        (host: tropic solves for the next psi from zu)
+
+    The tracer part is TimeLoop's step (look-ahead chains of the next step included: neither the MOBI sources nor the
+    T,S-derived fields depend on the velocities; the total advective velocities a chain formed are redone from the new
+    adv_vel).  Leapfrog steps only.  The caller has uploaded the ocean (load_ocean, load_velocity), the momentum inputs
+    (load_momentum: internal-mode u(tau), u(tau-1)) and the two polar filters if wanted."""
+
+    def __init__(self, model, dtts, dtuv, segment=0):
+        self.m, self.dtts, self.dtuv = model, float(dtts), float(dtuv)
+        self.tl = TimeLoop(model, dtts, nmix=0, segment=segment)
+        self.itt = 0
+        self.psi = np.zeros(model.shape("psi"), order="F")
+
+    def step(self, psi_tau, psi_taum1=None, accumulate_sbc=False, osegs=False, osege=False, rts=1.0):
+        """One leapfrog step; psi_tau (imt,jmt): stream function at tau.  On the first step the reference adds the
+        external mode to u(tau-1) as well (loadmw.F:88-90): give psi_taum1.  Returns zu (imt,jmt,2)."""
+        m = self.m
+        self.itt += 1
+        self.psi[..., 0] = psi_tau
+        if psi_taum1 is not None:
+            self.psi[..., 1] = psi_taum1
+        m.upload("psi", self.psi)
+        m.add_ext_mode(0)
+        if psi_taum1 is not None:
+            m.add_ext_mode(-1)
+        m.state_async()
+        check(m.lib.uvic_gpu_adv_vel_async(m.h), "adv_vel_async")
+        self.tl.step()                       # isopyc, tracer, look-ahead chains, rotation of t
+        m.clinic_async(accumulate_sbc, osegs, osege, rts)
+        m.rotate_u()
+        return m.download("zu")              # the step's only wait
 
 
 class TimeLoop:
