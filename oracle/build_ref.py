@@ -223,26 +223,37 @@ SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f
                ("m2", 14, 14, 6), ("m2", 102, 102, 19)]
 
 
-def build_default(force: bool = False, verbose: bool = False):
-    built = []
+def build_default(force: bool = False, verbose: bool = False, jobs: int = 4):
+    """Every library the tests use, `jobs` builds at a time (each is a chain of cpp/flang processes in its own scratch
+    directory; about five minutes one after the other)."""
+    from concurrent.futures import ThreadPoolExecutor
+    todo, built = [], []
     if (GPU_LIB_DIR / "libuvic_gpu.so").exists():
         for cfg, imt, jmt, km in SHIM_BUILDS:
             t = shim_lib_name(cfg, imt, jmt, km)
             srcs = [SHIM_DIR / "tracer_gpu.F", SHIM_DIR / "clinic_gpu.F", SHIM_DIR / "uvic_gpu_mod.F90"]
+            built.append(t)
             if t.exists() and not force and all(t.stat().st_mtime >= s_.stat().st_mtime for s_ in srcs):
-                built.append(t)
                 continue
-            if verbose:
-                print("building", t.name)
-            built.append(build(cfg, imt, jmt, km, shim=True))
+            todo.append((cfg, imt, jmt, km, True))
     for cfg, imt, jmt, km in DEFAULT_BUILDS:
         t = lib_name(cfg, imt, jmt, km)
+        built.append(t)
         if t.exists() and not force:
-            built.append(t)
             continue
+        todo.append((cfg, imt, jmt, km, False))
+    sys.path.insert(0, str(HERE / "ref"))
+    import gen_harness  # noqa: F401  (imported once, before the worker threads use it)
+
+    def one(job):
+        cfg, imt, jmt, km, shim = job
         if verbose:
-            print("building", t.name)
-        built.append(build(cfg, imt, jmt, km, verbose=False))
+            print("building", (shim_lib_name if shim else lib_name)(cfg, imt, jmt, km).name, flush=True)
+        return build(cfg, imt, jmt, km, shim=shim)
+
+    todo.sort(key=lambda j: -j[1] * j[2] * j[3])     # the large grids first
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(one, todo))
     return built
 
 
