@@ -64,6 +64,9 @@ CONFIGS = {
     # momentum row: physics only, nt=2, with the three options of run/mk.in that shape
     # `clinic` (explicit Coriolis term, 3-D viscosity coefficients, surface velocities handed to the ice model)
     "m2": BASE + "O_stream_function O_anisotropic_viscosity O_ice_evp".split(),
+    # the same without the two options that are additions of updates/09 and of the ice model: one viscosity per row
+    # (hmixc.h: amc_north(jmt), visc_ceu scalar), no isbcu/asbcu -- the other branch of the clinic overlay
+    "m2i": BASE + ["O_stream_function"],
 }
 
 # the reference's second boundary: -DO_TMM turns `tracer` into the column-batch source operator of the
@@ -81,6 +84,8 @@ ONLY_SOURCES = {
 EXTRA_SOURCES = {
     "m2": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F",
            "updates/09/source/mom/loadmw.F"],
+    "m2i": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F",
+            "updates/09/source/mom/loadmw.F"],
 }
 
 HDR_DIRS = ["source/common", "source/mom", "source/embm", "source/ice",
@@ -215,12 +220,13 @@ DEFAULT_BUILDS = [
     ("p2", 102, 102, 19), ("c30", 102, 102, 19),
     ("f18", 14, 14, 6), ("s37", 14, 14, 6),       # MOBI option sets F and run/mk.in's (tests/test_mobi_sets.py)
     ("m2", 14, 14, 6), ("m2", 102, 102, 19),      # momentum step: clinic, filuv, setvbc (tests/test_clinic.py)
+    ("m2i", 14, 14, 6),                           # clinic with one viscosity per row, without O_ice_evp
     ("tmm30", 64, 1, 6),                          # `tracer` as the O_TMM column-batch operator (tests/test_tmm.py)
 ]
 
 
 SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f18", 14, 14, 6), ("s37", 14, 14, 6),
-               ("m2", 14, 14, 6), ("m2", 102, 102, 19)]
+               ("m2", 14, 14, 6), ("m2", 102, 102, 19), ("m2i", 14, 14, 6)]
 
 
 def build_default(force: bool = False, verbose: bool = False, jobs: int = 4):

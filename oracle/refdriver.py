@@ -231,8 +231,15 @@ class RefOcean:
         g, v, S = self.ocean.grid, self.v, self.ref.set
         for n in ("dxmetr", "duw", "due", "dus", "dun"):
             v[n][...] = getattr(g, n)
-        for n in ("cori", "am3", "am4", "advmet", "hr", "visc_ceu", "amc_north", "amc_south"):
+        for n in ("cori", "am3", "am4", "advmet", "hr"):
             v[n][...] = getattr(mom, n)
+        if v["amc_north"].ndim == 3:          # O_anisotropic_viscosity: three-dimensional coefficients (hmixc.h)
+            for n in ("visc_ceu", "amc_north", "amc_south"):
+                v[n][...] = getattr(mom, n)
+        else:                                 # one per row; visc_ceu = visc_cnu = am
+            S("visc_ceu", mom.am); S("visc_cnu", mom.am)
+            v["amc_north"][...] = mom.amc_north_row
+            v["amc_south"][...] = mom.amc_south_row
         S("am", mom.am); S("kappa_m", mom.kappa_m); S("cdbot", mom.cdbot)
         S("dtuv", mom.dtuv); S("c2dtuv", 2.0 * mom.dtuv); S("acor", 0.0)
         v["visc_cbu"][...] = mom.kappa_m        # u09/mom/vmixc.F:85 (O_constvmix)

@@ -21,10 +21,10 @@ for p in (ROOT, ROOT / "oracle", ROOT / "tests" / "hostemu"):
 GRIDS = [(14, 14, 6), (102, 102, 19)]
 
 
-def _setup(imt, jmt, km):
+def _setup(imt, jmt, km, cfg="m2"):
     from uvic29_amd import synthetic
-    oc = synthetic.make_ocean("m2", imt, jmt, km)
-    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u)
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=(cfg == "m2"))
     return oc, mom, synthetic.load_eos(km), synthetic.make_filter_u(oc.grid, km)
 
 
@@ -38,15 +38,16 @@ def _oracle_step(oc, mom, eos, flt=None):
     return rho, M, up, zu
 
 
-@pytest.mark.parametrize("imt,jmt,km", GRIDS)
+@pytest.mark.parametrize("cfg,imt,jmt,km", [("m2",) + g for g in GRIDS] + [("m2i", 14, 14, 6)])
 @pytest.mark.parametrize("filtered", [False, True])
-def test_oracle_equals_reference(imt, jmt, km, filtered):
+def test_oracle_equals_reference(cfg, imt, jmt, km, filtered):
+    """(m2i: the reference built without O_anisotropic_viscosity and O_ice_evp -- one viscosity per row.)"""
     import oracle_c
     import refdriver
     import refmodel
-    if not refmodel.available("m2", imt, jmt, km):
-        pytest.skip("oracle/_ref build m2 %dx%dx%d not present" % (imt, jmt, km))
-    oc, mom, eos, flt = _setup(imt, jmt, km)
+    if not refmodel.available(cfg, imt, jmt, km):
+        pytest.skip("oracle/_ref build %s %dx%dx%d not present" % (cfg, imt, jmt, km))
+    oc, mom, eos, flt = _setup(imt, jmt, km, cfg)
     R = refdriver.RefOcean(oc)
     R.set_momentum(mom)
     if filtered:

@@ -200,19 +200,19 @@ def test_resident_overlay_through_an_euler_backward_step(exact, monkeypatch):
             assert np.abs(x - y).max() <= (0.0 if exact and n < 2 else PROD_TOL) * np.abs(y).max(), (slot, name)
 
 
-@pytest.mark.parametrize("dims", [(14, 14, 6), (102, 102, 19)])
-def test_overlay_clinic_matches_reference_clinic(dims, monkeypatch):
+@pytest.mark.parametrize("cfg,dims", [("m2", (14, 14, 6)), ("m2", (102, 102, 19)), ("m2i", (14, 14, 6))])
+def test_overlay_clinic_matches_reference_clinic(cfg, dims, monkeypatch):
     """The momentum row's boundary end to end: `clinic(joff,js,je,is,ie)` of the package's
     overlay (uvic2.9_amd/fortran/clinic_gpu.F) against the reference's own routine, through the reference's COMMON
     blocks: u(tau+1), zu and the four sbc planes of isbcu/asbcu, bit for bit, with the polar filter filuv on.  The
-    overlay shares the device instance of the `tracer` overlay, which runs first as in mom.F:389-395."""
+    overlay shares the device instance of the `tracer` overlay, which runs first as in mom.F:389-395.  (m2i: a build
+    without O_anisotropic_viscosity and O_ice_evp -- the overlay spreads the per-row coefficients itself.)"""
     monkeypatch.delenv("UVIC_EXACT", raising=False)
-    cfg = "m2"
     if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
         pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
     import refdriver
     oc = synthetic.make_ocean(cfg, *dims)
-    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=(cfg == "m2"))
     flt = synthetic.make_filter_u(oc.grid, dims[2])
     rng = np.random.default_rng(3)
     planes = rng.standard_normal((dims[0], dims[1], 4))

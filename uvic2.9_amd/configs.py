@@ -151,6 +151,7 @@ OPTION_SETS = {
     "p2": _build("p2", []),
     # the same two tracers; names the oracle/_ref build that also holds the momentum routines (`clinic`, §8f rank 4)
     "m2": _build("m2", []),
+    "m2i": _build("m2i", []),
     # BASELINE config 4 == SURVEY option set C (nt=30, nsrc=28, ntnpzd=25)
     "c30": _build("c30", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen",
                           "carbon_13", "carbon_14", "mobi_nitrogen_15"]),

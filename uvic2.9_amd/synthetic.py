@@ -253,7 +253,7 @@ def make_velocity(g, topo):
     return u
 
 
-def make_momentum(g, topo, u_tau):
+def make_momentum(g, topo, u_tau, anisotropic=True):
     """Inputs of the baroclinic momentum step (`clinic`) that the tracer step does not
     have: u(tau-1), wind stress, the static factors of setmom.F:770-803, 1104-1114 and the viscosity
     coefficients hmixc.F leaves on its first call (O_anisotropic_viscosity: three 3-D fields; here a smooth
@@ -300,6 +300,15 @@ def make_momentum(g, topo, u_tau):
     m.amc_north = F((imt, km, jmt)); m.amc_south = F((imt, km, jmt))
     m.amc_north[:] = visc_cnu * (g.cst[jp1] * g.dytr[jp1] * g.csur * g.dyur)[None, None, :]
     m.amc_south[:] = visc_cnu * (g.cst * g.dytr * g.csur * g.dyur)[None, None, :]
+    if not anisotropic:
+        # one coefficient per row (hmixc.F:104-136 without O_anisotropic_viscosity): visc_ceu = visc_cnu = am; the same
+        # numbers spread over (imt,km,jmt) are what the device fields hold
+        m.amc_north_row = m.am * (g.cst[jp1] * g.dytr[jp1] * g.csur * g.dyur)
+        m.amc_south_row = m.am * (g.cst * g.dytr * g.csur * g.dyur)
+        m.visc_ceu[:] = m.am
+        m.amc_north[:] = m.amc_north_row[None, None, :]
+        m.amc_south[:] = m.amc_south_row[None, None, :]
+    m.anisotropic = anisotropic
     m.kappa_m, m.cdbot, m.dtuv = 10.0, 1.3e-3, 1125.0
     m.grav, m.rho0r = 980.6, 1.0 / 1.035
     return m
