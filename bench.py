@@ -372,45 +372,46 @@ def main():
             if "filt" in pf:
                 nxt["filt"] = round(pf["filt"], 5)
             m.set_filter(ocean, None)
-            # §8(f) rank 4: baroclinic momentum step (state + clinic with the polar filter filuv and the sbc accumulation)
-            mom = synthetic.make_momentum(ocean.grid, ocean.topo, ocean.u)
-            m.load_momentum(ocean, mom)
-            m.set_filter_u(ocean, synthetic.make_filter_u(ocean.grid, km))
-            m.state(); m.clinic_only(True)
-            m.sync()
-            tq = time.perf_counter()
-            for _ in range(50):
-                m.state_async(); m.clinic_async(True)
-            m.sync()
-            nxt["state_clinic_ms_per_call"] = round((time.perf_counter() - tq) / 50 * 1e3, 5)
-            m.profile_live(True)
-            for _ in range(20):
-                m.state_async(); m.clinic_async(True)
-            m.sync()
-            pr = m.profile_read()
-            for k in ("state", "clinic_gradp", "clinic_tend", "clinic_finish", "filuv", "filuv_mean"):
-                if k in pr:
-                    nxt[k] = round(pr[k], 5)
-            # the whole memory-window loop of mom.F on the device (everything but tropic): tracer step with its look-ahead
-            # chains + add_ext_mode, state, adv_vel, clinic; one wait per step (zu back to the host, psi up)
-            from uvic29_amd.tracer import OceanLoop
-            m.load_ocean(ocean, to, so, c, src=src)
-            m.load_velocity(ocean)
-            m.load_momentum(ocean, mom)
-            oloop = OceanLoop(m, ocean.params.dtts, mom.dtuv)
-            psi0 = np.zeros((imt, jmt), order="F")
-            for _ in range(8):
-                oloop.step(psi0)
-            tq = time.perf_counter()
-            for _ in range(40):
-                zu_last = oloop.step(psi0)
-            nxt["ocean_loop_ms_per_step"] = round((time.perf_counter() - tq) / 40 * 1e3, 5)
-            nxt["ocean_loop_finite"] = bool(np.isfinite(zu_last).all() and np.isfinite(m.download("u1")).all())
-            m.set_filter_u(ocean, None)
-            if not a.no_cpu_baseline:
-                cms = clinic_cpu_baseline(imt, jmt, km)
-                if cms is not None:
-                    nxt["clinic_cpu_reference_ms_per_call"] = round(cms, 3)     # 1 core, compiled reference Fortran
+            if world == 1 and a.one_slab_of <= 1 and nt >= 2:    # single-rank runs on the whole grid only
+                # §8(f) rank 4: baroclinic momentum step (state + clinic with the polar filter filuv and the sbc accumulation)
+                mom = synthetic.make_momentum(ocean.grid, ocean.topo, ocean.u)
+                m.load_momentum(ocean, mom)
+                m.set_filter_u(ocean, synthetic.make_filter_u(ocean.grid, km))
+                m.state(); m.clinic_only(True)
+                m.sync()
+                tq = time.perf_counter()
+                for _ in range(50):
+                    m.state_async(); m.clinic_async(True)
+                m.sync()
+                nxt["state_clinic_ms_per_call"] = round((time.perf_counter() - tq) / 50 * 1e3, 5)
+                m.profile_live(True)
+                for _ in range(20):
+                    m.state_async(); m.clinic_async(True)
+                m.sync()
+                pr = m.profile_read()
+                for k in ("state", "clinic_gradp", "clinic_tend", "clinic_finish", "filuv", "filuv_mean"):
+                    if k in pr:
+                        nxt[k] = round(pr[k], 5)
+                # the whole memory-window loop of mom.F on the device (everything but tropic): tracer step with its look-ahead
+                # chains + add_ext_mode, state, adv_vel, clinic; one wait per step (zu back to the host, psi up)
+                from uvic29_amd.tracer import OceanLoop
+                m.load_ocean(ocean, to, so, c, src=src)
+                m.load_velocity(ocean)
+                m.load_momentum(ocean, mom)
+                oloop = OceanLoop(m, ocean.params.dtts, mom.dtuv)
+                psi0 = np.zeros((imt, jmt), order="F")
+                for _ in range(8):
+                    oloop.step(psi0)
+                tq = time.perf_counter()
+                for _ in range(40):
+                    zu_last = oloop.step(psi0)
+                nxt["ocean_loop_ms_per_step"] = round((time.perf_counter() - tq) / 40 * 1e3, 5)
+                nxt["ocean_loop_finite"] = bool(np.isfinite(zu_last).all() and np.isfinite(m.download("u1")).all())
+                m.set_filter_u(ocean, None)
+                if not a.no_cpu_baseline:
+                    cms = clinic_cpu_baseline(imt, jmt, km)
+                    if cms is not None:
+                        nxt["clinic_cpu_reference_ms_per_call"] = round(cms, 3)     # 1 core, compiled reference Fortran
         except Exception as e:   # never let the side measurement break the bench line
             nxt = {"error": str(e)}
         prof = live
