@@ -371,6 +371,12 @@ int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts);
  * the momentum step device-resident between the tracer steps */
 int uvic_gpu_state_async(uvic_gpu *h);
 int uvic_gpu_clinic_async(uvic_gpu *h, int sbc_flags, double rts);
+/* state + clinic of this time step on a stream of their own, beside the tracer step the caller queues next on the main
+ * stream (`clinic` reads rho, u and the advective velocities, none of which the tracer step writes).  zu is copied to
+ * zu_host (imt,jmt,2; null: not) and uvic_gpu_momentum_wait returns when it has arrived, so that the host's `tropic` can
+ * run beside the tracer step.  Later calls that touch u, the advective velocities or these fields wait for it themselves. */
+int uvic_gpu_momentum_async(uvic_gpu *h, int sbc_flags, double rts, double *zu_host);
+int uvic_gpu_momentum_wait(uvic_gpu *h);
 /* device-resident velocities: what u09/mom/loadmw.F does to u at the start of a time step with the memory window wide
  * open (:86-99): the time levels rotate (tau-1 <- tau <- tau+1, by pointer: UVIC_F_UM1/UM2, U1/U2, UP1/UP2) ... */
 int uvic_gpu_rotate_u(uvic_gpu *h);

@@ -727,6 +727,9 @@ struct uvic_gpu {
   int mobi_key;   // n15 | c13<<1 | caco3<<2 | silicon<<3 of the set bound by uvic_gpu_set_mobi_opt
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
+  hipStream_t side_mom;     // uvic_gpu_momentum_async: state + clinic beside the tracer step
+  hipEvent_t ev_mom_in, ev_mom_done;
+  bool mom_pending;
   int tmm_ncols;    // > 0: a column-batch handle (uvic_gpu_tmm_create); the batch is row 2, columns 2..ncols+1
   // baroclinic momentum step (uvic_gpu_state / uvic_gpu_clinic)
   uvic_clinic_params clinic_p;
@@ -832,7 +835,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 7; }   // 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 8; }   // 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -884,6 +887,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->have_mobi = false;
   h->have_vmix = false;
   h->tmm_ncols = 0;
+  h->side_mom = nullptr; h->ev_mom_in = h->ev_mom_done = nullptr; h->mom_pending = false;
   h->have_clinic = false;
   h->fltu_items = nullptr; h->fltu_mats = nullptr; h->fltu_rows = nullptr; h->fltu_nitems = h->fltu_threads = h->fltu_nrows = 0;
   h->flt_items = nullptr; h->flt_mats = nullptr; h->flt_nitems = 0; h->flt_threads = 0;
@@ -1080,6 +1084,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
   for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(h->ev_src_next[q]); (void)hipEventDestroy(h->ev_step_end[q]); }
+  if (h->side_mom) { (void)hipStreamSynchronize(h->side_mom); (void)hipStreamDestroy(h->side_mom); (void)hipEventDestroy(h->ev_mom_in); (void)hipEventDestroy(h->ev_mom_done); }
   (void)hipStreamDestroy(h->side_m[0]);
   if (h->side_m[1] != h->side_m[0]) (void)hipStreamDestroy(h->side_m[1]);
   if (h->side_ts != h->side2) (void)hipStreamDestroy(h->side_ts);
@@ -1260,6 +1265,14 @@ static int src_clean(uvic_gpu *h, void *src, hipStream_t st) {
   return 0;
 }
 
+// a transfer touches fields a momentum step on its own stream (uvic_gpu_momentum_async) may still read or write: wait for it
+static int mom_host_join(uvic_gpu *h) {
+  if (h->mom_pending) {
+    HIPCHK(hipEventSynchronize(h->ev_mom_done));
+    h->mom_pending = false;
+  }
+  return 0;
+}
 // new state (a time level of t) or new sources from the host: whatever the side streams computed ahead from the old ones
 // is void, and they must have finished before the buffers change under them
 static int state_from_host(uvic_gpu *h, int field) {
@@ -1291,6 +1304,8 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
   const int64_t n = field_elems(h->d, field);
   if (offset < 0 || count < 0 || offset + count > n) return fail_msg(std::string("uvic_gpu_upload: range outside field ") + FIELDS[field].name);
   HIPCHK(hipSetDevice(h->device));
+  if (field != UVIC_F_PSI)      // (the stream function is not read by a momentum step running beside the main stream)
+    if (int rc = mom_host_join(h)) return rc;
   const size_t es = elem_size(field);
   if (int rc = state_from_host(h, field)) return rc;
   HIPCHK(hipMemcpyAsync((char *)h->buf[field] + offset * es, host, count * es, hipMemcpyHostToDevice, h->stream));
@@ -1309,6 +1324,7 @@ extern "C" int uvic_gpu_upload(uvic_gpu *h, int field, const void *host, int64_t
 }
 extern "C" int uvic_gpu_download(uvic_gpu *h, int field, void *host, int64_t offset, int64_t count) {
   if (!h || !host) return fail_msg("uvic_gpu_download: null argument");
+  if (int rc = mom_host_join(h)) return rc;
   if (field < 0 || field >= UVIC_F_COUNT) return fail_msg("uvic_gpu_download: bad field id");
   const int64_t n = field_elems(h->d, field);
   if (offset < 0 || count < 0 || offset + count > n) return fail_msg(std::string("uvic_gpu_download: range outside field ") + FIELDS[field].name);
@@ -1327,6 +1343,7 @@ struct XferTimer {
 static int rows_xfer(uvic_gpu *h, int field, double *host, int jlo, int jhi, bool up) {
   XferTimer tm_;
   if (!h || !host) return fail_msg("uvic_gpu_*_rows: null argument");
+  if (int rc = mom_host_join(h)) return rc;
   if (field < 0 || field >= UVIC_F_COUNT || FIELDS[field].is_int) return fail_msg("uvic_gpu_*_rows: bad field id");
   const Kind kd = FIELDS[field].kind;
   if (kd != K_S && kd != K_C && kd != K_F) return fail_msg("uvic_gpu_*_rows: field has no row dimension");
@@ -1816,7 +1833,9 @@ static int launch_mobi(uvic_gpu *h) {
 }
 
 // -- producers of the shared inputs (kernels_prep.hpp) ---------------------------------
+static int mom_join(uvic_gpu *h);
 static int launch_adv_vel(uvic_gpu *h) {
+  if (int rc = mom_join(h)) return rc;     // a momentum step beside the main stream still reads the old ones
   velocity_touched(h, UVIC_F_ADV_VET);   // a look-ahead chain formed its total velocities from the old ones: redo them
   mark(h, "begin");
   hipLaunchKernelGGL(k_adv_vel_hor, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
@@ -1998,40 +2017,52 @@ static uvic_mom_ctx mom_ctx(uvic_gpu *h) {
   m.s_tau = h->ctx.t_tau + (size_t)d.imt * d.km * d.jmt;
   return m;
 }
-static int launch_state(uvic_gpu *h) {
+// `st`: the main stream (marks for the profile) or the momentum stream (uvic_gpu_momentum_async)
+static int launch_state(uvic_gpu *h, hipStream_t st) {
   if (h->ctx.n0 != 0) return fail_msg("uvic_gpu_state: this rank's tracer shard does not hold T and S");
   const uvic_mom_ctx m = mom_ctx(h);
-  mark(h, "begin");
-  hipLaunchKernelGGL(k_state, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, m);
-  mark(h, "state");
+  const bool mk = st == h->stream;
+  if (mk) mark(h, "begin");
+  hipLaunchKernelGGL(k_state, dim3(cell_blocks(h, 256)), dim3(256), 0, st, m);
+  if (mk) mark(h, "state");
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m);
-static int launch_clinic(uvic_gpu *h, int sbc_flags, double rts) {
+static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m, hipStream_t st);
+static int launch_clinic(uvic_gpu *h, int sbc_flags, double rts, hipStream_t st) {
   if (!h->have_clinic) return fail_msg("uvic_gpu_clinic: call uvic_gpu_set_clinic_params first");
   const uvic_mom_ctx m = mom_ctx(h);
-  mark(h, "begin");
-  hipLaunchKernelGGL(k_clinic_gradp, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m);
-  mark(h, "clinic_gradp");
-  hipLaunchKernelGGL(k_clinic_tend, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, m);
-  mark(h, "clinic_tend");
-  hipLaunchKernelGGL(k_clinic_finish, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, m, sbc_flags, rts);
-  mark(h, "clinic_finish");
-  if (int rc = launch_filuv(h, m)) return rc;
+  const bool mk = st == h->stream;
+  if (mk) mark(h, "begin");
+  hipLaunchKernelGGL(k_clinic_gradp, dim3(col_blocks(h, 64)), dim3(64), 0, st, m);
+  if (mk) mark(h, "clinic_gradp");
+  hipLaunchKernelGGL(k_clinic_tend, dim3(cell_blocks(h, 256)), dim3(256), 0, st, m);
+  if (mk) mark(h, "clinic_tend");
+  hipLaunchKernelGGL(k_clinic_finish, dim3(col_blocks(h, 64)), dim3(64), 0, st, m, sbc_flags, rts);
+  if (mk) mark(h, "clinic_finish");
+  if (int rc = launch_filuv(h, m, st)) return rc;
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m) {
+static int launch_filuv(uvic_gpu *h, const uvic_mom_ctx &m, hipStream_t st) {
   if (h->fltu_nitems == 0) return 0;
+  const bool mk = st == h->stream;
   // 2*H threads per strip (H = strip length rounded up to a wave): the two components are filtered side by side
-  hipLaunchKernelGGL(k_filuv, dim3((unsigned)h->fltu_nitems), dim3(2 * h->fltu_threads), (size_t)(4 * h->fltu_threads + 8) * 8, h->stream, m,
+  hipLaunchKernelGGL(k_filuv, dim3((unsigned)h->fltu_nitems), dim3(2 * h->fltu_threads), (size_t)(4 * h->fltu_threads + 8) * 8, st, m,
                      h->fltu_items, h->fltu_mats, (const double *)h->buf[UVIC_F_SPSIN], (const double *)h->buf[UVIC_F_SPCOS],
                      h->fltu_nitems);
-  mark(h, "filuv");
+  if (mk) mark(h, "filuv");
   const unsigned n = (unsigned)h->fltu_nrows * (unsigned)h->d.imt;
-  hipLaunchKernelGGL(k_filuv_mean, dim3((n + 63) / 64), dim3(64), 0, h->stream, m, h->fltu_rows, h->fltu_nrows);
-  mark(h, "filuv_mean");
+  hipLaunchKernelGGL(k_filuv_mean, dim3((n + 63) / 64), dim3(64), 0, st, m, h->fltu_rows, h->fltu_nrows);
+  if (mk) mark(h, "filuv_mean");
+  return 0;
+}
+// what the main stream queues next on u or the advective velocities waits for a momentum step still running beside it
+static int mom_join(uvic_gpu *h) {
+  if (h->mom_pending) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_mom_done, 0));
+    h->mom_pending = false;
+  }
   return 0;
 }
 extern "C" int uvic_gpu_rotate_u(uvic_gpu *h) {
@@ -2049,6 +2080,7 @@ extern "C" int uvic_gpu_add_ext_mode(uvic_gpu *h, int level) {
   if (!h) return fail_msg("null handle");
   if (level != 0 && level != -1) return fail_msg("uvic_gpu_add_ext_mode: level is 0 (tau) or -1 (tau-1)");
   HIPCHK(hipSetDevice(h->device));
+  if (int rc = mom_join(h)) return rc;
   const uvic_mom_ctx m = mom_ctx(h);
   const double *psi = (const double *)h->buf[UVIC_F_PSI] + (level == 0 ? 0 : (size_t)h->d.imt * h->d.jmt);
   double *u1 = (double *)h->buf[level == 0 ? UVIC_F_U1 : UVIC_F_UM1], *u2 = (double *)h->buf[level == 0 ? UVIC_F_U2 : UVIC_F_UM2];
@@ -2068,24 +2100,58 @@ extern "C" int uvic_gpu_set_clinic_params(uvic_gpu *h, const uvic_clinic_params 
 extern "C" int uvic_gpu_state(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));
-  if (int rc = launch_state(h)) return rc;
+  if (int rc = mom_join(h)) return rc;
+  if (int rc = launch_state(h, h->stream)) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 extern "C" int uvic_gpu_state_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));
-  return launch_state(h);
+  if (int rc = mom_join(h)) return rc;
+  return launch_state(h, h->stream);
 }
 extern "C" int uvic_gpu_clinic_async(uvic_gpu *h, int sbc_flags, double rts) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));
-  return launch_clinic(h, sbc_flags, rts);
+  if (int rc = mom_join(h)) return rc;
+  return launch_clinic(h, sbc_flags, rts, h->stream);
+}
+// state + clinic of this time step on a stream of their own, beside the tracer step the caller queues next on the main
+// stream: `clinic` reads rho (T,S at tau), u and the advective velocities, none of which the tracer step writes.  They start
+// behind what the main stream holds now (add_ext_mode, adv_vel); zu is copied to `zu_host` (imt,jmt,2; may be null) and
+// uvic_gpu_momentum_wait returns when it has arrived -- long before the tracer step ends, so that the host's `tropic` runs
+// beside it.  The next uvic_gpu_add_ext_mode / uvic_gpu_adv_vel / state / clinic on the main stream wait for it by event.
+extern "C" int uvic_gpu_momentum_async(uvic_gpu *h, int sbc_flags, double rts, double *zu_host) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->side_mom) {
+    HIPCHK(hipStreamCreateWithFlags(&h->side_mom, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_mom_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_mom_done, hipEventDisableTiming));
+  }
+  if (int rc = mom_join(h)) return rc;
+  HIPCHK(hipEventRecord(h->ev_mom_in, h->stream));
+  HIPCHK(hipStreamWaitEvent(h->side_mom, h->ev_mom_in, 0));
+  if (int rc = launch_state(h, h->side_mom)) return rc;
+  if (int rc = launch_clinic(h, sbc_flags, rts, h->side_mom)) return rc;
+  if (zu_host)
+    HIPCHK(hipMemcpyAsync(zu_host, h->buf[UVIC_F_ZU], (size_t)2 * h->d.imt * h->d.jmt * 8, hipMemcpyDeviceToHost, h->side_mom));
+  HIPCHK(hipEventRecord(h->ev_mom_done, h->side_mom));
+  h->mom_pending = true;
+  return 0;
+}
+extern "C" int uvic_gpu_momentum_wait(uvic_gpu *h) {
+  if (!h) return fail_msg("null handle");
+  if (h->side_mom) HIPCHK(hipEventSynchronize(h->ev_mom_done));
+  h->mom_pending = false;
+  return 0;
 }
 extern "C" int uvic_gpu_clinic(uvic_gpu *h, int sbc_flags, double rts) {
   if (!h) return fail_msg("null handle");
   HIPCHK(hipSetDevice(h->device));
-  if (int rc = launch_clinic(h, sbc_flags, rts)) return rc;
+  if (int rc = mom_join(h)) return rc;
+  if (int rc = launch_clinic(h, sbc_flags, rts, h->stream)) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2411,6 +2477,7 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
 }
 extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
+  if (h->side_mom) HIPCHK(hipStreamSynchronize(h->side_mom));
   for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
   HIPCHK(hipStreamSynchronize(h->side2));
   HIPCHK(hipStreamSynchronize(h->side_ts));

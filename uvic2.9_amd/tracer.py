@@ -193,6 +193,11 @@ class TracerModel:
         flags = (1 if accumulate_sbc else 0) | (2 if osegs else 0) | (4 if osege else 0)
         check(self.lib.uvic_gpu_clinic_async(self.h, flags, float(rts)), "clinic_async")
 
+    def set_host_sync(self, on):
+        """False: uploads are queued on the main stream and return (the host buffer must stay as it is until the copy
+        has run); True (default): they return when the copy is done."""
+        check(self.lib.uvic_gpu_set_host_sync(self.h, 1 if on else 0), "set_host_sync")
+
     def rotate_u(self):
         """tau-1 <- tau <- tau+1 of the velocities, by pointer (what loadmw does with the memory-window slots)."""
         check(self.lib.uvic_gpu_rotate_u(self.h), "rotate_u")
@@ -329,8 +334,10 @@ class OceanLoop:
     planes); tracers and velocities stay and rotate there.
 
         loadmw   -> add_ext_mode (u(tau) += external mode of psi), state (rho from T,S at tau)
-        adv_vel, isopyc (+K33), [setvbc: bottom drag inside clinic], tracer, clinic
-        (host: tropic solves for the next psi from zu)
+        adv_vel, isopyc (+K33), [setvbc: bottom drag inside clinic], tracer || clinic (clinic does not read what the
+        tracer step writes: it runs on a stream of its own beside it, and zu is back on the host long before the
+        tracer step ends)
+        (host: tropic solves for the next psi from zu -- beside the tracer step)
 
     The tracer part is TimeLoop's step (look-ahead chains of the next step included: neither the MOBI sources nor the
     T,S-derived fields depend on the velocities; the total advective velocities a chain formed are redone from the new
@@ -342,6 +349,10 @@ class OceanLoop:
         self.tl = TimeLoop(model, dtts, nmix=0, segment=segment)
         self.itt = 0
         self.psi = np.zeros(model.shape("psi"), order="F")
+        self.zu = np.zeros(model.shape("zu"), order="F")
+        for a in (self.zu, self.psi):        # both cross PCIe every step: page-locked, copies queued without waiting
+            check(model.lib.uvic_gpu_pin_host(model.h, a.ctypes.data_as(ctypes.c_void_p), a.nbytes), "pin_host")
+        model.set_host_sync(False)
 
     def step(self, psi_tau, psi_taum1=None, accumulate_sbc=False, osegs=False, osege=False, rts=1.0):
         """One leapfrog step; psi_tau (imt,jmt): stream function at tau.  On the first step the reference adds the
@@ -355,12 +366,14 @@ class OceanLoop:
         m.add_ext_mode(0)
         if psi_taum1 is not None:
             m.add_ext_mode(-1)
-        m.state_async()
         check(m.lib.uvic_gpu_adv_vel_async(m.h), "adv_vel_async")
-        self.tl.step()                       # isopyc, tracer, look-ahead chains, rotation of t
-        m.clinic_async(accumulate_sbc, osegs, osege, rts)
+        # state + clinic on their own stream, beside the tracer step; zu lands in page-locked memory
+        flags = (1 if accumulate_sbc else 0) | (2 if osegs else 0) | (4 if osege else 0)
+        check(m.lib.uvic_gpu_momentum_async(m.h, flags, float(rts), self.zu.ctypes.data_as(ctypes.c_void_p)), "momentum_async")
+        self.tl.step()                       # isopyc, tracer, look-ahead chains, rotation of t: queued, not waited for
         m.rotate_u()
-        return m.download("zu")              # the step's only wait
+        check(m.lib.uvic_gpu_momentum_wait(m.h), "momentum_wait")   # the step's only wait: zu, not the tracer step
+        return self.zu
 
 
 class TimeLoop:
