@@ -202,6 +202,8 @@ int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, const doubl
 /* page-lock a host range that is uploaded from or downloaded into every step (the reference's COMMON blocks live as
  * long as the process); the memory stays the caller's */
 int uvic_gpu_pin_host(uvic_gpu *h, void *ptr, int64_t bytes);
+/* ends the registration (uvic_gpu_destroy does so for every range the handle registered) */
+int uvic_gpu_unpin_host(uvic_gpu *h, void *ptr);
 /* the source-term kernel alone (for parity tests): fills UVIC_F_SRC */
 int uvic_gpu_mobi(uvic_gpu *h);
 

@@ -50,7 +50,7 @@ EXPORTS = [
     "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
     "uvic_gpu_state_async", "uvic_gpu_clinic_async",
     "uvic_gpu_tmm_create", "uvic_gpu_tmm_set_mobi", "uvic_gpu_tmm_sources", "uvic_gpu_rotate_u", "uvic_gpu_add_ext_mode", "uvic_gpu_adv_vel_async",
-    "uvic_gpu_momentum_async", "uvic_gpu_momentum_wait",
+    "uvic_gpu_momentum_async", "uvic_gpu_momentum_wait", "uvic_gpu_unpin_host",
 ]
 
 
@@ -132,6 +132,7 @@ def load():
     lib.uvic_gpu_adv_vel_async.argtypes = [ctypes.c_void_p]
     lib.uvic_gpu_momentum_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
     lib.uvic_gpu_momentum_wait.argtypes = [ctypes.c_void_p]
+    lib.uvic_gpu_unpin_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_rotate_u.argtypes = [ctypes.c_void_p]
     lib.uvic_gpu_add_ext_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_state.argtypes = [ctypes.c_void_p]

@@ -727,6 +727,7 @@ struct uvic_gpu {
   int mobi_key;   // n15 | c13<<1 | caco3<<2 | silicon<<3 of the set bound by uvic_gpu_set_mobi_opt
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
+  std::vector<void *> pinned;   // host ranges page-locked through uvic_gpu_pin_host
   hipStream_t side_mom;     // uvic_gpu_momentum_async: state + clinic beside the tracer step
   hipEvent_t ev_mom_in, ev_mom_done;
   bool mom_pending;
@@ -835,7 +836,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 8; }   // 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 9; }   // 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -1084,6 +1085,8 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
   for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(h->ev_src_next[q]); (void)hipEventDestroy(h->ev_step_end[q]); }
+  for (void *q : h->pinned) (void)hipHostUnregister(q);
+  h->pinned.clear();
   if (h->side_mom) { (void)hipStreamSynchronize(h->side_mom); (void)hipStreamDestroy(h->side_mom); (void)hipEventDestroy(h->ev_mom_in); (void)hipEventDestroy(h->ev_mom_done); }
   (void)hipStreamDestroy(h->side_m[0]);
   if (h->side_m[1] != h->side_m[0]) (void)hipStreamDestroy(h->side_m[1]);
@@ -2666,14 +2669,26 @@ extern "C" int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, 
   return 0;
 }
 // Page-lock a host range the caller will upload from or download into every step (COMMON blocks live as long as the
-// process): transfers then run at the link's rate instead of through the runtime's staging buffer.  Not owned: the
-// caller's memory stays the caller's; uvic_gpu_destroy does not unregister.
+// process): transfers then run at the link's rate instead of through the runtime's staging buffer.  The memory stays the
+// caller's; the registration is this handle's: uvic_gpu_destroy (or uvic_gpu_unpin_host) ends it, so that
+// a range the caller frees afterwards does not stay page-locked under whatever the allocator puts there next.
 extern "C" int uvic_gpu_pin_host(uvic_gpu *h, void *ptr, int64_t bytes) {
   if (!h || !ptr || bytes <= 0) return fail_msg("uvic_gpu_pin_host: null argument");
   HIPCHK(hipSetDevice(h->device));
   const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
   if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return 0; }
   if (e != hipSuccess) return fail("hipHostRegister", e, __LINE__);
+  h->pinned.push_back(ptr);
+  return 0;
+}
+extern "C" int uvic_gpu_unpin_host(uvic_gpu *h, void *ptr) {
+  if (!h || !ptr) return fail_msg("uvic_gpu_unpin_host: null argument");
+  auto it = std::find(h->pinned.begin(), h->pinned.end(), ptr);
+  if (it == h->pinned.end()) return 0;
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = uvic_gpu_sync(h)) return rc;
+  (void)hipHostUnregister(ptr);
+  h->pinned.erase(it);
   return 0;
 }
 extern "C" int uvic_gpu_set_host_sync(uvic_gpu *h, int on) {

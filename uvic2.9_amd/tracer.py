@@ -352,6 +352,8 @@ class OceanLoop:
         self.zu = np.zeros(model.shape("zu"), order="F")
         for a in (self.zu, self.psi):        # both cross PCIe every step: page-locked, copies queued without waiting
             check(model.lib.uvic_gpu_pin_host(model.h, a.ctypes.data_as(ctypes.c_void_p), a.nbytes), "pin_host")
+        # the registration ends with the model (uvic_gpu_destroy): keep the arrays at least that long
+        model._pinned = getattr(model, "_pinned", []) + [self.zu, self.psi]
         model.set_host_sync(False)
 
     def step(self, psi_tau, psi_taum1=None, accumulate_sbc=False, osegs=False, osege=False, rts=1.0):
