@@ -334,3 +334,35 @@ def test_gpu_memory_window_loop_equals_reference(imt, jmt, km, nsteps):
     um = np.stack([m.download("um1"), m.download("um2")], axis=-1)
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
     m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_momentum_entry_points_fail_loudly():
+    """Misuse is refused with a message, not computed through (the error convention of the C ABI: non-zero status and
+    uvic_gpu_last_error)."""
+    from uvic29_amd.capi import UvicGpuError
+    from uvic29_amd.tracer import TracerModel
+    oc, mom, eos, flt = _setup(14, 14, 6)
+    m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd, device=0)
+    m.load_ocean(oc, *eos)
+    with pytest.raises(UvicGpuError, match="set_clinic_params"):
+        m.clinic_only()                                   # before the scalars of clinic were given
+    with pytest.raises(UvicGpuError, match="level"):
+        m.add_ext_mode(2)
+    m.load_momentum(oc, mom)
+    bad = type(flt)(**{**flt.__dict__, "jfu1": 9, "jfu2": 5})
+    with pytest.raises(UvicGpuError, match="rows out of range"):
+        m.set_filter_u(oc, bad)
+    m.set_shard(n0=1, nt_local=1)                         # a tracer shard without T and S cannot form rho
+    with pytest.raises(UvicGpuError, match="T and S"):
+        m.state()
+    m.close()
+    from uvic29_amd.tmm import TmmOperator
+    from uvic29_amd import synthetic
+    c30 = synthetic.make_ocean("c30", 14, 14, 6)
+    with pytest.raises(UvicGpuError, match="at least 4 columns"):
+        TmmOperator(c30.cfg, c30.grid, 2)
+    op = TmmOperator(c30.cfg, c30.grid, 8)
+    with pytest.raises(UvicGpuError, match="tmm_set_mobi"):
+        op.sources(np.zeros((8, 6, c30.cfg.nt)), 2.0 * c30.params.dtts)
+    op.close()
