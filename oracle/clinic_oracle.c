@@ -8,10 +8,11 @@
  *   /root/reference/updates/09/source/mom/clinic.F:24-560    internal-mode velocities at tau+1 and the
  *                                                            vertically averaged forcing zu
  *   /root/reference/updates/09/source/mom/clinic.F:729-895   asbcu, isbcu
+ *   /root/reference/updates/09/source/mom/loadmw.F:590-667   add_ext_mode (O_stream_function)
  * with the statement functions of /root/reference/updates/09/source/mom/fdifm.h, for the options
  * O_consthmix O_constvmix O_anisotropic_viscosity O_stream_function O_cyclic (no O_implicitvmix,
  * O_damp_inertial_oscillation, O_biharmonic, O_neptune, O_pressure_gradient_average), one memory window
- * (joff = 0, js = 2, je = jmt-1, istrt = 2, iend = imt-1).  The polar filter (`filuv`) is filuv_oracle.c.
+ * (joff = 0, js = 2, je = jmt-1, istrt = 2, iend = imt-1).  The polar filter (`filuv`) is orc_filuv in filter_oracle.c.
  * Compile: gcc -O2 -ffp-contract=off -std=gnu99 (oracle_c.py).
  */
 #include <math.h>

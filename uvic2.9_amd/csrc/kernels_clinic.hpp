@@ -7,13 +7,16 @@
 //   plus what `clinic` takes from its neighbours in mom.F's loop and no other routine needs:
 //            the U-cell advective velocities (source/mom/adv_vel.F:150-231), the bottom drag
 //            (u09/mom/setvbc.F:170-194), and isbcu/asbcu (clinic.F:729-895)
+//   add_ext_mode  /root/reference/updates/09/source/mom/loadmw.F:590-667 (O_stream_function): the external mode added
+//            to the internal-mode velocities at the start of a step (device-resident velocities)
 //
 // Same expressions and evaluation order as the reference (the library is built -ffp-contract=off): results
 // are bit-identical.  Where the reference builds whole arrays first (adv_veu, adv_fe, diff_fb, ...), a cell
 // here evaluates the same expressions for the faces it needs; a face shared by two cells is evaluated twice
 // with the same operands.
 //
-// Three passes (the launch geometry is in uvic_gpu.hip):
+// The three passes of clinic (the launch geometry is in uvic_gpu.hip; the polar filter filuv that follows them is in
+// kernels_filter.hpp):
 //   clinic_gradp_column   lane per column: hydrostatic pressure gradient, summed downward
 //   clinic_tend_cell      thread per cell: the tendency of both components into u(tau+1)
 //   clinic_finish_column  lane per column: zu, the leapfrog update, removal of the vertical mean, cyclic images
