@@ -200,8 +200,9 @@ def test_resident_overlay_through_an_euler_backward_step(exact, monkeypatch):
             assert np.abs(x - y).max() <= (0.0 if exact and n < 2 else PROD_TOL) * np.abs(y).max(), (slot, name)
 
 
+@pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("cfg,dims", [("m2", (14, 14, 6)), ("m2", (102, 102, 19)), ("m2i", (14, 14, 6))])
-def test_overlay_clinic_matches_reference_clinic(cfg, dims, monkeypatch):
+def test_overlay_clinic_matches_reference_clinic(cfg, dims, resident, monkeypatch):
     """The momentum row's boundary end to end: `clinic(joff,js,je,is,ie)` of the package's
     overlay (uvic2.9_amd/fortran/clinic_gpu.F) against the reference's own routine, through the reference's COMMON
     blocks: u(tau+1), zu and the four sbc planes of isbcu/asbcu, bit for bit, with the polar filter filuv on.  The
