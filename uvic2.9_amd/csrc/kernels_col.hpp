@@ -72,6 +72,30 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
   const double sc = 1.0 / (c.slmxr * c.dtxsqr[k - 1]);
   const double dzt4r = 0.5 * c.dzt2r[k - 1];
 #define IDX(ii) X3(ii, k, j)
+  if (TMASK(i, k, j) == 0.0) {
+    // a land cell (37 % of the grid): every face coefficient carries its mask and is zero, only the vertical-diffusion
+    // slot is not masked here (it never was).  Nothing is divided, no slope is formed.
+    if (j >= 2) {
+      UV_CYC_STORE(c.K11, IDX, i, 0.0);
+      if (j <= jmt - 1)
+        for (int p = CF_AE; p < CF_AE + 5; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
+    }
+    for (int p = CF_AN; p < CF_AN + 5; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
+    UV_CYC_STORE(c.K22, IDX, i, 0.0);
+    if (j >= 2) {
+      if (k <= km - 1) {
+        UV_CYC_STORE(c.K33, IDX, i, 0.0);
+        if (j <= jmt - 1) {
+          for (int p = CF_CBX; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
+          const double dcb = c.diff_cbt_given ? c.diff_cbt[q] : c.diff_cbt_bg[q] + 0.0;
+          cf[CF_IDX(CF_BV, q, N3)] = dcb * c.dzwr[k] * (1.0 - c.aidif);
+        }
+      } else if (j <= jmt - 1) {
+        for (int p = CF_BV; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
+      }
+    }
+    return;
+  }
   if (j >= 2) {  // east face
     const double mm = TMASK(i, k, j) * TMASK(i + 1, k, j);
     const double Ai0 = .5 * (c.fisop[XFIS(i, j, k)] + c.fisop[XFIS(i + 1, j, k)]) * c.ahisop + c.addisop[q];
