@@ -29,7 +29,10 @@ def _rand_src(oc, seed=2029, scale=1e-9):
 
 @pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("c30", (102, 102, 19)),
                                       ("p2", (202, 202, 32)), ("c30", (202, 202, 32)), ("perf15", (102, 102, 19))])
-def test_one_step_vs_oracle(cfg, dims):
+@pytest.mark.parametrize("mode", [False, "columns"])
+def test_one_step_vs_oracle(cfg, dims, mode):
+    """mode False: production (T, S through the bit-exact kernels, the others through the column kernels); "columns":
+    every tracer through the column kernels"""
     from uvic29_amd.tracer import TracerModel
     oc = synthetic.make_ocean(performance_set(int(cfg[4:])) if cfg.startswith("perf") else cfg, *dims)
     to, so, c = synthetic.load_eos(dims[2])
@@ -38,11 +41,13 @@ def test_one_step_vs_oracle(cfg, dims):
     orc.isopyc(); orc.add_k33()
     want = orc.transport()
     m = TracerModel(*dims, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
-    m.set_exact(False)
+    m.set_exact(mode)
     m.load_ocean(oc, to, so, c, src=src)
     m.isopyc(); m.transport(); m.convect()
     got = m.download("t_taup1")
     jmt = dims[1]
+    if mode is False:   # T and S of the production path are the reference's bits
+        assert np.array_equal(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2])
     worst = 0.0
     for n, name in enumerate(oc.cfg.tracers):
         r = _rel(got[:, :, 1:jmt - 1, n], want[:, :, 1:jmt - 1, n])
@@ -76,8 +81,9 @@ def test_twenty_steps_vs_reference_golden_run(cfg):
     m.close()
 
 
+@pytest.mark.parametrize("mode", [False, "columns"])
 @pytest.mark.parametrize("dims", [(14, 14, 6), (102, 102, 19)])
-def test_whole_step_with_fused_convection_equals_the_separate_passes(dims):
+def test_whole_step_with_fused_convection_equals_the_separate_passes(dims, mode):
     """`uvic_gpu_tracer` sends T and S through both column passes and the convective walk first (side stream) and lets
     pass B of the other tracers replay the mixed segments before t(tau+1) is stored; `transport` + `convect` run pass A
     and B for all tracers together and convct2 as its own two passes.  Same bits, and convection does act on this ocean."""
@@ -88,7 +94,7 @@ def test_whole_step_with_fused_convection_equals_the_separate_passes(dims):
     out = {}
     for how in ("fused", "separate", "unmixed"):
         m = TracerModel(*dims, oc.cfg.nt, oc.cfg.nsrc, 0)      # sources given: the comparison is about transport + convection
-        m.set_exact(False)
+        m.set_exact(mode)
         m.load_ocean(oc, to, so, c, src=src)
         m.isopyc()
         if how == "fused":

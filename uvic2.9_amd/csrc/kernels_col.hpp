@@ -65,8 +65,10 @@ enum {
 #else
 #define UV_FAST_FP
 #endif
-UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
-  UV_FAST_FP
+// Nothing here is contracted: Ai, K11, K22, K33 come out bit-identical to isopyc_ai_cell (the T,S passes and diff_cbt =
+// background + K33 depend on them to the bit); the folded coefficients are products only.
+// `store_ai`: also store the sixteen Ai planes (the bit-exact T,S passes read them, kernels_fct.hpp).
+UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, int store_ai = 0) {
   UV_DIMS(c);
   const size_t q = X3(i, k, j);
   const double sc = 1.0 / (c.slmxr * c.dtxsqr[k - 1]);
@@ -75,6 +77,13 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
   if (TMASK(i, k, j) == 0.0) {
     // a land cell (37 % of the grid): every face coefficient carries its mask and is zero, only the vertical-diffusion
     // slot is not masked here (it never was).  Nothing is divided, no slope is formed.
+    if (store_ai)
+      for (int p = 0; p < 4; ++p) {
+        double *pe = c.Ai_ez + (size_t)p * N3, *pn = c.Ai_nz + (size_t)p * N3, *px = c.Ai_bx + (size_t)p * N3, *py = c.Ai_by + (size_t)p * N3;
+        if (j >= 2) UV_CYC_STORE(pe, IDX, i, 0.0);
+        UV_CYC_STORE(pn, IDX, i, 0.0);
+        if (j >= 2 && k <= km - 1) { UV_CYC_STORE(px, IDX, i, 0.0); UV_CYC_STORE(py, IDX, i, 0.0); }
+      }
     if (j >= 2) {
       UV_CYC_STORE(c.K11, IDX, i, 0.0);
       if (j <= jmt - 1)
@@ -111,6 +120,7 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
         } else {
           a = Ai0 * TMASK(i, k, j) * TMASK(i + 1, k, j);
         }
+        if (store_ai) { double *p = c.Ai_ez + (size_t)(ip + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
         sumz = sumz + c.dzw[k - 1 + kr] * a;
         if (j <= jmt - 1) cf[CF_IDX(CF_CE + ip + 2 * kr, q, N3)] = -dzt4r * (a * sl);
       }
@@ -137,6 +147,7 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
         } else {
           a = Ai0 * TMASK(i, k, j) * TMASK(i, k, j + 1);
         }
+        if (store_ai) { double *p = c.Ai_nz + (size_t)(jq + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
         sumz = sumz + c.dzw[k - 1 + kr] * a;
         cf[CF_IDX(CF_CN + jq + 2 * kr, q, N3)] = -csu_dzt4r * (a * sl);
       }
@@ -159,6 +170,7 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
           } else {
             a = Ai0 * TMASK(i, k + 1, j);
           }
+          if (store_ai) { double *p = c.Ai_bx + (size_t)(ip + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
           sumx = sumx + c.dxu[i - 1 + ip - 1] * a * (sxb * sxb);
           if (j <= jmt - 1) cf[CF_IDX(CF_CBX + ip + 2 * kr, q, N3)] = -c.dxt4r[i - 1] * (a * c.cstr[j - 1] * sl);
         }
@@ -175,6 +187,7 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {
           } else {
             a = Ai0 * TMASK(i, k + 1, j);
           }
+          if (store_ai) { double *p = c.Ai_by + (size_t)(jq + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
           sumy = sumy + facty * a * (syb * syb);
           if (j <= jmt - 1) cf[CF_IDX(CF_CBY + jq + 2 * kr, q, N3)] = -c.dyt4r[j - 1] * c.cstr[j - 1] * (a * c.csu[j - 1 + jq - 1] * sl);
         }

@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(64 * ISO_COL_PARTS) k_isopyc_column(const uvic
 // one workgroup per (row, local tracer, longitude chunk)
 struct TileGrid {
   int r0, nrows, nchunk, total;
+  int *zero_word;   // a counter the NEXT kernel on the stream wants cleared (spares a memset node), or null
 };
 __device__ __forceinline__ bool tile_decode(const uvic_ctx &c, const TileGrid &g, int &row, int &n1, int &chunk) {
   const int L = xcd_remap(blockIdx.x, g.total);
@@ -147,6 +148,7 @@ __device__ __forceinline__ bool tile_decode(const uvic_ctx &c, const TileGrid &g
 }
 __global__ void __launch_bounds__(1024) k_fct_rows(const uvic_ctx c, const TileGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the T,S passes: a latency chain others wait for
   int row, n1, chunk;
   if (!tile_decode(c, g, row, n1, chunk)) return;
   GpuEnv env;
@@ -154,6 +156,8 @@ __global__ void __launch_bounds__(1024) k_fct_rows(const uvic_ctx c, const TileG
 }
 __global__ void __launch_bounds__(1024) k_update_rows(const uvic_ctx c, const TileGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (g.zero_word && blockIdx.x == 0 && threadIdx.x == 0) *g.zero_word = 0;
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the T,S passes: a latency chain others wait for
   int row, n1, chunk;
   if (!tile_decode(c, g, row, n1, chunk)) return;
   GpuEnv env;
@@ -225,11 +229,11 @@ __global__ void __launch_bounds__(64) k_filuv_mean(const uvic_mom_ctx m, const i
   if (j < m.js || j > m.je) return;
   filuv_mean_column(m.imt, m.km, i, j, m.kmu, m.hr, m.dzt, m.up1, m.up2);
 }
-__global__ void __launch_bounds__(256) k_ai_coef(const uvic_ctx c, double *cf) {
+__global__ void __launch_bounds__(256) k_ai_coef(const uvic_ctx c, double *cf, int store_ai) {
   if (c.prio & 4) __builtin_amdgcn_s_setprio(3);   // short kernel of a latency chain: win issue arbitration over the bulk passes
   CELL_DECODE(c);
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
-  ai_coef_cell(c, cf, i, k, j);
+  ai_coef_cell(c, cf, i, k, j, store_ai);
 }
 __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
   CELL_DECODE(c);
@@ -701,6 +705,7 @@ struct uvic_gpu {
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
   double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
+  bool ts_exact;    // production default: T and S (whose bits decide every convective adjustment) go through the bit-exact kernels, the other tracers through the column kernels
   bool mixing_next_guard = false;
   bool yfin;        // pass A leaves the final y flux of each row's north face, pass B reads two of them (UVIC_YFIN, default 1)
   bool b_zglobal;   // pass B parks z(k) in t(tau+1) instead of LDS (UVIC_B_ZGLOBAL, default 1)
@@ -985,7 +990,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   HIPCHK(hipMemset(h->coef, 0, N3 * 16 * CF_PAIRS));
   iso_set_adopt(h);   // what was just allocated is set 0
   h->exact = false;
-  if (const char *e = getenv("UVIC_EXACT")) h->exact = atoi(e) != 0;
+  h->ts_exact = true;
+  if (const char *e = getenv("UVIC_EXACT")) { h->exact = atoi(e) == 1; h->ts_exact = atoi(e) != 2; }
   h->b_zglobal = false;   // measured: 91 us alone against 80 with both arrays in LDS (the pass is bound by memory traffic, not by occupancy)
   if (const char *e = getenv("UVIC_B_ZGLOBAL")) h->b_zglobal = atoi(e) != 0;
   h->yfin = true;
@@ -1414,9 +1420,13 @@ extern "C" int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p) {
   h->ctx.diff_cbt_given = p->diff_cbt_has_k33 ? 1 : 0;
   return 0;
 }
+extern "C" int uvic_gpu_sync(uvic_gpu *h);
 extern "C" int uvic_gpu_set_exact(uvic_gpu *h, int exact) {
   if (!h) return fail_msg("uvic_gpu_set_exact: null handle");
-  h->exact = exact != 0;
+  if (int rc = uvic_gpu_sync(h)) return rc;   // (a look-ahead chain may be writing what the other arithmetic recomputes in line)
+  h->exact = exact == 1;       // 1: every tracer through the bit-exact kernels
+  h->ts_exact = exact != 2;    // 0 (default): T and S exact, the others through the column kernels; 2: every tracer through the column kernels
+  for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;   // a look-ahead chain formed its products for the other arithmetic
   return 0;
 }
 extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je) {
@@ -1524,7 +1534,7 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
   if (h->exact)
     hipLaunchKernelGGL(k_isopyc_ai, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
   else   // column-kernel path: mixing tensor and folded coefficients in one pass (Ai_* stay in registers)
-    hipLaunchKernelGGL(k_ai_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef);
+    hipLaunchKernelGGL(k_ai_coef, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef, h->ts_exact ? 1 : 0);
   mark_on(h, "isopyc_ai", sid);
   hipLaunchKernelGGL(k_isopyc_adv, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c, coef);
   mark_on(h, "isopyc_adv", sid);
@@ -1562,6 +1572,30 @@ static int launch_isopyc(uvic_gpu *h) {
     return 0;
   }
   return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
+}
+// the bit-exact row kernels (kernels_fct.hpp) for the tracers of `c` (n0, nt_local) on stream `st`; marks go to list `sid`
+static int launch_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid, int *zero_word, const char *name_a, const char *name_b) {
+  if (c.nt_local <= 0) return 0;
+  TileGrid g1, g2;
+  g1.r0 = c.js - 1 < 2 ? 2 : c.js - 1;
+  const int r1 = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
+  g1.nrows = r1 - g1.r0 + 1;
+  g1.nchunk = h->nchunk;
+  g1.total = g1.nrows * c.nt_local * h->nchunk;
+  g1.zero_word = nullptr;
+  g2.r0 = c.js; g2.nrows = c.je - c.js + 1; g2.nchunk = h->nchunk;
+  g2.total = g2.nrows * c.nt_local * h->nchunk;
+  g2.zero_word = zero_word;
+  hipLaunchKernelGGL(k_fct_rows, dim3((unsigned)(((g1.total + 7) / 8) * 8)), dim3(h->fct_threads), h->fct_lds, st, c, g1);
+  mark_on(h, name_a, sid);
+  if (sid == 0 && h->src_from_prefetch) {  // the FCT kernel does not read the sources; only the update does
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+    h->src_from_prefetch = false;
+  }
+  hipLaunchKernelGGL(k_update_rows, dim3((unsigned)(((g2.total + 7) / 8) * 8)), dim3(h->upd_threads), h->upd_lds, st, c, g2);
+  mark_on(h, name_b, sid);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 // `convect_follows`: the caller runs convct2 right after (the whole `tracer` step): T,S may go first and the replay be fused
 static int launch_transport(uvic_gpu *h, bool convect_follows) {
@@ -1639,12 +1673,22 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       // pass B of T,S and the convective walk share a launch when nothing stands between them (the replay fused into pass B
       // of the others, UVIC_CONV_DECOUPLED=0, also works from the walk's records: same launch)
       static const bool fuse_env = !getenv("UVIC_TS_FUSE") || atoi(getenv("UVIC_TS_FUSE")) != 0;
-      const bool ts_fuse = fuse_env && h->yfin && ats.total > 0 && bts.total > 0 && w.count > 0 && c.nt_local >= 2;
+      const bool ts_fuse = !h->ts_exact && fuse_env && h->yfin && ats.total > 0 && bts.total > 0 && w.count > 0 && c.nt_local >= 2;
       if (ts_fuse) ats.zero_word = h->cv_list;
+      if (h->ts_exact) {
+        // T and S in the reference's own order of operations (kernels_fct.hpp): every convective adjustment is decided on
+        // their bits (convect.F:189-255), and a density comparison of rounding size flips on a 1-ulp difference
+        if (int rc = launch_rows(h, cts, h->side_ts, 3, w.count > 0 ? h->cv_list : nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
+        if (w.count > 0)
+          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
+        mark_on(h, "convect_ts", 3);
+      } else {
       if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       mark_on(h, "colfct_ts", 3);
-      if (ts_fuse) {
+      }
+      if (h->ts_exact) {
+      } else if (ts_fuse) {
         const size_t lds_b = ((size_t)2 * 2 * (c.km + 1) * 64 + (size_t)12 * c.km) * 8;
         hipLaunchKernelGGL(k_colupd_conv_ts, dim3((unsigned)(((bts.nwaves + 7) / 8) * 8)), dim3(64, 2), lds_b, h->side_ts, cts, (const double *)S, bts, h->cv_list);
         mark_on(h, "colupd_conv_ts", 3);
@@ -1699,37 +1743,34 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     } else {
       if (int rc = land_clean(h, c, h->stream)) return rc;
       mark(h, "begin");
-      launch_a(c, a, S, h->stream);
+      // the local tracers among T and S go through the bit-exact kernels (see above), the others through the column kernels
+      const int n_ts = (h->ts_exact && c.n0 < 2) ? std::min(c.n0 + c.nt_local, 2) - c.n0 : 0;
+      if (n_ts > 0) {
+        uvic_ctx cts = c;
+        cts.nt_local = n_ts;
+        if (int rc = launch_rows(h, cts, h->stream, 0, nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
+      }
+      const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+      uvic_ctx cr = c;
+      cr.n0 = c.n0 + n_ts; cr.nt_local = c.nt_local - n_ts;
+      cr.Rpm = c.Rpm + (size_t)n_ts * N3 * 2;
+      ColGrid ar = a, br = b;
+      ar.total = ar.nwaves * cr.nt_local;
+      br.total = br.nwaves * cr.nt_local;
+      launch_a(cr, ar, S + (size_t)n_ts * N3, h->stream);
       mark(h, "colfct");
       if (h->src_from_prefetch) {
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
         h->src_from_prefetch = false;
       }
-      launch_b(c, b, (const double *)S, h->stream, false);
+      launch_b(cr, br, (const double *)(S + (size_t)n_ts * N3), h->stream, false);
     }
     mark(h, "colupd");
     HIPCHK(hipGetLastError());
     return 0;
   }
-  TileGrid g1, g2;
-  g1.r0 = c.js - 1 < 2 ? 2 : c.js - 1;
-  const int r1 = c.je + 1 > c.jmt - 1 ? c.jmt - 1 : c.je + 1;
-  g1.nrows = r1 - g1.r0 + 1;
-  g1.nchunk = h->nchunk;
-  g1.total = g1.nrows * c.nt_local * h->nchunk;
-  g2.r0 = c.js; g2.nrows = c.je - c.js + 1; g2.nchunk = h->nchunk;
-  g2.total = g2.nrows * c.nt_local * h->nchunk;
   mark(h, "begin");
-  hipLaunchKernelGGL(k_fct_rows, dim3((unsigned)(((g1.total + 7) / 8) * 8)), dim3(h->fct_threads), h->fct_lds, h->stream, c, g1);
-  mark(h, "fct_rows");
-  if (h->src_from_prefetch) {  // the FCT kernel does not read the sources; only the update does
-    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
-    h->src_from_prefetch = false;
-  }
-  hipLaunchKernelGGL(k_update_rows, dim3((unsigned)(((g2.total + 7) / 8) * 8)), dim3(h->upd_threads), h->upd_lds, h->stream, c, g2);
-  mark(h, "update_rows");
-  HIPCHK(hipGetLastError());
-  return 0;
+  return launch_rows(h, c, h->stream, 0, nullptr, "fct_rows", "update_rows");
 }
 static int launch_convect(uvic_gpu *h) {
   mark(h, "begin");

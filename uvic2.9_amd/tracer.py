@@ -296,8 +296,12 @@ class TracerModel:
         check(self.lib.uvic_gpu_prefetch_sources(self.h, float(c2dtts_next)), "prefetch_sources")
 
     def set_exact(self, on):
-        """True: bit-exact row kernels; False: lane-per-column kernels with folded coefficients."""
-        check(self.lib.uvic_gpu_set_exact(self.h, 1 if on else 0), "set_exact")
+        """Arithmetic of the transport step: False / 0 = production (T and S through the bit-exact kernels -- every
+        convective adjustment is decided on their bits --, the other tracers through the column kernels);
+        True / 1 = every tracer through the bit-exact kernels; "columns" / 2 = every tracer through the column kernels
+        (T and S then agree with the reference to rounding only)."""
+        mode = 2 if on in ("columns", 2) and on is not True else (1 if on else 0)
+        check(self.lib.uvic_gpu_set_exact(self.h, mode), "set_exact")
 
     def set_mixing(self, on):
         check(self.lib.uvic_gpu_set_mixing(self.h, 1 if on else 0), "set_mixing")
