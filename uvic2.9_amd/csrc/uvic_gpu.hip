@@ -18,6 +18,7 @@
 
 #include "../../include/uvic_gpu.h"
 #include "kernels_col.hpp"
+#include "kernels_colx.hpp"
 #include "kernels_prep.hpp"
 #include "kernels_filter.hpp"
 #include "kernels_clinic.hpp"
@@ -381,6 +382,55 @@ __global__ void __launch_bounds__(128) k_colupd_conv_ts(const uvic_ctx c, const 
   const int wid = (i - 1) + c.imt * (j - 1);
   if (cvl && c.cv_nseg[wid] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid;
 }
+// ---- T and S in the reference's own order of operations (kernels_colx.hpp) --------------------------------
+// a workgroup = four waves on the same 64 lanes of the pass-A lane map: (T, advective), (S, advective), (T, diffusive), (S, diffusive)
+__global__ void __launch_bounds__(256) k_colx_fct(const uvic_ctx c, const ColxOut o, const ColGrid g) {
+  if (g.zero_word && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *g.zero_word = 0;   // (a counter a later kernel of the stream wants cleared)
+  const int blk = xcd_remap(blockIdx.x, g.nwaves);
+  if (blk >= g.nwaves) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const int tr = wv & 1;
+  if (tr >= c.nt_local) return;
+  const int code = g.lanes[(size_t)blk * 64 + threadIdx.x];
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
+  if (wv < 2) colx_adv_wave(c, o, code, c.n0 + tr + 1, tr);
+  else colx_dif_wave(c, o, code, c.n0 + tr + 1, tr);
+}
+// pass B of the local tracers among T and S, one wave per (wave of the pass-B lane map, tracer)
+__global__ void __launch_bounds__(64) k_colx_upd(const uvic_ctx c, const ColxOut o, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int blk = xcd_remap(blockIdx.x, g.total);
+  if (blk >= g.total) return;
+  const int tr = blk / g.nwaves;
+  const int code = g.lanes[(size_t)(blk % g.nwaves) * 64 + threadIdx.x];
+  colx_upd_wave(c, o, lds, code, c.n0 + tr + 1, tr);
+}
+// ... and, for T and S together, with the convective walk in the same launch (as k_colupd_conv_ts)
+__global__ void __launch_bounds__(128) k_colx_upd_conv(const uvic_ctx c, const ColxOut o, const ColGrid g, int *cvl) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int nblk = g.nwaves;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
+  const size_t per_wave = (size_t)2 * (c.km + 1) * 64;
+  double *tab = lds + 2 * per_wave;
+  for (int q = threadIdx.y * 64 + threadIdx.x; q < 12 * c.km; q += 128) {   // the per-level tables of the walk
+    const int a = q / c.km, k = q % c.km;
+    tab[q] = a < 9 ? c.c[q] : (a == 9 ? c.to[k] : (a == 10 ? c.so[k] : c.dztxcl[k]));
+  }
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
+  int code = 0;
+  if (blk < nblk) {
+    code = g.lanes[(size_t)blk * 64 + threadIdx.x];
+    colx_upd_wave(c, o, lds + (size_t)wv * per_wave, code, c.n0 + wv + 1, wv);
+  }
+  __syncthreads();
+  if (blk >= nblk || wv != 0 || !COL_LANE_OWNED(code)) return;
+  const int i = COL_LANE_I(code), j = COL_LANE_R(code);
+  double *zT = lds + (size_t)(c.km + 1) * 64, *zS = lds + per_wave + (size_t)(c.km + 1) * 64;   // zwork[k][lane], k = 1..km
+  convect_ts_column(c, i, j, zT + 64 + threadIdx.x, zS + 64 + threadIdx.x, 64, tab, true);
+  const int wid = (i - 1) + c.imt * (j - 1);
+  if (cvl && c.cv_nseg[wid] > 0) cvl[1 + atomicAdd(cvl, 1)] = wid;
+}
 __global__ void __launch_bounds__(128) k_convect(const uvic_ctx c) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid % c.imt + 1, j = gid / c.imt + 1;
@@ -705,6 +755,7 @@ struct uvic_gpu {
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
   double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
+  bool ts_rows;     // ... through the row kernels of kernels_fct.hpp instead of the exact column kernels (cross-check: set_exact(3))
   bool ts_exact;    // production default: T and S (whose bits decide every convective adjustment) go through the bit-exact kernels, the other tracers through the column kernels
   bool mixing_next_guard = false;
   bool yfin;        // pass A leaves the final y flux of each row's north face, pass B reads two of them (UVIC_YFIN, default 1)
@@ -991,6 +1042,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   iso_set_adopt(h);   // what was just allocated is set 0
   h->exact = false;
   h->ts_exact = true;
+  h->ts_rows = false;
   if (const char *e = getenv("UVIC_EXACT")) { h->exact = atoi(e) == 1; h->ts_exact = atoi(e) != 2; }
   h->b_zglobal = false;   // measured: 91 us alone against 80 with both arrays in LDS (the pass is bound by memory traffic, not by occupancy)
   if (const char *e = getenv("UVIC_B_ZGLOBAL")) h->b_zglobal = atoi(e) != 0;
@@ -1426,6 +1478,7 @@ extern "C" int uvic_gpu_set_exact(uvic_gpu *h, int exact) {
   if (int rc = uvic_gpu_sync(h)) return rc;   // (a look-ahead chain may be writing what the other arithmetic recomputes in line)
   h->exact = exact == 1;       // 1: every tracer through the bit-exact kernels
   h->ts_exact = exact != 2;    // 0 (default): T and S exact, the others through the column kernels; 2: every tracer through the column kernels
+  h->ts_rows = exact == 3;     // 3: as 0 with T and S through the row kernels (cross-check of the exact column kernels)
   for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;   // a look-ahead chain formed its products for the other arithmetic
   return 0;
 }
@@ -1597,6 +1650,33 @@ static int launch_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid, 
   HIPCHK(hipGetLastError());
   return 0;
 }
+// T and S (the local tracers among them: c.n0 < 2, c.nt_local <= 2) through the exact column kernels on stream `st`.
+// `walk`: pass B and the convective T,S walk in one launch (both tracers local, the whole `tracer` step)
+static int launch_colx(uvic_gpu *h, const uvic_ctx &c, const ColGrid &a, const ColGrid &b, hipStream_t st, int sid, bool walk) {
+  if (c.nt_local <= 0) return 0;
+  ColxOut o;
+  o.adv_x = h->work[3]; o.adv_z = h->work[4]; o.fn = h->work[5]; o.dif = h->work[6];
+  ColGrid ga = a, gb = b;
+  ga.zero_word = walk ? h->cv_list : nullptr;
+  gb.total = gb.nwaves * c.nt_local;
+  if (ga.nwaves > 0) hipLaunchKernelGGL(k_colx_fct, dim3((unsigned)(((ga.nwaves + 7) / 8) * 8)), dim3(64, 4), 0, st, c, o, ga);
+  mark_on(h, "colx_fct_ts", sid);
+  if (sid == 0 && h->src_from_prefetch) {  // (T or S with a source term: only the update reads it)
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+    h->src_from_prefetch = false;
+  }
+  if (gb.nwaves > 0) {
+    if (walk) {
+      const size_t lds_b = ((size_t)2 * 2 * (c.km + 1) * 64 + (size_t)12 * c.km) * 8;
+      hipLaunchKernelGGL(k_colx_upd_conv, dim3((unsigned)(((gb.nwaves + 7) / 8) * 8)), dim3(64, 2), lds_b, st, c, o, gb, h->cv_list);
+    } else {
+      hipLaunchKernelGGL(k_colx_upd, dim3((unsigned)(((gb.total + 7) / 8) * 8)), dim3(64), (size_t)2 * (c.km + 1) * 64 * 8, st, c, o, gb);
+    }
+  }
+  mark_on(h, walk ? "colx_upd_conv_ts" : "colx_upd_ts", sid);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 // `convect_follows`: the caller runs convct2 right after (the whole `tracer` step): T,S may go first and the replay be fused
 static int launch_transport(uvic_gpu *h, bool convect_follows) {
   const uvic_ctx &c = h->ctx;
@@ -1678,10 +1758,14 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (h->ts_exact) {
         // T and S in the reference's own order of operations (kernels_fct.hpp): every convective adjustment is decided on
         // their bits (convect.F:189-255), and a density comparison of rounding size flips on a 1-ulp difference
-        if (int rc = launch_rows(h, cts, h->side_ts, 3, w.count > 0 ? h->cv_list : nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
-        if (w.count > 0)
-          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
-        mark_on(h, "convect_ts", 3);
+        if (h->ts_rows) {
+          if (int rc = launch_rows(h, cts, h->side_ts, 3, w.count > 0 ? h->cv_list : nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
+          if (w.count > 0)
+            hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
+          mark_on(h, "convect_ts", 3);
+        } else {
+          if (int rc = launch_colx(h, cts, ats, bts, h->side_ts, 3, w.count > 0)) return rc;
+        }
       } else {
       if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
       else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
@@ -1748,7 +1832,8 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (n_ts > 0) {
         uvic_ctx cts = c;
         cts.nt_local = n_ts;
-        if (int rc = launch_rows(h, cts, h->stream, 0, nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
+        if (h->ts_rows) { if (int rc = launch_rows(h, cts, h->stream, 0, nullptr, "fct_rows_ts", "update_rows_ts")) return rc; }
+        else if (int rc = launch_colx(h, cts, a, b, h->stream, 0, false)) return rc;
       }
       const size_t N3 = (size_t)c.imt * c.km * c.jmt;
       uvic_ctx cr = c;

@@ -299,8 +299,9 @@ class TracerModel:
         """Arithmetic of the transport step: False / 0 = production (T and S through the bit-exact kernels -- every
         convective adjustment is decided on their bits --, the other tracers through the column kernels);
         True / 1 = every tracer through the bit-exact kernels; "columns" / 2 = every tracer through the column kernels
-        (T and S then agree with the reference to rounding only)."""
-        mode = 2 if on in ("columns", 2) and on is not True else (1 if on else 0)
+        (T and S then agree with the reference to rounding only); "rows" / 3 = as production with T and S through the
+        row kernels of kernels_fct.hpp instead of the exact column kernels (cross-check)."""
+        mode = {"columns": 2, "rows": 3}.get(on) if isinstance(on, str) else (int(on) if on in (2, 3) and on is not True else (1 if on else 0))
         check(self.lib.uvic_gpu_set_exact(self.h, mode), "set_exact")
 
     def set_mixing(self, on):
