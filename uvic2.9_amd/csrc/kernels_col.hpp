@@ -67,44 +67,21 @@ enum {
 #endif
 // Nothing here is contracted: Ai, K11, K22, K33 come out bit-identical to isopyc_ai_cell (the T,S passes and diff_cbt =
 // background + K33 depend on them to the bit); the folded coefficients are products only.
-// `store_ai`: also store the sixteen Ai planes (the bit-exact T,S passes read them, kernels_fct.hpp).
+// `store_ai`: also store the sixteen Ai planes (the exact T,S kernels read them, kernels_colx.hpp).
+// A land cell (37 % of the grid) is left at once: every product of it carries its mask and is zero, the buffers are
+// zero-filled when they are allocated and again when kmt changes (uvic_gpu.hip: iso_set_alloc, make_tmask), and nothing
+// reads the one unmasked slot (the vertical-diffusion coefficient) of a land cell: t(tau-1) is zero on both sides of
+// the face it belongs to.  The nineteen coefficients leave in ten 16-byte stores.
 UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, int store_ai = 0) {
   UV_DIMS(c);
   const size_t q = X3(i, k, j);
+  if (TMASK(i, k, j) == 0.0) return;
   const double sc = 1.0 / (c.slmxr * c.dtxsqr[k - 1]);
   const double dzt4r = 0.5 * c.dzt2r[k - 1];
+  double cfv[2 * CF_DPAIRS];
+  for (int p = 0; p < 2 * CF_DPAIRS; ++p) cfv[p] = 0.0;
+  const bool inner = j >= 2 && j <= jmt - 1;   // rows whose east and bottom faces are needed
 #define IDX(ii) X3(ii, k, j)
-  if (TMASK(i, k, j) == 0.0) {
-    // a land cell (37 % of the grid): every face coefficient carries its mask and is zero, only the vertical-diffusion
-    // slot is not masked here (it never was).  Nothing is divided, no slope is formed.
-    if (store_ai)
-      for (int p = 0; p < 4; ++p) {
-        double *pe = c.Ai_ez + (size_t)p * N3, *pn = c.Ai_nz + (size_t)p * N3, *px = c.Ai_bx + (size_t)p * N3, *py = c.Ai_by + (size_t)p * N3;
-        if (j >= 2) UV_CYC_STORE(pe, IDX, i, 0.0);
-        UV_CYC_STORE(pn, IDX, i, 0.0);
-        if (j >= 2 && k <= km - 1) { UV_CYC_STORE(px, IDX, i, 0.0); UV_CYC_STORE(py, IDX, i, 0.0); }
-      }
-    if (j >= 2) {
-      UV_CYC_STORE(c.K11, IDX, i, 0.0);
-      if (j <= jmt - 1)
-        for (int p = CF_AE; p < CF_AE + 5; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
-    }
-    for (int p = CF_AN; p < CF_AN + 5; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
-    UV_CYC_STORE(c.K22, IDX, i, 0.0);
-    if (j >= 2) {
-      if (k <= km - 1) {
-        UV_CYC_STORE(c.K33, IDX, i, 0.0);
-        if (j <= jmt - 1) {
-          for (int p = CF_CBX; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
-          const double dcb = c.diff_cbt_given ? c.diff_cbt[q] : c.diff_cbt_bg[q] + 0.0;
-          cf[CF_IDX(CF_BV, q, N3)] = dcb * c.dzwr[k] * (1.0 - c.aidif);
-        }
-      } else if (j <= jmt - 1) {
-        for (int p = CF_BV; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
-      }
-    }
-    return;
-  }
   if (j >= 2) {  // east face
     const double mm = TMASK(i, k, j) * TMASK(i + 1, k, j);
     const double Ai0 = .5 * (c.fisop[XFIS(i, j, k)] + c.fisop[XFIS(i + 1, j, k)]) * c.ahisop + c.addisop[q];
@@ -122,14 +99,12 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, i
         }
         if (store_ai) { double *p = c.Ai_ez + (size_t)(ip + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
         sumz = sumz + c.dzw[k - 1 + kr] * a;
-        if (j <= jmt - 1) cf[CF_IDX(CF_CE + ip + 2 * kr, q, N3)] = -dzt4r * (a * sl);
+        cfv[CF_CE + ip + 2 * kr] = -dzt4r * (a * sl);
       }
     const double k11 = dzt4r * sumz;
     UV_CYC_STORE(c.K11, IDX, i, k11);
-    if (j <= jmt - 1) {
-      const double cstdxur = c.cstr[j - 1] * c.dxur[i - 1];
-      cf[CF_IDX(CF_AE, q, N3)] = (c.diff_cet * cstdxur + k11 * cstdxur) * mm;
-    }
+    const double cstdxur = c.cstr[j - 1] * c.dxur[i - 1];
+    cfv[CF_AE] = (c.diff_cet * cstdxur + k11 * cstdxur) * mm;
   }
   {  // north face
     const double mm = TMASK(i, k, j) * TMASK(i, k, j + 1);
@@ -149,62 +124,65 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, i
         }
         if (store_ai) { double *p = c.Ai_nz + (size_t)(jq + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
         sumz = sumz + c.dzw[k - 1 + kr] * a;
-        cf[CF_IDX(CF_CN + jq + 2 * kr, q, N3)] = -csu_dzt4r * (a * sl);
+        cfv[CF_CN + jq + 2 * kr] = -csu_dzt4r * (a * sl);
       }
     const double k22 = dzt4r * sumz;
     UV_CYC_STORE(c.K22, IDX, i, k22);
-    cf[CF_IDX(CF_AN, q, N3)] = (c.diff_cnt * c.csu_dyur[j - 1] + k22 * c.csu_dyur[j - 1]) * mm;
+    cfv[CF_AN] = (c.diff_cnt * c.csu_dyur[j - 1] + k22 * c.csu_dyur[j - 1]) * mm;
   }
-  if (j >= 2) {  // bottom face
-    if (k <= km - 1) {
-      const double Ai0 = 0.5 * (c.fisop[XFIS(i, j, k + 1)] + c.fisop[XFIS(i, j, k)]) * c.ahisop;
-      double sumx = 0.0;
-      for (int ip = 0; ip <= 1; ++ip)
-        for (int kr = 0; kr <= 1; ++kr) {
-          const double sl = drodxb(i, k, j, ip, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
-          const double sxb = dabs(sl);
-          double a;
-          if (sxb > sc) {
-            const double r = sc / (sxb + UV_EPSLN);
-            a = Ai0 * TMASK(i, k + 1, j) * (r * r);
-          } else {
-            a = Ai0 * TMASK(i, k + 1, j);
-          }
-          if (store_ai) { double *p = c.Ai_bx + (size_t)(ip + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
-          sumx = sumx + c.dxu[i - 1 + ip - 1] * a * (sxb * sxb);
-          if (j <= jmt - 1) cf[CF_IDX(CF_CBX + ip + 2 * kr, q, N3)] = -c.dxt4r[i - 1] * (a * c.cstr[j - 1] * sl);
+  if (j >= 2 && k <= km - 1) {  // bottom face
+    const double Ai0 = 0.5 * (c.fisop[XFIS(i, j, k + 1)] + c.fisop[XFIS(i, j, k)]) * c.ahisop;
+    double sumx = 0.0;
+    for (int ip = 0; ip <= 1; ++ip)
+      for (int kr = 0; kr <= 1; ++kr) {
+        const double sl = drodxb(i, k, j, ip, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
+        const double sxb = dabs(sl);
+        double a;
+        if (sxb > sc) {
+          const double r = sc / (sxb + UV_EPSLN);
+          a = Ai0 * TMASK(i, k + 1, j) * (r * r);
+        } else {
+          a = Ai0 * TMASK(i, k + 1, j);
         }
-      double sumy = 0.0;
-      for (int jq = 0; jq <= 1; ++jq) {
-        const double facty = c.csu[j - 1 + jq - 1] * c.dyu[j - 1 + jq - 1];
-        for (int kr = 0; kr <= 1; ++kr) {
-          const double sl = drodyb(i, k, j, jq, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
-          const double syb = dabs(sl);
-          double a;
-          if (syb > sc) {
-            const double r = sc / (syb + UV_EPSLN);
-            a = Ai0 * TMASK(i, k + 1, j) * (r * r);
-          } else {
-            a = Ai0 * TMASK(i, k + 1, j);
-          }
-          if (store_ai) { double *p = c.Ai_by + (size_t)(jq + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
-          sumy = sumy + facty * a * (syb * syb);
-          if (j <= jmt - 1) cf[CF_IDX(CF_CBY + jq + 2 * kr, q, N3)] = -c.dyt4r[j - 1] * c.cstr[j - 1] * (a * c.csu[j - 1 + jq - 1] * sl);
+        if (store_ai) { double *p = c.Ai_bx + (size_t)(ip + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
+        sumx = sumx + c.dxu[i - 1 + ip - 1] * a * (sxb * sxb);
+        cfv[CF_CBX + ip + 2 * kr] = -c.dxt4r[i - 1] * (a * c.cstr[j - 1] * sl);
+      }
+    double sumy = 0.0;
+    for (int jq = 0; jq <= 1; ++jq) {
+      const double facty = c.csu[j - 1 + jq - 1] * c.dyu[j - 1 + jq - 1];
+      for (int kr = 0; kr <= 1; ++kr) {
+        const double sl = drodyb(i, k, j, jq, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
+        const double syb = dabs(sl);
+        double a;
+        if (syb > sc) {
+          const double r = sc / (syb + UV_EPSLN);
+          a = Ai0 * TMASK(i, k + 1, j) * (r * r);
+        } else {
+          a = Ai0 * TMASK(i, k + 1, j);
         }
+        if (store_ai) { double *p = c.Ai_by + (size_t)(jq + 2 * kr) * N3; UV_CYC_STORE(p, IDX, i, a); }
+        sumy = sumy + facty * a * (syb * syb);
+        cfv[CF_CBY + jq + 2 * kr] = -c.dyt4r[j - 1] * c.cstr[j - 1] * (a * c.csu[j - 1 + jq - 1] * sl);
       }
-      const double k33 = c.dxt4r[i - 1] * sumx + c.dyt4r[j - 1] * c.cstr[j - 1] * sumy;
-      UV_CYC_STORE(c.K33, IDX, i, k33);
-      if (j <= jmt - 1) {
-        // diff_cbt = background + K33 is what isopyc_column stores for this cell; a given diff_cbt (host or device
-        // vmixc) is read instead -- when vmixc runs on the device after isopyc, coef_bv_cell renews this slot
-        const double dcb = c.diff_cbt_given ? c.diff_cbt[q] : c.diff_cbt_bg[q] + k33;
-        cf[CF_IDX(CF_BV, q, N3)] = dcb * c.dzwr[k] * (1.0 - c.aidif);
-      }
-    } else if (j <= jmt - 1) {
-      for (int p = CF_BV; p < CF_COUNT; ++p) cf[CF_IDX(p, q, N3)] = 0.0;
     }
+    const double k33 = c.dxt4r[i - 1] * sumx + c.dyt4r[j - 1] * c.cstr[j - 1] * sumy;
+    UV_CYC_STORE(c.K33, IDX, i, k33);
+    // diff_cbt = background + K33 is what isopyc_column stores for this cell; a given diff_cbt (host or device
+    // vmixc) is read instead -- when vmixc runs on the device after isopyc, coef_bv_cell renews this slot
+    const double dcb = c.diff_cbt_given ? c.diff_cbt[q] : c.diff_cbt_bg[q] + k33;
+    cfv[CF_BV] = dcb * c.dzwr[k] * (1.0 - c.aidif);
   }
 #undef IDX
+  if (inner) {
+    double *cfa = (double *)__builtin_assume_aligned(cf, 16);
+    for (int p = 0; p < CF_DPAIRS; ++p) {
+      cfa[2 * ((size_t)p * N3 + q)] = cfv[2 * p];
+      cfa[2 * ((size_t)p * N3 + q) + 1] = cfv[2 * p + 1];
+    }
+  } else {   // row 1 (and a last row, which the kernel does not visit): the north-face slots alone
+    for (int p = CF_AN; p < CF_AN + 5; ++p) cf[CF_IDX(p, q, N3)] = cfv[p];
+  }
 }
 // the vertical-diffusion coefficient alone (after a device vmixc has rewritten diff_cbt)
 UVIC_DEV void coef_bv_cell(const uvic_ctx &c, double *cf, int i, int k, int j) {

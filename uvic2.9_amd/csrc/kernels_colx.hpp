@@ -46,6 +46,27 @@ __device__ __forceinline__ void x_ratio(double fxa, double fxb, double tlo, doub
   rm = fmn(1., mask * (tlo - trmin) / (pminus + UV_EPSLN));
 }
 
+// Division with a shared reciprocal.  The compiler's sequence for x / y in fp64 is: r = v_rcp_f64(y), two Newton steps on r,
+// q = x*r, the residual x - y*q, one correction of q (plus v_div_scale / v_div_fixup, which act only on operands near the
+// ends of the exponent range: not on slopes and tracer differences).  The reciprocal depends on y alone, and the twenty
+// quotients of a cell's isopycnal fluxes have nine denominators between them, most of which a neighbouring lane or the
+// level above has formed already: x_rcp once per denominator, x_div per quotient, the same bits as x / y.
+__device__ __forceinline__ double x_rcp(double y) {
+  double r = __builtin_amdgcn_rcp(y);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double x_div(double x, double y, double r) {
+#ifdef UV_COLX_PLAIN_DIV
+  (void)r;
+  return x / y;
+#else
+  const double q = x * r;
+  return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+#endif
+}
+
 // what the two halves leave for pass B, one plane per local tracer each (views of the FCT work arrays, which the
 // column path does not use for T and S): ADV_Tx, ADV_Tz, the final north-face flux, D
 struct ColxOut {
@@ -226,6 +247,9 @@ __device__ __forceinline__ void colx_dif_wave(const uvic_ctx &c, const ColxOut &
   double dz_c = 0.0, dz_s = 0.0, dz_n = 0.0;
   double dfb_up = stf, dfbi_up = 0.0;     // tracer.F:1060, isopyc.F:1062
   if (kz == 0) dfb_up = btf;              // (face 0 is the bottom face of a land column, tracer.F:1061)
+  // drodz + epsln of the own column with the gradient of the face ABOVE level s, and its reciprocal: at level s+1 this is
+  // what level s formed for its bottom face with alphai, betai of level s+1 (isopyc.h:135-136), so it is handed down
+  double yu_c = al1 * dzT0 + be1 * dzS0 + UV_EPSLN, ru_c = x_rcp(yu_c);
   for (int s = 1; s <= km; ++s) {
     const bool last = (s == km);
     const int sp = last ? km : s + 1;
@@ -257,17 +281,24 @@ __device__ __forceinline__ void colx_dif_wave(const uvic_ctx &c, const ColxOut &
     const double m_e = shfl_e(m_c), mc2_e = shfl_e(mc2);
     const double dx_c = m_e - m_c, dx_d = mc2_e - mc2;            // T(i+1) - T(i) at levels s, s+1
     const double dxw_c = shfl_w(dx_c), dxw_d = shfl_w(dx_d);      // T(i) - T(i-1)
+    // drodz + epsln (isopyc.h:125-136) of the own column below level s, of the north and south columns above and below it,
+    // and their reciprocals; those of the east column are the east lane's own (the same expression on the same operands)
+    const double yd_c = al1 * dzT1 + be1 * dzS1 + UV_EPSLN, rd_c = x_rcp(yd_c);
+    const double yu_n = al_n * dzTn0 + be_n * dzSn0 + UV_EPSLN, ru_n = x_rcp(yu_n);
+    const double yd_n = al_n * dzTn1 + be_n * dzSn1 + UV_EPSLN, rd_n = x_rcp(yd_n);
+    const double yu_s = al_s * dzTs0 + be_s * dzSs0 + UV_EPSLN, ru_s = x_rcp(yu_s);
+    const double yd_s = al_s * dzTs1 + be_s * dzSs1 + UV_EPSLN, rd_s = x_rcp(yd_s);
+    const double yu_e = shfl_e(yu_c), ru_e = shfl_e(ru_c), yd_e = shfl_e(yd_c), rd_e = shfl_e(rd_c);
     // ---- east face: tracer.F:930-942, isopyc.F:953-1002 -------------------------------------------------
     double dfe;
     {
       const double al_e = shfl_e(al1), be_e = shfl_e(be1);
-      const double dzT0e = shfl_e(dzT0), dzS0e = shfl_e(dzS0), dzT1e = shfl_e(dzT1), dzS1e = shfl_e(dzS1);
       const double dro_x0 = al1 * dxT1 + be1 * dxS1, dro_x1 = al_e * dxT1 + be_e * dxS1;
       double sumz = 0.0;
-      sumz = sumz - aez[0] * dz_c * dro_x0 / (al1 * dzT0 + be1 * dzS0 + UV_EPSLN);
-      sumz = sumz - aez[1] * dze_up * dro_x1 / (al_e * dzT0e + be_e * dzS0e + UV_EPSLN);
-      sumz = sumz - aez[2] * dz_dn * dro_x0 / (al1 * dzT1 + be1 * dzS1 + UV_EPSLN);
-      sumz = sumz - aez[3] * dze_dn * dro_x1 / (al_e * dzT1e + be_e * dzS1e + UV_EPSLN);
+      sumz = sumz - x_div(aez[0] * dz_c * dro_x0, yu_c, ru_c);
+      sumz = sumz - x_div(aez[1] * dze_up * dro_x1, yu_e, ru_e);
+      sumz = sumz - x_div(aez[2] * dz_dn * dro_x0, yd_c, rd_c);
+      sumz = sumz - x_div(aez[3] * dze_dn * dro_x1, yd_e, rd_e);
       const double flux_x = dzt4r * sumz;
       dfe = bg_e * dx_c + k11 * cstdxur * dx_c + flux_x;
     }
@@ -279,10 +310,10 @@ __device__ __forceinline__ void colx_dif_wave(const uvic_ctx &c, const ColxOut &
       const double dT = mn1 - m_c;
       const double dro_y0 = al1 * dyT1 + be1 * dyS1, dro_y1 = al_n * dyT1 + be_n * dyS1;
       double sumz = 0.0;
-      sumz = sumz - anz[0] * dz_c * dro_y0 / (al1 * dzT0 + be1 * dzS0 + UV_EPSLN);
-      sumz = sumz - anz[1] * dz_n * dro_y1 / (al_n * dzTn0 + be_n * dzSn0 + UV_EPSLN);
-      sumz = sumz - anz[2] * dz_dn * dro_y0 / (al1 * dzT1 + be1 * dzS1 + UV_EPSLN);
-      sumz = sumz - anz[3] * dzn_dn * dro_y1 / (al_n * dzTn1 + be_n * dzSn1 + UV_EPSLN);
+      sumz = sumz - x_div(anz[0] * dz_c * dro_y0, yu_c, ru_c);
+      sumz = sumz - x_div(anz[1] * dz_n * dro_y1, yu_n, ru_n);
+      sumz = sumz - x_div(anz[2] * dz_dn * dro_y0, yd_c, rd_c);
+      sumz = sumz - x_div(anz[3] * dzn_dn * dro_y1, yd_n, rd_n);
       const double flux_y = csu_n * dzt4r * sumz;
       dfn_n = bg_n * dT + k22n * csu_dyur_n * dT + flux_y;
     }
@@ -290,10 +321,10 @@ __device__ __forceinline__ void colx_dif_wave(const uvic_ctx &c, const ColxOut &
       const double dT = m_c - ms1;
       const double dro_y0 = al_s * dyTs1 + be_s * dySs1, dro_y1 = al1 * dyTs1 + be1 * dySs1;
       double sumz = 0.0;
-      sumz = sumz - asz[0] * dz_s * dro_y0 / (al_s * dzTs0 + be_s * dzSs0 + UV_EPSLN);
-      sumz = sumz - asz[1] * dz_c * dro_y1 / (al1 * dzT0 + be1 * dzS0 + UV_EPSLN);
-      sumz = sumz - asz[2] * dzs_dn * dro_y0 / (al_s * dzTs1 + be_s * dzSs1 + UV_EPSLN);
-      sumz = sumz - asz[3] * dz_dn * dro_y1 / (al1 * dzT1 + be1 * dzS1 + UV_EPSLN);
+      sumz = sumz - x_div(asz[0] * dz_s * dro_y0, yu_s, ru_s);
+      sumz = sumz - x_div(asz[1] * dz_c * dro_y1, yu_c, ru_c);
+      sumz = sumz - x_div(asz[2] * dzs_dn * dro_y0, yd_s, rd_s);
+      sumz = sumz - x_div(asz[3] * dz_dn * dro_y1, yd_c, rd_c);
       const double flux_y = csu_s * dzt4r * sumz;
       dfn_s = bg_s * dT + k22s * csu_dyur_s * dT + flux_y;
     }
@@ -304,18 +335,19 @@ __device__ __forceinline__ void colx_dif_wave(const uvic_ctx &c, const ColxOut &
     if (!last) {
       dfb = dcb * t_dzwr.at(s - 1) * (m_c - mc2);
       const double dxTw1 = shfl_w(dxT1), dxSw1 = shfl_w(dxS1), dxTw2 = shfl_w(dxT2), dxSw2 = shfl_w(dxS2);
-      const double den0 = al1 * dzT1 + be1 * dzS1 + UV_EPSLN, den1 = al2 * dzT1 + be2 * dzS1 + UV_EPSLN;
+      const double den1 = al2 * dzT1 + be2 * dzS1 + UV_EPSLN, rcp1 = x_rcp(den1);
       double sumx = 0.0;
-      sumx = sumx - abx[0] * cstr_j * dxw_c * (al1 * dxTw1 + be1 * dxSw1) / den0;     // ip = 0, kr = 0
-      sumx = sumx - abx[2] * cstr_j * dxw_d * (al2 * dxTw2 + be2 * dxSw2) / den1;     // ip = 0, kr = 1
-      sumx = sumx - abx[1] * cstr_j * dx_c * (al1 * dxT1 + be1 * dxS1) / den0;        // ip = 1, kr = 0
-      sumx = sumx - abx[3] * cstr_j * dx_d * (al2 * dxT2 + be2 * dxS2) / den1;        // ip = 1, kr = 1
+      sumx = sumx - x_div(abx[0] * cstr_j * dxw_c * (al1 * dxTw1 + be1 * dxSw1), yd_c, rd_c);     // ip = 0, kr = 0
+      sumx = sumx - x_div(abx[2] * cstr_j * dxw_d * (al2 * dxTw2 + be2 * dxSw2), den1, rcp1);     // ip = 0, kr = 1
+      sumx = sumx - x_div(abx[1] * cstr_j * dx_c * (al1 * dxT1 + be1 * dxS1), yd_c, rd_c);        // ip = 1, kr = 0
+      sumx = sumx - x_div(abx[3] * cstr_j * dx_d * (al2 * dxT2 + be2 * dxS2), den1, rcp1);        // ip = 1, kr = 1
       double sumy = 0.0;
-      sumy = sumy - aby[0] * csu_s * (m_c - ms1) * (al1 * dyTs1 + be1 * dySs1) / den0;   // jq = 0, kr = 0
-      sumy = sumy - aby[2] * csu_s * (mc2 - ms2) * (al2 * dyTs2 + be2 * dySs2) / den1;   // jq = 0, kr = 1
-      sumy = sumy - aby[1] * csu_n * (mn1 - m_c) * (al1 * dyT1 + be1 * dyS1) / den0;     // jq = 1, kr = 0
-      sumy = sumy - aby[3] * csu_n * (mn2 - mc2) * (al2 * dyT2 + be2 * dyS2) / den1;     // jq = 1, kr = 1
+      sumy = sumy - x_div(aby[0] * csu_s * (m_c - ms1) * (al1 * dyTs1 + be1 * dySs1), yd_c, rd_c);   // jq = 0, kr = 0
+      sumy = sumy - x_div(aby[2] * csu_s * (mc2 - ms2) * (al2 * dyTs2 + be2 * dySs2), den1, rcp1);   // jq = 0, kr = 1
+      sumy = sumy - x_div(aby[1] * csu_n * (mn1 - m_c) * (al1 * dyT1 + be1 * dyS1), yd_c, rd_c);     // jq = 1, kr = 0
+      sumy = sumy - x_div(aby[3] * csu_n * (mn2 - mc2) * (al2 * dyT2 + be2 * dyS2), den1, rcp1);     // jq = 1, kr = 1
       dfbi = dxt4r * sumx + dyt4r_cstr * sumy;
+      yu_c = den1; ru_c = rcp1;   // the own column's drodz above level s+1
     }
     if (s == kz) dfb = btf;   // tracer.F:1061 (after the interior values are formed)
     const double DIFF_Tz = (dfb_up - dfb) * ddztr * aidif1 + (dfbi_up - dfbi) * ddztr;

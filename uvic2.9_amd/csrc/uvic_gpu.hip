@@ -926,6 +926,10 @@ static void bind_ctx(uvic_gpu *h) {
 }
 
 // the t(:,:,:,:,-1:1) slots rotate by pointer; tmask is derived from kmt on upload
+// -- the three sets of T,S-derived fields ---------------------------------------------
+static const int ISO_FIELDS[16] = {UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT, UVIC_F_AI_EZ, UVIC_F_AI_NZ,
+                                   UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33, UVIC_F_ADV_VETISO,
+                                   UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO, UVIC_F_DIFF_CBT};
 static int make_tmask(uvic_gpu *h);
 static void iso_set_adopt(uvic_gpu *h);
 static void iso_set_release(uvic_gpu *h);
@@ -1201,6 +1205,13 @@ static int make_tmask(uvic_gpu *h) {
   HIPCHK(hipStreamSynchronize(h->side2));
   h->prefetch_pending = h->src_from_prefetch = false;
   for (int q = 0; q < 3; ++q) h->iso_set[q].for_step = -1;
+  // what was ocean may be land now: ai_coef_cell leaves land cells alone and counts on zeros there
+  for (int q = 0; q < 3; ++q) {
+    uvic_gpu::IsoSet &S = h->iso_set[q];
+    if (!S.allocated) continue;
+    for (int f = 5; f < 12; ++f) HIPCHK(hipMemsetAsync(S.f[f], 0, (size_t)field_elems(h->d, ISO_FIELDS[f]) * 8, h->stream));   // Ai_*, K11, K22, K33
+    HIPCHK(hipMemsetAsync(S.coef, 0, (size_t)imt * h->d.km * jmt * 16 * CF_PAIRS, h->stream));
+  }
   (void)hipFree(h->wet_dev);
   h->wet_dev = nullptr;
   HIPCHK(hipMalloc((void **)&h->wet_dev, (wet.size() + 1) * 4));
@@ -1491,10 +1502,6 @@ extern "C" int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int
   return 0;
 }
 
-// -- the three sets of T,S-derived fields ---------------------------------------------
-static const int ISO_FIELDS[16] = {UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT, UVIC_F_AI_EZ, UVIC_F_AI_NZ,
-                                   UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33, UVIC_F_ADV_VETISO,
-                                   UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO, UVIC_F_DIFF_CBT};
 static void iso_set_adopt(uvic_gpu *h) {   // uvic_gpu_create: the buffers just allocated are set 0
   uvic_gpu::IsoSet &S = h->iso_set[0];
   for (int q = 0; q < 16; ++q) S.f[q] = h->buf[ISO_FIELDS[q]];
