@@ -230,11 +230,22 @@ void *uvic_gpu_field_devptr(uvic_gpu *h, int field);
 void *uvic_gpu_stream(uvic_gpu *h); /* hipStream_t the kernels are launched on */
 
 int uvic_gpu_set_params(uvic_gpu *h, const uvic_params *p);
-/* arithmetic of the transport kernels: 1 = every expression in the reference's order
- * (bit-identical to the reference Fortran built without FMA contraction);
- * 0 (default; env UVIC_EXACT overrides at create) = isopycnal coefficients folded once
- * per step, agreement with the reference to rounding (<= 1e-12 relative, tests) */
+/* arithmetic of the transport kernels (env UVIC_EXACT names the mode at create):
+ *   0 (default): T and S -- on whose bits every convective adjustment is decided, convect.F:189-255 -- in the
+ *      reference's order of operations (bit-identical to the reference Fortran built without FMA contraction:
+ *      tracer_adv_flx.F:500-999, isopyc.F:953-1108, invtri.F), the other tracers with the isopycnal coefficients
+ *      folded once per step (agreement to rounding: <= 1e-13 relative after one step, <= 1e-12 after 100, tests);
+ *   1: every tracer in the reference's order of operations (bit-identical);
+ *   2: every tracer through the folded column kernels (T and S then agree to rounding only);
+ *   3: as 0 with T and S through the row kernels instead of the exact column kernels (cross-check). */
 int uvic_gpu_set_exact(uvic_gpu *h, int exact);
+/* cross-check and tuning switches for tests and tools; the defaults are what the library is measured with.
+ *   "nchunk" n: longitude chunks of the row kernels (0 = automatic);  "mobi_generic" 1: option set C through the
+ *   general MOBI column kernel (call before uvic_gpu_set_mobi_opt);  "mobi_team" 0: one thread per column instead
+ *   of four-wave teams;  "convect_onepass" 1: convct2 (convect.F:99-311) as one kernel over all tracers;
+ *   "mobi_streams" 1: every look-ahead MOBI chain on one side stream.  Non-zero status for an unknown name.
+ * The shipped library reads no other environment variable than UVIC_EXACT. */
+int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value);
 /* work decomposition: this instance computes tracers n0+1..n0+nt_local and rows
  * js..je (1-based, inclusive); defaults: all tracers, rows 2..jmt-1 */
 int uvic_gpu_set_shard(uvic_gpu *h, int n0, int nt_local, int js, int je);

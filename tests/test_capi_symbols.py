@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 20
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/uvic_gpu.h but not exported"
-    assert lib.uvic_gpu_abi_version() == 9
+    assert lib.uvic_gpu_abi_version() == 10
 
 
 def test_field_table_matches_header():
@@ -35,3 +35,17 @@ def test_product_has_no_cpu_path(monkeypatch):
     monkeypatch.setattr(capi, "_lib", None)
     with pytest.raises(capi.UvicGpuError):
         capi.load()
+
+
+def test_shipped_library_reads_one_environment_variable():
+    """Measurement switches live in the experiments build (-DUVIC_EXPERIMENTS) only: the shipped library names no
+    environment variable but UVIC_EXACT (the Fortran overlay's switch), so no UVIC_* setting can change its results or
+    its schedule; cross-check paths are reached through uvic_gpu_set_option."""
+    lib_path = ROOT / "uvic2.9_amd" / "csrc" / "libuvic_gpu.so"
+    if not lib_path.exists():
+        import __graft_entry__ as ge
+        ge.build()
+    blob = lib_path.read_bytes()
+    names = set(m.decode() for m in re.findall(rb"UVIC_[A-Z0-9_]{3,}", blob))
+    names -= {n for n in names if n.startswith("UVIC_F_")}          # field names in error messages
+    assert names <= {"UVIC_EXACT"}, sorted(names)

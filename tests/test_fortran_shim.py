@@ -233,6 +233,11 @@ def test_overlay_clinic_matches_reference_clinic(cfg, dims, resident, monkeypatc
     prepare(ref)
     shim = refdriver.RefOcean(oc, shim=True)
     prepare(shim)
+    # before `tracer` has made the device instance (a run that opens with an Euler backward step or a diagnostic step, on
+    # which the tracer overlay falls back) the clinic overlay hands the step to the reference routine as well
+    want_u, want_zu, _ = ref.clinic()
+    got_u, got_zu, _ = shim.clinic()
+    assert np.array_equal(got_u, want_u) and np.array_equal(got_zu, want_zu)
     shim.step()                      # isopyc, "+K33", tracer (overlay): creates the device instance, sends adv_v?t
     for itt, (osegs, osege) in enumerate(((1, 0), (0, 0), (0, 1))):
         for R in (ref, shim):

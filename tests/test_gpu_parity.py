@@ -105,14 +105,14 @@ def test_twenty_steps_match_golden_run_p2():
     m.close()
 
 
-@pytest.mark.parametrize("nchunk", ["1", "3"])
-def test_longitude_chunking_is_invisible(nchunk, monkeypatch):
-    monkeypatch.setenv("UVIC_NCHUNK", nchunk)
+@pytest.mark.parametrize("nchunk", [1, 3])
+def test_longitude_chunking_is_invisible(nchunk):
     oc = synthetic.make_ocean(performance_set(8), 102, 102, 19)
     to, so, c = synthetic.load_eos(19)
     src = _rand_src(oc)
     orc = oracle_c.Oracle(oc, to=to, so=so, c=c, src=src)
     m = _model(oc, to, so, c, src=src)
+    m.set_option("nchunk", nchunk)
     orc.isopyc(); orc.add_k33(); m.isopyc()
     want = orc.transport()
     m.transport(); m.convect()

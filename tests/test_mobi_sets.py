@@ -145,17 +145,16 @@ def test_gpu_sources_of_the_other_option_sets_vs_oracle(cfg, dims):
 
 
 @pytest.mark.gpu
-def test_gpu_general_kernel_with_the_flags_of_set_c_vs_the_set_c_oracle(monkeypatch):
-    """The general kernel forced onto option set C (UVIC_MOBI_GENERIC=1) against the oracle that is pinned hardest."""
+def test_gpu_general_kernel_with_the_flags_of_set_c_vs_the_set_c_oracle():
+    """The general kernel forced onto option set C (set_option "mobi_generic") against the oracle that is pinned hardest."""
     from uvic29_amd.tracer import TracerModel
-    monkeypatch.setenv("UVIC_MOBI_GENERIC", "1")
     oc = synthetic.make_ocean("c30", 14, 14, 6)
     prm = pm.load_table("c30", 6)
     to, so, c = synthetic.load_eos(6)
     want = mobi_c.mobi_sources(oc, prm, oc.t_taum1, 2 * oc.params.dtts)
     m = TracerModel(14, 14, 6, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
     m.load_ocean(oc, to, so, c)
-    m.set_mobi(oc)
+    m.set_mobi(oc, generic=True)
     m.mobi()
     got = m.download("src")
     for s, name in enumerate(oc.cfg.sources):

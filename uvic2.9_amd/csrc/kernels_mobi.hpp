@@ -1146,7 +1146,7 @@ static inline int mobi_bind(int imt, int jmt, int km, const uvic_mobi_params *hp
   mobi_set_work(dev, st->work, imt, jmt, km);
   dev->pi = hf->pi; dev->radian = hf->radian; dev->relyr = hf->relyr; dev->co2ccn = hf->co2ccn;
   dev->carb_shared = 1;
-  if (const char *e = getenv("UVIC_CARB_SHARED")) dev->carb_shared = atoi(e) != 0;
+
   return 0;
 }
 #endif

@@ -50,7 +50,7 @@ typedef struct uvic_ctx {
   double *tot_b;                                                  /* (imt,km+1,jmt) */
   double *adv_x, *adv_z;                                          /* ADV_Tx, ADV_Tz (imt,km,jmt,nt) */
   double *RpY, *RmY;                                              /* y-limiter ratios (imt,km,jmt,nt) */
-  double *Rpm;                                                    /* the same as pairs (2,imt,km,jmt,nt): column kernels */
+  double *fny;                                                    /* column kernels: HALF of the final limited flux through the north face (imt,km,jmt,nt) */
   /* convection: mixed segments found from T,S by convect_ts_column, applied to the other
    * tracers by convect_apply_cell.  cv_nseg (imt,jmt); cv_kt, cv_kb, cv_z (imt,km,jmt) */
   int *cv_nseg, *cv_kt, *cv_kb;

@@ -30,6 +30,17 @@
 #include "uvic_ctx.h"
 
 using namespace uvic;
+// Measurement switches read from the environment exist in the experiments build only (-DUVIC_EXPERIMENTS, tools/): the
+// shipped library reads UVIC_EXACT (the Fortran overlay's one switch) and nothing else; tests and tools
+// reach its cross-check paths through uvic_gpu_set_option.
+static const char *uv_env(const char *name) {
+#ifdef UVIC_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 #define UV_STR_(x) #x
 #define UV_STR(x) UV_STR_(x)
 
@@ -241,7 +252,6 @@ __global__ void __launch_bounds__(256) k_coef_bv(const uvic_ctx c, double *cf) {
   if (j > c.jmt - 1 || i < 2 || i > c.imt - 1 || SLAB_OUT(c, j)) return;
   coef_bv_cell(c, cf, i, k, j);
 }
-// NTR tracers per lane (kernels_col.hpp); g.total counts waves = (waves of the lane map) x ceil(nt_local / NTR)
 // The total advective velocities adv_v?t + adv_v?tiso are formed by the isopyc kernels.  When those ran a step ahead and the
 // host has since uploaded this step's adv_vet/vnt/vbt (the Fortran overlay does, every step), the sums are formed again
 // from the new velocities and the GM velocities computed ahead: the same additions, element by element.
@@ -263,96 +273,43 @@ __global__ void __launch_bounds__(256) k_tot_vel(const uvic_ctx c, double *cf) {
   }
   if (gid < NF) c.tot_b[gid] = c.adv_vbt[gid] + c.adv_vbtiso[gid];
 }
-template <int NTR, int PART, bool AHEAD = false, bool YFIN = false>
-__device__ __forceinline__ void colfct_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g) {
-  const int nblk = (g.total + 3) / 4;
-  const int blk = xcd_remap(blockIdx.x, nblk);
-  int code, n1[NTR];
-  bool live[NTR];
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);  // wave-uniform: the tracers and the wave of the lane map live in scalar registers
-  if (blk >= nblk || !col_decode<NTR>(c, g, blk * 4 + wv, code, n1, live)) return;
-  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colfct_wave<NTR, PART, AHEAD, false, YFIN>(c, cf, S, code, n1, live);
-}
-__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
-// the pass as two sweeps, four waves per SIMD each: diffusive fluxes first (S), then the FCT advection (R+-Y, S)
-__global__ void __launch_bounds__(256) k_colfct_dif(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_DIF>(c, cf, S, g); }
-__global__ void __launch_bounds__(256) k_colfct_adv(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ADV>(c, cf, S, g); }
-// the four waves of a workgroup share the coefficient pairs of a level through LDS: they are four tracers of the same lanes
-// (g.total counts waves = waves of the lane map x the tracer count rounded up to a multiple of four; a wave beyond the
-// launch's tracers stands in for the first one, brings its share of the pairs and stores nothing)
-template <bool AHEAD, bool YFIN = false>
-__device__ __forceinline__ void colfct_sh_body(const uvic_ctx &c, const double *cf, double *S, const ColGrid &g, double *lds) {
+// pass A of the bulk launch: the four waves of a workgroup are four tracers of the same 64 lanes and share the coefficient and
+// velocity pairs of a level through LDS (g.total counts waves = waves of the lane map x the tracer count rounded up to a
+// multiple of four; a wave beyond the launch's tracers stands in for the first one, brings its share of the pairs and
+// stores nothing)
+__global__ void __launch_bounds__(256) k_colfct(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const int nblk = g.total / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
   if (blk >= nblk) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
   const int ngrp = (c.nt_local + 3) / 4;              // workgroups per wave of the lane map
   const int nl = (blk % ngrp) * 4 + wv;
-  int n1[1] = {c.n0 + (nl < c.nt_local ? nl : 0) + 1};
-  bool live[1] = {nl < c.nt_local};
   const int code = g.lanes[(size_t)(blk / ngrp) * 64 + threadIdx.x];
-  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
-  colfct_wave<1, PART_ALL, AHEAD, true, YFIN>(c, cf, S, code, n1, live, lds, wv);
+  colfct_wave<true>(c, cf, S, code, c.n0 + (nl < c.nt_local ? nl : 0) + 1, nl < c.nt_local, lds, wv);
 }
-__global__ void __launch_bounds__(256) k_colfct_sh(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  colfct_sh_body<false>(c, cf, S, g, lds);
-}
-// ... and what a wave loads for itself (t of three rows, velocities) one level ahead into a second register set: 239 VGPRs,
-// two waves on a SIMD, neither of which waits for memory inside a level
-__global__ void __launch_bounds__(256) k_colfct_sha(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  colfct_sh_body<true>(c, cf, S, g, lds);
-}
-// the forms that leave the final y flux of the north face to pass B instead of the limiter ratios (kernels_col.hpp: YFIN)
-__global__ void __launch_bounds__(256) k_colfct_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
+// pass A with every load the wave's own (T and S when they go through the column kernels, set_exact(2)): work item =
+// (wave of the lane map, tracer), tracers fastest
+__global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
   if (g.zero_word && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *g.zero_word = 0;   // (a counter a later kernel of the stream wants cleared)
-  colfct_body<1, PART_ALL, false, true>(c, cf, S, g);
-}
-__global__ void __launch_bounds__(256) k_colfct_sh_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  colfct_sh_body<false, true>(c, cf, S, g, lds);
-}
-__global__ void __launch_bounds__(256) k_colfct_sha_y(const uvic_ctx c, const double *cf, double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  colfct_sh_body<true, true>(c, cf, S, g, lds);
-}
-// two tracers per lane: half the waves, shared coefficient and velocity loads, two dependency chains per wave
-__global__ void __launch_bounds__(256) k_colfct2(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<2, PART_ALL>(c, cf, S, g); }
-// the same pass for T and S alone on the side stream: own name, so that a profile tells the two launches apart
-__global__ void __launch_bounds__(256) k_colfct_ts(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL>(c, cf, S, g); }
-#ifdef UV_TS_AHEAD   // measured: the same 100 us in the loop with a level-ahead register set (256 VGPRs): not the memory wait of a level
-__global__ void __launch_bounds__(256) k_colfct_ts_ahead(const uvic_ctx c, const double *cf, double *S, const ColGrid g) { colfct_body<1, PART_ALL, true>(c, cf, S, g); }
-#endif
-template <bool ZG, bool YFIN = false>
-__device__ __forceinline__ void colupd_body(const uvic_ctx &c, const double *S, const ColGrid &g, double *lds) {
-  const int nblk = (g.total + COLUPD_WAVES - 1) / COLUPD_WAVES;
+  const int nblk = (g.total + 3) / 4;
   const int blk = xcd_remap(blockIdx.x, nblk);
-  int code, n1;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.y);
-  if (blk >= nblk || !col_decode_rows(c, g, blk * COLUPD_WAVES + wv, code, n1)) return;
+  const int item = blk * 4 + wv;
+  if (blk >= nblk || item >= g.total) return;
+  const int code = g.lanes[(size_t)(item / c.nt_local) * 64 + threadIdx.x];
   if (c.prio & 2) __builtin_amdgcn_s_setprio(3);   // the short T,S passes: a latency chain others wait for
-  colupd_wave<ZG, YFIN>(c, S, lds + (size_t)wv * (ZG ? 1 : 2) * (c.km + 1) * 64, code, n1, g.fuse_convect);
+  colfct_wave<false>(c, cf, S, code, c.n0 + item % c.nt_local + 1, true);
 }
-__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
+// pass B: one wave per (wave of the pass-B lane map, tracer), the waves of one tracer next to each other (rows ascending), so
+// that rows r-1 and r of the final fluxes a wave reads are its neighbour's centre row
+__global__ void __launch_bounds__(64) k_colupd(const uvic_ctx c, const double *S, const ColGrid g) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  colupd_body<false>(c, S, g, lds);
-}
-// pass B reading the final y fluxes pass A left (YFIN)
-__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_y(const uvic_ctx c, const double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (g.zero_word && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *g.zero_word = 0;
-  colupd_body<false, true>(c, S, g, lds);
-}
-// the same with z(k) parked in t(tau+1) (half the LDS per wave); no fused convective replay
-__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_zg(const uvic_ctx c, const double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  colupd_body<true>(c, S, g, lds);
-}
-__global__ void __launch_bounds__(64 * COLUPD_WAVES) k_colupd_ts(const uvic_ctx c, const double *S, const ColGrid g) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  colupd_body<false>(c, S, g, lds);
+  const int blk = xcd_remap(blockIdx.x, g.total);
+  if (blk >= g.total) return;
+  const int code = g.lanes[(size_t)(blk % g.nwaves) * 64 + threadIdx.x];
+  if (c.prio & 2) __builtin_amdgcn_s_setprio(3);
+  colupd_wave(c, S, lds, code, c.n0 + blk / g.nwaves + 1);
 }
 // Pass B of T and S and the convective walk in one launch: a workgroup is two waves, T and S of the same 64 ocean columns;
 // each solves its column (t(tau+1) stored, and kept in its LDS), then the first wave walks the columns as convect_ts_column
@@ -372,7 +329,7 @@ __global__ void __launch_bounds__(128) k_colupd_conv_ts(const uvic_ctx c, const 
   int code = 0;
   if (blk < nblk) {
     code = g.lanes[(size_t)blk * 64 + threadIdx.x];
-    colupd_wave<false, true>(c, S, lds + (size_t)wv * per_wave, code, c.n0 + wv + 1, 0, true);
+    colupd_wave(c, S, lds + (size_t)wv * per_wave, code, c.n0 + wv + 1, true);
   }
   __syncthreads();
   if (blk >= nblk || wv != 0 || !COL_LANE_OWNED(code)) return;
@@ -753,14 +710,11 @@ struct uvic_gpu {
   double *cv_z;
   bool exact_convect;  // single-kernel convct2 (debug: UVIC_CONVECT_ONEPASS=1)
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
-  double *rpm;      // y-limiter ratios R+, R- as pairs (column kernels)
+  double *fny;      // column kernels: half of the final limited flux through the north face of every cell, per tracer
   bool exact;       // bit-exact row kernels (kernels_fct.hpp) instead of the column path
   bool ts_rows;     // ... through the row kernels of kernels_fct.hpp instead of the exact column kernels (cross-check: set_exact(3))
   bool ts_exact;    // production default: T and S (whose bits decide every convective adjustment) go through the bit-exact kernels, the other tracers through the column kernels
   bool mixing_next_guard = false;
-  bool yfin;        // pass A leaves the final y flux of each row's north face, pass B reads two of them (UVIC_YFIN, default 1)
-  bool b_zglobal;   // pass B parks z(k) in t(tau+1) instead of LDS (UVIC_B_ZGLOBAL, default 1)
-  int a_mode;       // pass A of the bulk launch: 1 = one sweep, 2 = one sweep with two tracers per lane, 3 = two sweeps (UVIC_A_MODE)
   // ocean columns, row by row (WetCols): device list, and where each row starts in it (host, size jmt+2)
   int *wet_dev;
   std::vector<int> wet_row_start;
@@ -800,7 +754,8 @@ struct uvic_gpu {
   double *flt_mats;
   int flt_nitems, flt_threads;
   double mobi_dtnpzd;
-  bool mobi_team;   // four-wave team kernel (default) or one thread per column (UVIC_MOBI_TEAM=0)
+  bool mobi_team;   // four-wave team kernel (default) or one thread per column (set_option "mobi_team" 0)
+  bool mobi_generic;   // set_option "mobi_generic": option set C through the general column kernel as well (cross-check)
   // one-step-ahead source terms on side streams (uvic_gpu_prefetch_sources): two of them, taken in turn, so that
   // the MOBI chain of step n+2 (pre -> team -> post) may start while that of step n+1 is still running
   hipStream_t side_m[2];
@@ -833,8 +788,6 @@ struct uvic_gpu {
   double *sbc_acc;              // device (imt, jmt, sbc_count)
   // what the look-ahead MOBI chain assumed about the step it computed for (checked when that step starts)
   double src_relyr, src_co2ccn, src_c2dtts;
-  bool ts_apply;      // ... and pass B of the other tracers did not replay the mixing: convect_apply follows it (conv_decoupled)
-  bool conv_decoupled;   // pass B of the other tracers does not wait for the T,S chain (UVIC_CONV_DECOUPLED, default 1)
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
   bool ts_no_src;     // itrc(1) = itrc(2) = 0: T and S have no source term (known from the upload of itrc)
   // The T,S-derived fields (mixing tensor, GM velocities, folded coefficients, diff_cbt) exist in three sets: step m
@@ -892,7 +845,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 9; }   // 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_* (O_TMM column-batch source operator); 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 10; }   // 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -922,7 +875,7 @@ static void bind_ctx(uvic_gpu *h) {
   if (h->mixing) c.t_taum1 = c.t_tau;  // forward step: both slots hold tau (updates/09/source/mom/loadmw.F:107-111)
   c.tot_e = h->work[0]; c.tot_n = h->work[1]; c.tot_b = h->work[2];
   c.adv_x = h->work[3]; c.adv_z = h->work[4]; c.RpY = h->work[5]; c.RmY = h->work[6];
-  c.Rpm = h->rpm;
+  c.fny = h->fny;
 }
 
 // the t(:,:,:,:,-1:1) slots rotate by pointer; tmask is derived from kmt on upload
@@ -935,6 +888,46 @@ static void iso_set_adopt(uvic_gpu *h);
 static void iso_set_release(uvic_gpu *h);
 static int use_iso_set(uvic_gpu *h, int s);
 
+// tile geometry of the row kernels (kernels_fct.hpp): the fewest longitude chunks whose tile fits the LDS budget, or `nchunk_forced`
+static int set_tile_geometry(uvic_gpu *h, int nchunk_forced) {
+  const uvic_dims *dims = &h->d;
+  int budget_kb = 150;
+  if (const char *e = uv_env("UVIC_LDS_BUDGET_KB")) budget_kb = atoi(e);
+  h->fct_threads = 1024;
+  if (const char *e = uv_env("UVIC_FCT_THREADS")) h->fct_threads = atoi(e);
+  h->upd_threads = 512;
+  if (const char *e = uv_env("UVIC_UPD_THREADS")) h->upd_threads = atoi(e);
+  int nchunk = 1;
+  for (;; ++nchunk) {
+    const int per = (dims->imt - 2 + nchunk - 1) / nchunk;
+    const int W = per + 4;
+    const size_t need = ((size_t)W * dims->km * 6 + (size_t)W * (dims->km + 1) * 2) * 8;
+    if (need <= (size_t)budget_kb * 1024 || per <= 8) break;
+  }
+  if (nchunk_forced > 0) nchunk = nchunk_forced;
+  h->nchunk = nchunk;
+  const int per = (dims->imt - 2 + nchunk - 1) / nchunk;
+  const int W = per + 4;
+  h->fct_lds = ((size_t)W * dims->km * 6 + (size_t)W * (dims->km + 1) * 2) * 8;
+  h->upd_lds = ((size_t)W * dims->km * 3 + (size_t)W * (dims->km + 1) * 2) * 8;
+  if (h->fct_lds > 160 * 1024) return fail_msg("row kernels: the tile does not fit LDS with this many longitude chunks");
+  HIPCHK(hipFuncSetAttribute((const void *)k_fct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fct_lds));
+  HIPCHK(hipFuncSetAttribute((const void *)k_update_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->upd_lds));
+  return 0;
+}
+extern "C" int uvic_gpu_sync(uvic_gpu *h);
+// cross-check and tuning switches for tests and tools (the defaults are what the library is measured with)
+extern "C" int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value) {
+  if (!h || !name) return fail_msg("uvic_gpu_set_option: null argument");
+  if (int rc = uvic_gpu_sync(h)) return rc;
+  const std::string n(name);
+  if (n == "nchunk") return set_tile_geometry(h, value);           // longitude chunks of the row kernels (0: automatic)
+  if (n == "mobi_generic") { h->mobi_generic = value != 0; return 0; }   // option set C through the general MOBI kernel (before set_mobi_opt)
+  if (n == "mobi_team") { h->mobi_team = value != 0; return 0; }         // 0: one thread per column instead of four-wave teams
+  if (n == "convect_onepass") { h->exact_convect = value != 0; return 0; }   // convct2 as one kernel over all tracers
+  if (n == "mobi_streams") { h->mobi_two_streams = value != 1 && h->side_m[1] != h->side_m[0]; return 0; }   // 1: every MOBI chain on the first side stream
+  return fail_msg("uvic_gpu_set_option: unknown option " + n);
+}
 extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device) {
   if (!out || !dims) return fail_msg("uvic_gpu_create: null argument");
   if (dims->imt < 6 || dims->jmt < 6 || dims->km < 2 || dims->nt < 2)
@@ -966,7 +959,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   // 256-N compute units (the mask bits go round the 8 XCDs), which stay free for the side streams.
   {
     int main_cus = 0;
-    if (const char *e = getenv("UVIC_MAIN_CUS")) main_cus = atoi(e);
+    if (const char *e = uv_env("UVIC_MAIN_CUS")) main_cus = atoi(e);
     if (main_cus >= 8 && main_cus < 256) {
       uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int b = 0; b < main_cus; ++b) mask[b / 32] |= 1u << (b % 32);
@@ -977,7 +970,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   }
   h->mobi_flip = 0;
   h->mobi_two_streams = true;
-  if (const char *e = getenv("UVIC_MOBI_STREAMS")) h->mobi_two_streams = atoi(e) != 1;
+  if (const char *e = uv_env("UVIC_MOBI_STREAMS")) h->mobi_two_streams = atoi(e) != 1;
   HIPCHK(hipStreamCreateWithFlags(&h->side_m[0], hipStreamNonBlocking));
   if (h->mobi_two_streams) HIPCHK(hipStreamCreateWithFlags(&h->side_m[1], hipStreamNonBlocking));
   else h->side_m[1] = h->side_m[0];
@@ -985,13 +978,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->side_ts = h->side2;   // a stream of their own did not pay: the device has four hardware queues
   HIPCHK(hipEventCreateWithFlags(&h->ev_fct_done, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_done, hipEventDisableTiming));
-  h->ts_apply = false;
   h->host_sync = true; h->ts_host = nullptr; h->ts_host_queued = false;
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_host, hipEventDisableTiming));
   h->sbc_count = 0; h->sbc_tracer = nullptr; h->sbc_acc = nullptr;
   h->src_relyr = h->src_co2ccn = 0.0;
-  h->conv_decoupled = true;
-  if (const char *e = getenv("UVIC_CONV_DECOUPLED")) h->conv_decoupled = atoi(e) != 0;
   h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false; h->unmix_at_rotate = false;
   for (int q = 0; q < 3; ++q) {
     memset(&h->iso_set[q], 0, sizeof h->iso_set[q]);
@@ -1012,7 +1002,8 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->end_ready = h->end_pending = false;
   h->src_alt = nullptr;
   h->mobi_team = true;
-  if (const char *e = getenv("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
+  h->mobi_generic = false;
+  if (const char *e = uv_env("UVIC_MOBI_TEAM")) h->mobi_team = atoi(e) != 0;
   h->prefetch_pending = h->src_from_prefetch = h->mixing = false;
   for (int f = 0; f < UVIC_F_COUNT; ++f) {
     const size_t bytes = (size_t)field_elems(h->d, f) * elem_size(f);
@@ -1037,10 +1028,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
     HIPCHK(hipMalloc((void **)&h->cv_z, N3 * 8));
     HIPCHK(hipMemset(h->cv_z, 0, N3 * 8));
     h->exact_convect = false;
-    if (const char *e = getenv("UVIC_CONVECT_ONEPASS")) h->exact_convect = atoi(e) != 0;
+    if (const char *e = uv_env("UVIC_CONVECT_ONEPASS")) h->exact_convect = atoi(e) != 0;
   }
-  HIPCHK(hipMalloc((void **)&h->rpm, N3 * 16 * (size_t)dims->nt));
-  HIPCHK(hipMemset(h->rpm, 0, N3 * 16 * (size_t)dims->nt));
+  HIPCHK(hipMalloc((void **)&h->fny, N3 * 8 * (size_t)dims->nt));
+  HIPCHK(hipMemset(h->fny, 0, N3 * 8 * (size_t)dims->nt));
   HIPCHK(hipMalloc((void **)&h->coef, N3 * 16 * CF_PAIRS));
   HIPCHK(hipMemset(h->coef, 0, N3 * 16 * CF_PAIRS));
   iso_set_adopt(h);   // what was just allocated is set 0
@@ -1048,17 +1039,6 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->ts_exact = true;
   h->ts_rows = false;
   if (const char *e = getenv("UVIC_EXACT")) { h->exact = atoi(e) == 1; h->ts_exact = atoi(e) != 2; }
-  h->b_zglobal = false;   // measured: 91 us alone against 80 with both arrays in LDS (the pass is bound by memory traffic, not by occupancy)
-  if (const char *e = getenv("UVIC_B_ZGLOBAL")) h->b_zglobal = atoi(e) != 0;
-  h->yfin = true;
-  if (const char *e = getenv("UVIC_YFIN")) h->yfin = atoi(e) != 0;
-  // measured (102x102x19, alone, 30 tracers): 1 = one sweep 131 us, 2 = two tracers per lane 116, 3 = two sweeps 63 + 79 (in the
-  // loop these three tie), 4 = one sweep with the coefficient pairs shared through LDS by the four waves of a workgroup:
-  // 100 us for 28 tracers against 117, 151 against 169 in the loop; 5 = 4 with the wave's own loads one level ahead (239 VGPRs,
-  // two waves on a SIMD): 88 us, 135 in the loop
-  h->a_mode = 5;
-  if (const char *e = getenv("UVIC_A_MODE")) h->a_mode = atoi(e);
-  if (h->a_mode < 1 || h->a_mode > 5) h->a_mode = 1;
   // tmask lives in its own buffer (derived data)
   double *tmask;
   HIPCHK(hipMalloc((void **)&tmask, N3 * 8));
@@ -1069,39 +1049,13 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   bind_ctx(h);
   h->ctx.n0 = 0; h->ctx.nt_local = dims->nt; h->ctx.js = 2; h->ctx.je = dims->jmt - 1;
   h->ctx.c2dtts = 0.0; h->ctx.aidif = 0.5;
-  h->ctx.no_landskip = getenv("UVIC_NO_LANDSKIP") ? 1 : 0;
-  h->ctx.prio = getenv("UVIC_TEAM_PRIO0") ? 1 : 0;
-  if (const char *e = getenv("UVIC_SMALL_PRIO")) h->ctx.prio |= atoi(e) ? 4 : 0;
-  // tile geometry: keep the FCT tile within the LDS budget
-  int budget_kb = 150;
-  if (const char *e = getenv("UVIC_LDS_BUDGET_KB")) budget_kb = atoi(e);
-  h->fct_threads = 1024;
-  if (const char *e = getenv("UVIC_FCT_THREADS")) h->fct_threads = atoi(e);
-  h->upd_threads = 512;
-  if (const char *e = getenv("UVIC_UPD_THREADS")) h->upd_threads = atoi(e);
-  int nchunk = 1;
-  for (;; ++nchunk) {
-    const int per = (dims->imt - 2 + nchunk - 1) / nchunk;
-    const int W = per + 4;
-    const size_t need = ((size_t)W * dims->km * 6 + (size_t)W * (dims->km + 1) * 2) * 8;
-    if (need <= (size_t)budget_kb * 1024 || per <= 8) break;
-  }
-  if (const char *e = getenv("UVIC_NCHUNK")) nchunk = atoi(e);
-  h->nchunk = nchunk;
+  h->ctx.no_landskip = uv_env("UVIC_NO_LANDSKIP") ? 1 : 0;
+  h->ctx.prio = uv_env("UVIC_TEAM_PRIO0") ? 1 : 0;
+  if (const char *e = uv_env("UVIC_SMALL_PRIO")) h->ctx.prio |= atoi(e) ? 4 : 0;
+  if (int rc = set_tile_geometry(h, 0)) return rc;
   {
-    const int per = (dims->imt - 2 + nchunk - 1) / nchunk;
-    const int W = per + 4;
-    h->fct_lds = ((size_t)W * dims->km * 6 + (size_t)W * (dims->km + 1) * 2) * 8;
-    h->upd_lds = ((size_t)W * dims->km * 3 + (size_t)W * (dims->km + 1) * 2) * 8;
-  }
-  HIPCHK(hipFuncSetAttribute((const void *)k_fct_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fct_lds));
-  HIPCHK(hipFuncSetAttribute((const void *)k_update_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->upd_lds));
-  {
-    const size_t colupd_lds = (size_t)COLUPD_WAVES * 2 * (h->d.km + 1) * 64 * 8;
-    if (colupd_lds > 64 * 1024) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_colupd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
-      HIPCHK(hipFuncSetAttribute((const void *)k_colupd_ts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
-    }
+    const size_t colupd_lds = (size_t)2 * (h->d.km + 1) * 64 * 8;
+    if (colupd_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void *)k_colupd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)colupd_lds));
   }
   // Touch every stream once now: a HIP stream gets its hardware queue when it is first used, and the four of this
   // library must get the device's four queues before anything else in the process (RCCL's own streams, created with the
@@ -1119,17 +1073,20 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
 extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  (void)uvic_gpu_sync(h);   // every stream, the momentum side stream included: it may still be copying into a pinned host range
   iso_set_release(h);   // the three sets of T,S-derived fields; clears their views in buf[], work[0..2], coef
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
-  (void)hipFree(h->rpm);
+  (void)hipFree(h->fny);
   (void)hipFree(h->wet_dev);
   (void)hipFree(h->lanes_dev);
   for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
+  (void)hipFree(h->fltu_items);
+  (void)hipFree(h->fltu_mats);
+  (void)hipFree(h->fltu_rows);
   for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
   (void)hipFree(h->cv_z);
   (void)hipFree(h->cv_list);
@@ -1217,8 +1174,8 @@ static int make_tmask(uvic_gpu *h) {
   HIPCHK(hipMalloc((void **)&h->wet_dev, (wet.size() + 1) * 4));
   if (!wet.empty()) HIPCHK(hipMemcpy(h->wet_dev, wet.data(), wet.size() * 4, hipMemcpyHostToDevice));
   h->src_zeroed.clear();   // what was ocean may be land now
-  // all-land waves of pass A leave R+- alone
-  HIPCHK(hipMemsetAsync(h->rpm, 0, (size_t)imt * h->d.km * jmt * 16 * (size_t)h->d.nt, h->stream));
+  // pass A stores the flux of ocean cells only
+  HIPCHK(hipMemsetAsync(h->fny, 0, (size_t)imt * h->d.km * jmt * 8 * (size_t)h->d.nt, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1241,7 +1198,7 @@ static int build_col_lanes(uvic_gpu *h) {
   std::vector<int> la, lb;
   // (with the final y flux formed in pass A, the pass needs rows js-1..je: the flux through the north face of row je is
   // formed there from t of rows up to je+2, which the 2-row halo holds; else R+-Y of row je+1 is needed as well)
-  const int ra0 = c.js - 1 < 2 ? 2 : c.js - 1, ra1 = h->yfin ? std::min(c.je, jmt - 1) : (c.je + 1 > jmt - 1 ? jmt - 1 : c.je + 1);
+  const int ra0 = c.js - 1 < 2 ? 2 : c.js - 1, ra1 = std::min(c.je, jmt - 1);
   for (int r = ra0; r <= ra1; ++r) {
     // runs of this row as (start x, length), cyclic
     std::vector<std::pair<int, int>> runs;
@@ -1586,8 +1543,6 @@ static unsigned col_blocks(const uvic_gpu *h, int bs) {
 // the T,S-derived fields of a step (mixing tensor, GM velocities, folded coefficients): ctx `c` says what is read
 // (t_taum1) and where the products go; `sid` 0 = main stream, 2 = the isopyc side stream
 static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStream_t st, int sid) {
-  static const bool dbg_skip = getenv("UVIC_DBG_SKIP_ISO") != nullptr;   // timing experiment only: results are wrong
-  if (dbg_skip && sid != 0) return 0;
   mark_on(h, "begin", sid);
   hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
   mark_on(h, "isopyc_elements", sid);
@@ -1689,180 +1644,139 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   const uvic_ctx &c = h->ctx;
   if (c.nt_local <= 0) return 0;
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
-  if (!h->exact) {  // lane-per-column path
-    if (int rc = build_col_lanes(h)) return rc;
-    ColGrid a, b;
-    a.lanes = h->lanes_dev; a.nwaves = h->nwaves_a; a.total = a.nwaves * c.nt_local;
-    b.lanes = h->lanes_dev + (size_t)h->nwaves_a * 64; b.nwaves = h->nwaves_b; b.total = b.nwaves * c.nt_local;
-    double *S = h->work[3];
-    a.fuse_convect = b.fuse_convect = 0;
-    a.zero_word = b.zero_word = nullptr;
-    const size_t upd_lds = (size_t)COLUPD_WAVES * 2 * (c.km + 1) * 64 * 8;
-    auto blocks_a = [](const ColGrid &g) { return (unsigned)((((g.total + 3) / 4 + 7) / 8) * 8); };
-    // the bulk launch of pass A: a_ntr tracers per lane (g.total counts waves)
-    auto blocks_b = [](const ColGrid &g) { return (unsigned)((((g.total + COLUPD_WAVES - 1) / COLUPD_WAVES + 7) / 8) * 8); };
-    auto launch_a = [&](const uvic_ctx &cc, ColGrid g, const double *Sg, hipStream_t st) {
-      const int ntr = h->a_mode == 2 ? 2 : 1;
-      g.total = g.nwaves * ((cc.nt_local + ntr - 1) / ntr);
-      if (g.total <= 0) return;
-      const double *cf = (const double *)h->coef;
-      if (h->a_mode >= 4) {
-        g.total = g.nwaves * ((cc.nt_local + 3) / 4) * 4;
-        const size_t sh_lds = (size_t)2 * COL_SHARE_SLOTS(h->yfin) * 64 * 16;
-        if (h->yfin && h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha_y, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
-        else if (h->yfin) hipLaunchKernelGGL(k_colfct_sh_y, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
-        else if (h->a_mode == 5) hipLaunchKernelGGL(k_colfct_sha, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
-        else hipLaunchKernelGGL(k_colfct_sh, dim3(blocks_a(g)), dim3(64, 4), sh_lds, st, cc, cf, (double *)Sg, g);
-      } else if (h->yfin) {
-        hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
-      } else if (h->a_mode == 2) hipLaunchKernelGGL(k_colfct2, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
-      else if (h->a_mode == 3) {
-        hipLaunchKernelGGL(k_colfct_dif, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
-        mark(h, "colfct_dif");
-        hipLaunchKernelGGL(k_colfct_adv, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
-      } else hipLaunchKernelGGL(k_colfct, dim3(blocks_a(g)), dim3(64, 4), 0, st, cc, cf, (double *)Sg, g);
-    };
-    // pass B of a launch (`ts`: the T,S launch on the side stream, own kernel name for the profiles)
-    auto launch_b = [&](const uvic_ctx &cc, const ColGrid &g, const double *Sg, hipStream_t st, bool ts) {
-      if (g.total <= 0) return;
-      if (h->yfin) hipLaunchKernelGGL(k_colupd_y, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds, st, cc, Sg, g);
-      else if (ts) hipLaunchKernelGGL(k_colupd_ts, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds, st, cc, Sg, g);
-      else if (h->b_zglobal && !g.fuse_convect) hipLaunchKernelGGL(k_colupd_zg, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds / 2, st, cc, Sg, g);
-      else hipLaunchKernelGGL(k_colupd, dim3(blocks_b(g)), dim3(64, COLUPD_WAVES), upd_lds, st, cc, Sg, g);
-    };
-    // T and S first: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both passes and
-    // the walk run on the side stream while the main stream works on the other tracers, whose pass B then finds the
-    // mixed segments ready and replays them itself (no separate convection pass over t(tau+1)).  Not under tracer
-    // sharding, where convection follows the exchange.
-    const bool split = convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 &&
-                       h->ts_no_src;
-    if (split) {
-      // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
-      // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
-      if (h->iso_waited && h->step_begun) {
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
-        h->ts_waited_begin = h->step_no;
-        if (h->iso_set[h->iso_cur].st != h->side_ts)   // (the chain ran on this very stream: nothing to wait for, and a wait packet costs ~6 us)
-          HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
-      } else {
-        HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
-      }
-      uvic_ctx cts = c;
-      cts.nt_local = 2;
-      cts.prio |= 2;
-      ColGrid ats = a, bts = b;
-      ats.total = ats.nwaves * 2;
-      bts.total = bts.nwaves * 2;
-      mark_on(h, "begin", 3);
-      const WetCols w = wet_range(h, c.js, c.je);
-      const size_t cv_lds = (size_t)2 * h->d.km * 64 * 8;
-      // pass B of T,S and the convective walk share a launch when nothing stands between them (the replay fused into pass B
-      // of the others, UVIC_CONV_DECOUPLED=0, also works from the walk's records: same launch)
-      static const bool fuse_env = !getenv("UVIC_TS_FUSE") || atoi(getenv("UVIC_TS_FUSE")) != 0;
-      const bool ts_fuse = !h->ts_exact && fuse_env && h->yfin && ats.total > 0 && bts.total > 0 && w.count > 0 && c.nt_local >= 2;
-      if (ts_fuse) ats.zero_word = h->cv_list;
-      if (h->ts_exact) {
-        // T and S in the reference's own order of operations (kernels_fct.hpp): every convective adjustment is decided on
-        // their bits (convect.F:189-255), and a density comparison of rounding size flips on a 1-ulp difference
-        if (h->ts_rows) {
-          if (int rc = launch_rows(h, cts, h->side_ts, 3, w.count > 0 ? h->cv_list : nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
-          if (w.count > 0)
-            hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
-          mark_on(h, "convect_ts", 3);
-        } else {
-          if (int rc = launch_colx(h, cts, ats, bts, h->side_ts, 3, w.count > 0)) return rc;
-        }
-      } else {
-      if (ats.total > 0 && h->yfin) hipLaunchKernelGGL(k_colfct_y, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
-      else if (ats.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks_a(ats)), dim3(64, 4), 0, h->side_ts, cts, (const double *)h->coef, S, ats);
-      mark_on(h, "colfct_ts", 3);
-      }
-      if (h->ts_exact) {
-      } else if (ts_fuse) {
-        const size_t lds_b = ((size_t)2 * 2 * (c.km + 1) * 64 + (size_t)12 * c.km) * 8;
-        hipLaunchKernelGGL(k_colupd_conv_ts, dim3((unsigned)(((bts.nwaves + 7) / 8) * 8)), dim3(64, 2), lds_b, h->side_ts, cts, (const double *)S, bts, h->cv_list);
-        mark_on(h, "colupd_conv_ts", 3);
-      } else {
-        // (the list counter of the convective walk is cleared by pass B before it: a memset node costs the chain ~10 us)
-        const bool zero_in_b = h->yfin && bts.total > 0;
-        if (zero_in_b) bts.zero_word = h->cv_list;
-        launch_b(cts, bts, (const double *)S, h->side_ts, true);
-        mark_on(h, "colupd_ts", 3);
-        if (!zero_in_b) HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
-        if (w.count > 0)
-          hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), cv_lds + (size_t)12 * h->d.km * 8, h->side_ts, cts, w, h->cv_list);
-        mark_on(h, "convect_ts", 3);
-      }
-      // one barrier packet less on the main stream (~8 us each): the side stream waits for the sources as well before it
-      // signals, and the main stream waits for that one event
-      if (h->src_from_prefetch && !h->conv_decoupled) {
-        HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_src_ready, 0));
-        h->src_from_prefetch = false;
-      }
-      HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
-      if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
-        HIPCHK(hipMemcpyAsync(h->ts_host, c.t_taup1, (size_t)2 * c.imt * c.km * c.jmt * 8, hipMemcpyDeviceToHost, h->side_ts));
-        HIPCHK(hipEventRecord(h->ev_ts_host, h->side_ts));
-        h->ts_host_queued = true;
-      }
-      h->ts_ahead = true;
-      h->ts_apply = h->conv_decoupled;
-      if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
-      // the other tracers on the main stream: work arrays are indexed from the group's first tracer
-      const size_t N3 = (size_t)c.imt * c.km * c.jmt;
-      uvic_ctx cr = c;
-      cr.n0 = 2; cr.nt_local = c.nt - 2;
-      cr.Rpm = c.Rpm + 2 * N3 * 2;
-      ColGrid ar = a, br = b;
-      ar.total = ar.nwaves * cr.nt_local;
-      br.total = br.nwaves * cr.nt_local;
-      br.fuse_convect = h->conv_decoupled ? 0 : 1;
-      if (int rc = land_clean(h, c, h->stream)) return rc;
-      mark(h, "begin");
-      launch_a(cr, ar, S + 2 * N3, h->stream);
-      mark(h, "colfct");
-      if (h->src_from_prefetch) {
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
-        h->src_from_prefetch = false;
-      }
-      static const bool dbg_nowait = getenv("UVIC_DBG_NOWAIT_TS") != nullptr;   // timing experiment only: results are wrong
-      // decoupled: the mixed segments are replayed by convect_apply after this pass (launch_convect), so that the main
-      // stream does not stand still between its two passes while the T,S chain (three short kernels) finishes
-      if (!dbg_nowait && !h->conv_decoupled) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
-      launch_b(cr, br, (const double *)(S + 2 * N3), h->stream, false);
-    } else {
-      if (int rc = land_clean(h, c, h->stream)) return rc;
-      mark(h, "begin");
-      // the local tracers among T and S go through the bit-exact kernels (see above), the others through the column kernels
-      const int n_ts = (h->ts_exact && c.n0 < 2) ? std::min(c.n0 + c.nt_local, 2) - c.n0 : 0;
-      if (n_ts > 0) {
-        uvic_ctx cts = c;
-        cts.nt_local = n_ts;
-        if (h->ts_rows) { if (int rc = launch_rows(h, cts, h->stream, 0, nullptr, "fct_rows_ts", "update_rows_ts")) return rc; }
-        else if (int rc = launch_colx(h, cts, a, b, h->stream, 0, false)) return rc;
-      }
-      const size_t N3 = (size_t)c.imt * c.km * c.jmt;
-      uvic_ctx cr = c;
-      cr.n0 = c.n0 + n_ts; cr.nt_local = c.nt_local - n_ts;
-      cr.Rpm = c.Rpm + (size_t)n_ts * N3 * 2;
-      ColGrid ar = a, br = b;
-      ar.total = ar.nwaves * cr.nt_local;
-      br.total = br.nwaves * cr.nt_local;
-      launch_a(cr, ar, S + (size_t)n_ts * N3, h->stream);
-      mark(h, "colfct");
-      if (h->src_from_prefetch) {
-        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
-        h->src_from_prefetch = false;
-      }
-      launch_b(cr, br, (const double *)(S + (size_t)n_ts * N3), h->stream, false);
-    }
-    mark(h, "colupd");
-    HIPCHK(hipGetLastError());
-    return 0;
+  if (h->exact) {
+    mark(h, "begin");
+    return launch_rows(h, c, h->stream, 0, nullptr, "fct_rows", "update_rows");
   }
-  mark(h, "begin");
-  return launch_rows(h, c, h->stream, 0, nullptr, "fct_rows", "update_rows");
+  // lane-per-column path
+  if (int rc = build_col_lanes(h)) return rc;
+  ColGrid a, b;
+  a.lanes = h->lanes_dev; a.nwaves = h->nwaves_a; a.total = a.nwaves * c.nt_local;
+  b.lanes = h->lanes_dev + (size_t)h->nwaves_a * 64; b.nwaves = h->nwaves_b; b.total = b.nwaves * c.nt_local;
+  a.zero_word = b.zero_word = nullptr;
+  double *S = h->work[3];
+  const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+  const size_t upd_lds = (size_t)2 * (c.km + 1) * 64 * 8;
+  const double *cf = (const double *)h->coef;
+  auto blocks8 = [](int n) { return (unsigned)(((n + 7) / 8) * 8); };
+  // pass A of the bulk launch (the four waves of a workgroup: four tracers of the same lanes; g.total counts waves)
+  auto launch_a = [&](const uvic_ctx &cc, ColGrid g, const double *Sg, hipStream_t st) {
+    g.total = g.nwaves * ((cc.nt_local + 3) / 4) * 4;
+    if (g.total <= 0) return;
+    hipLaunchKernelGGL(k_colfct, dim3(blocks8(g.total / 4)), dim3(64, 4), (size_t)2 * COL_SHARE_SLOTS * 64 * 16, st, cc, cf, (double *)Sg, g);
+  };
+  auto launch_b = [&](const uvic_ctx &cc, const ColGrid &g, const double *Sg, hipStream_t st) {
+    if (g.total <= 0) return;
+    hipLaunchKernelGGL(k_colupd, dim3(blocks8(g.total)), dim3(64), upd_lds, st, cc, Sg, g);
+  };
+  // the tracers of `cc` (T and/or S) through the column kernels on stream `st` (set_exact(2)); `walk`: pass B and the
+  // convective T,S walk in one launch
+  auto launch_ts_columns = [&](const uvic_ctx &cc, hipStream_t st, int sid, bool walk) {
+    ColGrid ga = a, gb = b;
+    ga.total = ga.nwaves * cc.nt_local; gb.total = gb.nwaves * cc.nt_local;
+    ga.zero_word = walk ? h->cv_list : nullptr;
+    if (ga.total > 0) hipLaunchKernelGGL(k_colfct_ts, dim3(blocks8((ga.total + 3) / 4)), dim3(64, 4), 0, st, cc, cf, S, ga);
+    mark_on(h, "colfct_ts", sid);
+    if (walk) {
+      const size_t lds_b = ((size_t)2 * 2 * (c.km + 1) * 64 + (size_t)12 * c.km) * 8;
+      hipLaunchKernelGGL(k_colupd_conv_ts, dim3(blocks8(gb.nwaves)), dim3(64, 2), lds_b, st, cc, (const double *)S, gb, h->cv_list);
+      mark_on(h, "colupd_conv_ts", sid);
+    } else {
+      launch_b(cc, gb, (const double *)S, st);
+      mark_on(h, "colupd_ts", sid);
+    }
+  };
+  // T and S first, on the side stream: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both
+  // passes and the walk run there while the main stream works on the other tracers; the mixed ranges the walk lists are
+  // replayed on those by k_convect_apply_list afterwards (launch_convect).  Not under tracer sharding, where convection
+  // follows the exchange.
+  const bool split = convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 && h->ts_no_src;
+  if (split) {
+    // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
+    // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
+    if (h->iso_waited && h->step_begun) {
+      HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
+      h->ts_waited_begin = h->step_no;
+      if (h->iso_set[h->iso_cur].st != h->side_ts)   // (the chain ran on this very stream: nothing to wait for, and a wait packet costs ~6 us)
+        HIPCHK(hipStreamWaitEvent(h->side_ts, h->iso_set[h->iso_cur].ev, 0));
+    } else {
+      HIPCHK(hipEventRecord(h->ev_fct_done, h->stream));
+      HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_fct_done, 0));
+    }
+    uvic_ctx cts = c;
+    cts.nt_local = 2;
+    cts.prio |= 2;
+    mark_on(h, "begin", 3);
+    const WetCols w = wet_range(h, c.js, c.je);
+    if (h->ts_exact && h->ts_rows) {   // cross-check: the row kernels of kernels_fct.hpp, then the walk on its own
+      if (int rc = launch_rows(h, cts, h->side_ts, 3, w.count > 0 ? h->cv_list : nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
+      if (w.count > 0)
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), ((size_t)2 * h->d.km * 64 + (size_t)12 * h->d.km) * 8, h->side_ts, cts, w, h->cv_list);
+      mark_on(h, "convect_ts", 3);
+    } else if (h->ts_exact) {
+      // T and S in the reference's own order of operations (kernels_colx.hpp): every convective adjustment is decided on
+      // their bits (convect.F:189-255), and a density comparison of rounding size flips on a 1-ulp difference
+      if (int rc = launch_colx(h, cts, a, b, h->side_ts, 3, w.count > 0)) return rc;
+    } else {
+      launch_ts_columns(cts, h->side_ts, 3, w.count > 0);
+    }
+    HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
+    if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
+      HIPCHK(hipMemcpyAsync(h->ts_host, c.t_taup1, (size_t)2 * c.imt * c.km * c.jmt * 8, hipMemcpyDeviceToHost, h->side_ts));
+      HIPCHK(hipEventRecord(h->ev_ts_host, h->side_ts));
+      h->ts_host_queued = true;
+    }
+    h->ts_ahead = true;
+    if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
+    // the other tracers on the main stream: work arrays are indexed from the group's first tracer
+    uvic_ctx cr = c;
+    cr.n0 = 2; cr.nt_local = c.nt - 2;
+    cr.fny = c.fny + 2 * N3;
+    ColGrid br = b;
+    br.total = br.nwaves * cr.nt_local;
+    if (int rc = land_clean(h, c, h->stream)) return rc;
+    mark(h, "begin");
+    launch_a(cr, a, S + 2 * N3, h->stream);
+    mark(h, "colfct");
+    if (h->src_from_prefetch) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+      h->src_from_prefetch = false;
+    }
+    launch_b(cr, br, (const double *)(S + 2 * N3), h->stream);
+  } else {
+    if (int rc = land_clean(h, c, h->stream)) return rc;
+    mark(h, "begin");
+    // the local tracers among T and S take their own kernels first (bit-exact in the production step), the others the bulk passes
+    const int n_ts = c.n0 < 2 ? std::min(c.n0 + c.nt_local, 2) - c.n0 : 0;
+    if (n_ts > 0) {
+      uvic_ctx cts = c;
+      cts.nt_local = n_ts;
+      if (h->ts_exact && h->ts_rows) { if (int rc = launch_rows(h, cts, h->stream, 0, nullptr, "fct_rows_ts", "update_rows_ts")) return rc; }
+      else if (h->ts_exact) { if (int rc = launch_colx(h, cts, a, b, h->stream, 0, false)) return rc; }
+      else {
+        if (h->src_from_prefetch) {   // (T or S with a source term: pass B reads it)
+          HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+          h->src_from_prefetch = false;
+        }
+        launch_ts_columns(cts, h->stream, 0, false);
+      }
+    }
+    uvic_ctx cr = c;
+    cr.n0 = c.n0 + n_ts; cr.nt_local = c.nt_local - n_ts;
+    cr.fny = c.fny + (size_t)n_ts * N3;
+    ColGrid br = b;
+    br.total = br.nwaves * cr.nt_local;
+    launch_a(cr, a, S + (size_t)n_ts * N3, h->stream);
+    mark(h, "colfct");
+    if (h->src_from_prefetch) {
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
+      h->src_from_prefetch = false;
+    }
+    launch_b(cr, br, (const double *)(S + (size_t)n_ts * N3), h->stream);
+  }
+  mark(h, "colupd");
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 static int launch_convect(uvic_gpu *h) {
   mark(h, "begin");
@@ -1871,10 +1785,9 @@ static int launch_convect(uvic_gpu *h) {
     mark(h, "convect");
   } else {
     const WetCols w = wet_range(h, h->ctx.js, h->ctx.je);
-    const bool fused = h->ts_ahead;   // T,S walk on the side stream, replay inside pass B (launch_transport): all done
+    const bool fused = h->ts_ahead;   // the T,S walk has run on the side stream (launch_transport): its mixed ranges are replayed here
     h->ts_ahead = false;
-    if (fused && h->ts_apply) {       // ... or left to convect_apply here, once the walk has finished
-      h->ts_apply = false;
+    if (fused) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
       if (w.count > 0 && h->d.nt > 2)   // over the list of columns the walk mixed (few): 64 workgroups stride over it
         hipLaunchKernelGGL(k_convect_apply_list, dim3(64), dim3(256), 0, h->stream, h->ctx, (const int *)h->cv_list, w.count);
@@ -2435,7 +2348,7 @@ extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing
   if ((iso_ahead & 2) && !h->ctx.diff_cbt_given)
     if (int rc = prefetch_isopyc_ahead(h, 2)) return rc;
   h->unmix_at_rotate = mixing != 0;
-  static const bool fewer = getenv("UVIC_MAIN_ALIAS") && atoi(getenv("UVIC_MAIN_ALIAS")) != 0;
+  static const bool fewer = uv_env("UVIC_MAIN_ALIAS") && atoi(uv_env("UVIC_MAIN_ALIAS")) != 0;
   h->idle_until_next = fewer && (iso_ahead & 4) != 0;   // bit 2: the caller queues nothing on the main stream before the next step
   return 0;
 }
@@ -2700,8 +2613,7 @@ extern "C" int uvic_gpu_set_mobi(uvic_gpu *h, const uvic_mobi_params *p, const u
 }
 extern "C" int uvic_gpu_set_mobi_opt(uvic_gpu *h, const uvic_mobi_params *p, const uvic_mobi_options *o, const uvic_mobi_forcing *f) {
   if (!h || !p || !o || !f) return fail_msg("uvic_gpu_set_mobi_opt: null argument");
-  static const bool force_gen = getenv("UVIC_MOBI_GENERIC") && atoi(getenv("UVIC_MOBI_GENERIC")) != 0;   // cross-check only
-  if (o->n15 && o->c13 && !o->caco3 && !o->silicon && !force_gen) return uvic_gpu_set_mobi(h, p, f);   // option set C: its own kernels
+  if (o->n15 && o->c13 && !o->caco3 && !o->silicon && !h->mobi_generic) return uvic_gpu_set_mobi(h, p, f);   // option set C: its own kernels
   if (p->nsrc != h->d.nsrc || p->ntnpzd != h->d.ntnpzd) return fail_msg("uvic_gpu_set_mobi_opt: nsrc/ntnpzd differ from uvic_gpu_create");
   if (p->dtnpzd <= 0.0) return fail_msg("uvic_gpu_set_mobi_opt: dtnpzd must be positive");
   if (p->ntnpzd > UV_MOBI_MAXT) return fail_msg("uvic_gpu_set_mobi_opt: ntnpzd > 40");
@@ -2840,6 +2752,7 @@ __global__ void __launch_bounds__(256) k_sbc_accumulate(const uvic_ctx c, const 
   if (gid >= ns * count) return;
   const int q = (int)(gid / ns), ij = (int)(gid % ns);
   const int i = ij % c.imt, j = ij / c.imt;
+  if (i < 1 || i > c.imt - 2 || j < 1 || j > c.jmt - 2) return;   // set_sbc.F:40-72 runs over i = 2..imt-1 and the rows of the window
   double a = acc[gid];
   if (zero_first && c.kmt[ij] != 0) a = 0.0;
   const size_t N3 = (size_t)c.imt * c.km * c.jmt;
@@ -2878,7 +2791,7 @@ extern "C" int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload) {
 extern "C" int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_host) {
   if (!h || !s) return fail_msg("uvic_gpu_overlay_step: null argument");
   HIPCHK(hipSetDevice(h->device));
-  static const bool timing = getenv("UVIC_OVL_TIMING") != nullptr;   // diagnosis: host wall time of the call's parts
+  static const bool timing = uv_env("UVIC_OVL_TIMING") != nullptr;   // diagnosis: host wall time of the call's parts
   const auto tq0 = std::chrono::steady_clock::now();
   h->ts_host = ts_host;
   h->ts_host_queued = false;

@@ -105,14 +105,17 @@ class TracerModel:
             setattr(self.params, k, v)
         check(self.lib.uvic_gpu_set_params(self.h, ctypes.byref(self.params)), "set_params")
 
-    def set_mobi(self, ocean, table=None):
+    def set_mobi(self, ocean, table=None, generic=False):
         """Upload MOBI parameters (COMMON /npzd_r/ after mobi_init) and forcing; from
-        then on `tracer` computes the source terms on the device."""
+        then on `tracer` computes the source terms on the device.  generic: option set C through the general
+        column kernel as well (cross-check)."""
         from . import mobi as pm
         prm = table if table is not None else pm.load_table(ocean.cfg.name, ocean.grid.km)
         P = pm.make_params(ocean.cfg, ocean.grid, prm)
         F = pm.Forcing(ocean)
-        if pm.is_set_c(ocean.cfg) and os.environ.get("UVIC_MOBI_GENERIC", "0") == "0":
+        if generic:
+            self.set_option("mobi_generic", 1)
+        if pm.is_set_c(ocean.cfg) and not generic:
             check(self.lib.uvic_gpu_set_mobi(self.h, ctypes.byref(P), ctypes.byref(F.c)), "set_mobi")
         else:   # another option set of SURVEY.md §2c: flags and the extra parameters travel in uvic_mobi_options
             O = pm.make_options(ocean.cfg, ocean.grid, prm)
@@ -304,6 +307,10 @@ class TracerModel:
         mode = {"columns": 2, "rows": 3}.get(on) if isinstance(on, str) else (int(on) if on in (2, 3) and on is not True else (1 if on else 0))
         check(self.lib.uvic_gpu_set_exact(self.h, mode), "set_exact")
 
+    def set_option(self, name, value):
+        """cross-check and tuning switches of the library (include/uvic_gpu.h: uvic_gpu_set_option)"""
+        check(self.lib.uvic_gpu_set_option(self.h, name.encode(), int(value)), f"set_option {name}")
+
     def set_mixing(self, on):
         check(self.lib.uvic_gpu_set_mixing(self.h, 1 if on else 0), "set_mixing")
 
@@ -391,7 +398,7 @@ class TimeLoop:
     With MOBI, the source terms of the next leapfrog step are started one step ahead on a
     side stream (they depend only on t(tau-1) of that step = t(tau) of this one)."""
 
-    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True, segment=0, clock=None):
+    def __init__(self, model, dtts, nmix=16, shard=None, prefetch=True, segment=0, clock=None, iso2=False):
         """segment = ntspos, the ocean steps per coupling segment (u09/common/UVic_ESCM.F:177-189): the surface forcing
         MOBI reads changes at a segment's first step, whose sources therefore cannot be computed one step ahead
         (0: the forcing never changes during the loop)."""
@@ -400,7 +407,7 @@ class TimeLoop:
         # clock = (relyr of the first step, increment per step, co2ccn): the reference advances relyr every ocean step and
         # MOBI takes the month of the dust field and the declination from it (u09/mom/tracer.F:311-338); None: it stands still
         self.clock = clock
-        self.iso2 = os.environ.get("UVIC_ISO2", "0") != "0"      # 1: isopyc two steps ahead on the idle MOBI stream (measured: no gain)
+        self.iso2 = bool(iso2)      # isopyc two steps ahead on the idle MOBI stream (measured: no gain)
         self.itt = 0
 
     def _mixing(self, itt):
