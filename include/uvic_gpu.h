@@ -316,6 +316,19 @@ int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload);
  * surface sums (sbc_zero: a segment's first step, set_sbc.F:40-48; sbc_accumulate), T,S of t(tau+1) to `ts_host`
  * (imt, km, jmt, 2; what clinic and the next loadmw read) and the rotation of the time levels.  Returns as soon as T,S
  * are on the host; pass B of the other tracers may still be running, the next call queues behind it. */
+/* ---- time-step integrals of O_time_step_monitor on the device ----------------------------------------------
+ * With tsiint = tsiper (the shipped run/control.in: 10 days each) tsiperts (source/common/switch.F:458-459) is true on
+ * EVERY ocean step, and `tracer` then also forms tbar, travar, dtabs (diagt1, u09/mom/tracer.F:1516-1537, from t(tau),
+ * t(tau-1) and t(tau+1) before convection) and the volume sum of delta 14C (:1329-1353), `clinic` ektot (u09/mom/
+ * clinic.F:616-630).  uvic_gpu_set_tsi(h, 1, ic14, idic) names the step that follows such a step (until the next
+ * uvic_gpu_rotate; ic14 = idic = 0: no delta-14C sum); uvic_gpu_tsi_read waits for the step and fills the arrays as
+ * source/common/diag.h declares them, (0:km, nt, jmt) each, every sum added along i in the reference's order (bit-identical
+ * with bit-identical tracers), and dc14bar (the rows' sums added in row order: equal to the reference's single running
+ * sum to rounding).  uvic_gpu_tsi_ektot does the same for ektot (0:km, jmt) from UVIC_F_U1, UVIC_F_U2. */
+int uvic_gpu_set_tsi(uvic_gpu *h, int on, int ic14, int idic);
+int uvic_gpu_tsi_read(uvic_gpu *h, double *tbar, double *travar, double *dtabs, double *dc14bar);
+int uvic_gpu_tsi_ektot(uvic_gpu *h, double rho0, double *ektot);
+
 typedef struct uvic_overlay_step {
   double c2dtts, c2dtts_next, relyr_next, co2ccn_next;
   int32_t mixing, mobi_ahead, iso_ahead, sbc_zero, sbc_accumulate, pad;

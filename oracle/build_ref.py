@@ -69,6 +69,10 @@ CONFIGS = {
     "m2i": BASE + ["O_stream_function"],
 }
 
+# option set C with the momentum routines and the time-step monitor of run/mk.in (tsiperts steps: tbar, travar, dtabs,
+# dc14bar of diagt1 and ektot of clinic, which the overlays form on the device)
+CONFIGS["t30"] = CONFIGS["c30"] + "O_stream_function O_anisotropic_viscosity O_ice_evp O_time_step_monitor".split()
+
 # the reference's second boundary: -DO_TMM turns `tracer` into the column-batch source operator of the
 # Transport-Matrix-Method driver: imt = batch size, jmt = 1 (u09/common/size.h:26-30)
 CONFIGS["tmm30"] = CONFIGS["c30"] + ["O_TMM"]
@@ -85,6 +89,8 @@ EXTRA_SOURCES = {
     "m2": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F",
            "updates/09/source/mom/loadmw.F"],
     "m2i": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F",
+            "updates/09/source/mom/loadmw.F"],
+    "t30": ["updates/09/source/mom/clinic.F", "source/common/filuv.F", "updates/09/source/mom/setvbc.F",
             "updates/09/source/mom/loadmw.F"],
 }
 
@@ -222,11 +228,12 @@ DEFAULT_BUILDS = [
     ("m2", 14, 14, 6), ("m2", 102, 102, 19),      # momentum step: clinic, filuv, setvbc (tests/test_clinic.py)
     ("m2i", 14, 14, 6),                           # clinic with one viscosity per row, without O_ice_evp
     ("tmm30", 64, 1, 6),                          # `tracer` as the O_TMM column-batch operator (tests/test_tmm.py)
+    ("t30", 14, 14, 6),                           # option set C + clinic + O_time_step_monitor (tsiperts steps on the device)
 ]
 
 
 SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f18", 14, 14, 6), ("s37", 14, 14, 6),
-               ("m2", 14, 14, 6), ("m2", 102, 102, 19), ("m2i", 14, 14, 6)]
+               ("m2", 14, 14, 6), ("m2", 102, 102, 19), ("m2i", 14, 14, 6), ("t30", 14, 14, 6)]
 
 
 def build_default(force: bool = False, verbose: bool = False, jobs: int = 4):

@@ -24,7 +24,7 @@ from pathlib import Path
 HEADERS = [
     "mw.h", "isopyc.h", "grdvar.h", "coord.h", "levind.h", "vmixc.h",
     "hmixc.h", "accel.h", "scalar.h", "switch.h", "state.h", "tmngr.h",
-    "csbc.h", "diaga.h", "ice.h", "atm.h", "cembm.h", "mobi.h", "emode.h",
+    "csbc.h", "diag.h", "diaga.h", "ice.h", "atm.h", "cembm.h", "mobi.h", "emode.h",
     "cregin.h", "timeavgs.h", "index.h", "cfilt.h", "calendar.h", "tidal_kv.h", "cpolar.h",
 ]
 

@@ -255,3 +255,63 @@ def test_overlay_clinic_matches_reference_clinic(cfg, dims, resident, monkeypatc
     want_u, want_zu, _ = ref.clinic()
     got_u, got_zu, _ = shim.clinic()
     assert np.array_equal(got_u, want_u) and np.array_equal(got_zu, want_zu)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("resident", [False, True])
+def test_time_step_monitor_steps_stay_on_the_device(resident, exact, monkeypatch):
+    """With the shipped run/control.in (tsiint = tsiper = 10 days) tsiperts (source/common/switch.F:458-459) is true on
+    EVERY ocean step and run/mk.in defines O_time_step_monitor: `tracer` then also forms tbar, travar, dtabs (diagt1,
+    u09/mom/tracer.F:1516-1537; dtabs from t(tau+1) BEFORE convection) and dc14bar (:1329-1353), `clinic` ektot
+    (clinic.F:616-630).  The overlays keep such steps on the device and hand the same COMMON arrays to diago: three
+    steps (leapfrog, leapfrog, forward) of option set C built with the time-step monitor against the unmodified
+    reference -- the integrals bit for bit in the exact arithmetic (dc14bar, a single running sum over the whole grid in
+    the reference, to rounding), to the production tolerance otherwise."""
+    _arith(monkeypatch, exact)
+    if resident:
+        monkeypatch.setenv("UVIC_RESIDENT", "1")
+    else:
+        monkeypatch.delenv("UVIC_RESIDENT", raising=False)
+    cfg, dims = "t30", (14, 14, 6)
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
+    ref = refdriver.RefOcean(oc)
+    shim = refdriver.RefOcean(oc, shim=True)
+    jmt = dims[1]
+    for R in (ref, shim):
+        R.set_momentum(mom)
+        R.ref.set("tsiperts", 1)
+        R.state(); R.adv_vel_u(); R.setvbc()
+    names = ("tbar", "travar", "dtabs")
+    for it in range(1, 4):
+        forward = it == 3
+        for R in (ref, shim):
+            R.set_step_kind(forward)
+            _segment_switches(R, it, 4)
+            for n in names + ("ektot",):        # diagi zeroes them at the start of every step (source/mom/diagi.F:193-205)
+                R.v[n][...] = 0.0
+            R.ref.set("dc14bar", 0.0)
+        want = ref.step().copy()
+        got = shim.step().copy()
+        assert _same(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2], exact), it
+        if not exact and it == 1:   # the device did this step: the other tracers carry the column kernels' rounding
+            assert not np.array_equal(got[:, :, 1:jmt - 1, 2:], want[:, :, 1:jmt - 1, 2:])
+        for n in names:
+            a, b = shim.v[n], ref.v[n]
+            assert np.abs(b).max() > 0, n
+            if exact:
+                # (T, S bit for bit; the MOBI tracers through the device's exp/log: to rounding)
+                assert np.array_equal(a[:, :2], b[:, :2]), (it, n)
+            scale = np.abs(b).max(axis=(0, 2), keepdims=True)
+            assert (np.abs(a - b) <= PROD_TOL * np.maximum(scale, 1e-300)).all(), (it, n)
+        d_got, d_want = float(shim.v["dc14bar"][0]), float(ref.v["dc14bar"][0])
+        assert d_want != 0.0 and abs(d_got - d_want) <= PROD_TOL * abs(d_want), (it, d_got, d_want)
+        # clinic of the same step: ektot from u(tau)
+        want_u, _, _ = ref.clinic()
+        got_u, _, _ = shim.clinic()
+        assert np.array_equal(got_u[:, :, 1:-1], want_u[:, :, 1:-1])
+        assert np.abs(ref.v["ektot"]).max() > 0 and np.array_equal(shim.v["ektot"], ref.v["ektot"]), it
+        ref.rotate(); shim.rotate()

@@ -50,7 +50,7 @@ EXPORTS = [
     "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
     "uvic_gpu_state_async", "uvic_gpu_clinic_async",
     "uvic_gpu_tmm_create", "uvic_gpu_tmm_set_mobi", "uvic_gpu_tmm_sources", "uvic_gpu_rotate_u", "uvic_gpu_add_ext_mode", "uvic_gpu_adv_vel_async",
-    "uvic_gpu_momentum_async", "uvic_gpu_momentum_wait", "uvic_gpu_unpin_host", "uvic_gpu_set_option",
+    "uvic_gpu_momentum_async", "uvic_gpu_momentum_wait", "uvic_gpu_unpin_host", "uvic_gpu_set_option", "uvic_gpu_set_tsi", "uvic_gpu_tsi_read", "uvic_gpu_tsi_ektot",
 ]
 
 
@@ -119,6 +119,9 @@ def load():
     lib.uvic_gpu_set_mixing.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_set_exact.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    lib.uvic_gpu_set_tsi.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.uvic_gpu_tsi_read.argtypes = [ctypes.c_void_p] * 5
+    lib.uvic_gpu_tsi_ektot.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
     lib.uvic_gpu_set_mobi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_set_mobi_opt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_profile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),

@@ -155,6 +155,10 @@ OPTION_SETS = {
     # BASELINE config 4 == SURVEY option set C (nt=30, nsrc=28, ntnpzd=25)
     "c30": _build("c30", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen",
                           "carbon_13", "carbon_14", "mobi_nitrogen_15"]),
+    # the same set; names the oracle/_ref build with the momentum routines and O_time_step_monitor (the tsiperts steps of
+    # the shipped run/control.in: tests/test_fortran_shim.py)
+    "t30": _build("t30", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_alk", "mobi_nitrogen",
+                          "carbon_13", "carbon_14", "mobi_nitrogen_15"]),
     # SURVEY option set E (nt=13): the nearest buildable set to BASELINE config 2
     "e13": _build("e13", ["mobi", "mobi_o2", "mobi_iron", "carbon", "mobi_caco3"]),
     # SURVEY option set F (nt=18): the nearest buildable set to BASELINE config 3

@@ -596,6 +596,79 @@ __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m,
   mobi_column_kernel(c, m, i, j);
 }
 
+// ---- the time-step integrals of O_time_step_monitor (diagt1, u09/mom/tracer.F:1516-1537; :1329-1353; clinic.F:616-630) ----
+// With tsiint = tsiper (the shipped run/control.in) every ocean step is one of these: the sums are formed here so that the
+// step stays on the device.  One thread per (row, level, tracer) adds along i in the reference's order (a running sum is
+// not associative: the same order gives the same bits).  tp = t(tau+1) BEFORE convection (diagt1 is called at tracer.F:1161).
+// acc: tbar, travar, dtabs, each (0:km, nt, jmt) as source/common/diag.h declares them.
+__global__ void __launch_bounds__(64) k_tsi_rows(const uvic_ctx c, double *acc) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrows = c.je - c.js + 1;
+  if (gid >= (long long)c.km * nrows * c.nt_local) return;
+  const int k = (int)(gid % c.km) + 1;
+  const int j = c.js + (int)((gid / c.km) % nrows);
+  const int n = c.n0 + (int)(gid / ((long long)c.km * nrows)) + 1;
+  const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+  const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
+  const double *tt = c.t_tau + (size_t)(n - 1) * N3 + row, *tm = c.t_taum1 + (size_t)(n - 1) * N3 + row;
+  const double *tp = c.t_taup1 + (size_t)(n - 1) * N3 + row, *msk = c.tmask + row;
+  const double r2dt = 1.0 / c.c2dtts, cosdyt = c.cst[j - 1] * c.dyt[j - 1];
+  const double fx = r2dt / c.dtxcel[k - 1], dztk = c.dzt[k - 1];
+  double s_bar = 0.0, s_var = 0.0, s_abs = 0.0;
+  for (int i0 = 1; i0 < c.imt - 1; i0 += 8) {   // (i = 2..imt-1; eight columns per memory round trip)
+    double a[8], p[8], m[8], w[8];
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u < c.imt - 1 ? i0 + u : c.imt - 2;
+      a[u] = tt[i]; p[u] = tp[i]; m[u] = tm[i];
+      w[u] = dztk * c.dxt[i] * cosdyt * msk[i];
+    }
+    _Pragma("unroll") for (int u = 0; u < 8; ++u)
+      if (i0 + u < c.imt - 1) {
+        const double temp3 = a[u] * w[u], temp1 = a[u] * a[u] * w[u], temp2 = dabs(p[u] - m[u]) * w[u] * fx;
+        s_bar = s_bar + temp3; s_var = s_var + temp1; s_abs = s_abs + temp2;
+      }
+  }
+  const size_t q = (size_t)k + (size_t)(c.km + 1) * ((size_t)(n - 1) + (size_t)c.nt * (j - 1)), NA = (size_t)(c.km + 1) * c.nt * c.jmt;
+  acc[q] = s_bar; acc[NA + q] = s_var; acc[2 * NA + q] = s_abs;
+}
+// delta 14C of the final t(tau+1) weighted by the cell volume, one partial sum per row (k outer, i inner as tracer.F:1342-1353);
+// the caller adds the rows in order
+__global__ void __launch_bounds__(64) k_tsi_dc14(const uvic_ctx c, int ic14, int idic, double rc14std, double *rows) {
+  const int j = c.js + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > c.je) return;
+  const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+  const double rrc14std = 1000. / rc14std, fy = c.cst[j - 1] * c.dyt[j - 1];
+  double sum = 0.0;
+  for (int k = 1; k <= c.km; ++k) {
+    const double fyz = fy * c.dzt[k - 1];
+    const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
+    const double *t14 = c.t_taup1 + (size_t)(ic14 - 1) * N3 + row, *tdic = c.t_taup1 + (size_t)(idic - 1) * N3 + row, *msk = c.tmask + row;
+    for (int i = 1; i < c.imt - 1; ++i) {
+      const double dc14 = (rrc14std * t14[i] / (tdic[i] + UV_EPSLN) - 1000.) * msk[i];
+      sum = sum + dc14 * c.dxt[i] * fyz * msk[i];
+    }
+  }
+  rows[j - 1] = sum;
+}
+// global kinetic energy on the tau velocity, clinic.F:616-630: ektot(k, jrow) = sum over n = 1, 2 and i = 2..imt-1 of
+// u(i,k,j,n,tau)**2 * (rho0/2 csu dyu) dzt dxu, added in that order; one thread per (row, level); out (0:km, jmt)
+__global__ void __launch_bounds__(64) k_tsi_ektot(const uvic_ctx c, const double *u1, const double *u2, double rho0, double *out) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nrows = c.je - c.js + 1;
+  if (gid >= c.km * nrows) return;
+  const int k = gid % c.km + 1, j = c.js + gid / c.km;
+  const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
+  const double fx = rho0 * 0.5 * c.csu[j - 1] * c.dyu[j - 1], fxz = fx * c.dzt[k - 1];
+  double sum = 0.0;
+  for (int n = 0; n < 2; ++n) {
+    const double *u = (n ? u2 : u1) + row;
+    for (int i = 1; i < c.imt - 1; ++i) {
+      const double weight = fxz * c.dxu[i];
+      sum = sum + u[i] * u[i] * weight;
+    }
+  }
+  out[(size_t)k + (size_t)(c.km + 1) * (j - 1)] = sum;
+}
 // Pass B runs over the ocean columns only; t(tau+1) is zero on land (the update is masked, tracer.F:1109-1130).  This
 // kernel clears the land columns of rows js..je of every local tracer (and the cyclic images of land columns 2 and
 // imt-1) ONCE per buffer: nothing on the device writes there afterwards, see land_clean().
@@ -786,6 +859,10 @@ struct uvic_gpu {
   int sbc_count;                // tracers whose surface level is accumulated
   int *sbc_tracer;              // device: their 1-based tracer numbers
   double *sbc_acc;              // device (imt, jmt, sbc_count)
+  // time-step integrals (O_time_step_monitor) formed on the device on the steps the caller names (uvic_gpu_set_tsi)
+  bool tsi_step;                // this step
+  int tsi_ic14, tsi_idic;       // tracer numbers of 14C and DIC (0: no delta-14C sum)
+  double *tsi_acc;              // tbar, travar, dtabs, each (0:km, nt, jmt); then jmt row sums of delta 14C
   // what the look-ahead MOBI chain assumed about the step it computed for (checked when that step starts)
   double src_relyr, src_co2ccn, src_c2dtts;
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
@@ -981,6 +1058,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->host_sync = true; h->ts_host = nullptr; h->ts_host_queued = false;
   HIPCHK(hipEventCreateWithFlags(&h->ev_ts_host, hipEventDisableTiming));
   h->sbc_count = 0; h->sbc_tracer = nullptr; h->sbc_acc = nullptr;
+  h->tsi_step = false; h->tsi_acc = nullptr; h->tsi_ic14 = h->tsi_idic = 0;
   h->src_relyr = h->src_co2ccn = 0.0;
   h->ts_ahead = false; h->serial = false; h->ts_no_src = false; h->step_begun = false; h->iso_waited = false; h->unmix_at_rotate = false;
   for (int q = 0; q < 3; ++q) {
@@ -1092,6 +1170,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->cv_list);
   (void)hipFree(h->sbc_tracer);
   (void)hipFree(h->sbc_acc);
+  (void)hipFree(h->tsi_acc);
   (void)hipEventDestroy(h->ev_ts_host);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
@@ -1588,6 +1667,15 @@ static int launch_isopyc(uvic_gpu *h) {
   }
   return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
 }
+// the time-step integrals of the tracers of `c` on stream `st`: after their pass B, before convection (diagt1, tracer.F:1161)
+static int launch_tsi_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid) {
+  if (!h->tsi_step || c.nt_local <= 0) return 0;
+  const long long n = (long long)c.km * (c.je - c.js + 1) * c.nt_local;
+  hipLaunchKernelGGL(k_tsi_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c, h->tsi_acc);
+  mark_on(h, "tsi_rows", sid);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 // the bit-exact row kernels (kernels_fct.hpp) for the tracers of `c` (n0, nt_local) on stream `st`; marks go to list `sid`
 static int launch_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid, int *zero_word, const char *name_a, const char *name_b) {
   if (c.nt_local <= 0) return 0;
@@ -1646,7 +1734,8 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
   if (h->exact) {
     mark(h, "begin");
-    return launch_rows(h, c, h->stream, 0, nullptr, "fct_rows", "update_rows");
+    if (int rc = launch_rows(h, c, h->stream, 0, nullptr, "fct_rows", "update_rows")) return rc;
+    return launch_tsi_rows(h, c, h->stream, 0);
   }
   // lane-per-column path
   if (int rc = build_col_lanes(h)) return rc;
@@ -1708,17 +1797,23 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     cts.prio |= 2;
     mark_on(h, "begin", 3);
     const WetCols w = wet_range(h, c.js, c.je);
-    if (h->ts_exact && h->ts_rows) {   // cross-check: the row kernels of kernels_fct.hpp, then the walk on its own
-      if (int rc = launch_rows(h, cts, h->side_ts, 3, w.count > 0 ? h->cv_list : nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
-      if (w.count > 0)
-        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), ((size_t)2 * h->d.km * 64 + (size_t)12 * h->d.km) * 8, h->side_ts, cts, w, h->cv_list);
-      mark_on(h, "convect_ts", 3);
+    // (a time-step-monitor step wants t(tau+1) of T and S before convection: pass B, the sums, then the walk on its own)
+    const bool walk_fused = w.count > 0 && !h->tsi_step && !(h->ts_exact && h->ts_rows);
+    if (h->ts_exact && h->ts_rows) {   // cross-check: the row kernels of kernels_fct.hpp
+      if (int rc = launch_rows(h, cts, h->side_ts, 3, nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
     } else if (h->ts_exact) {
       // T and S in the reference's own order of operations (kernels_colx.hpp): every convective adjustment is decided on
       // their bits (convect.F:189-255), and a density comparison of rounding size flips on a 1-ulp difference
-      if (int rc = launch_colx(h, cts, a, b, h->side_ts, 3, w.count > 0)) return rc;
+      if (int rc = launch_colx(h, cts, a, b, h->side_ts, 3, walk_fused)) return rc;
     } else {
-      launch_ts_columns(cts, h->side_ts, 3, w.count > 0);
+      launch_ts_columns(cts, h->side_ts, 3, walk_fused);
+    }
+    if (!walk_fused) {
+      if (int rc = launch_tsi_rows(h, cts, h->side_ts, 3)) return rc;
+      HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
+      if (w.count > 0)
+        hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), ((size_t)2 * h->d.km * 64 + (size_t)12 * h->d.km) * 8, h->side_ts, cts, w, h->cv_list);
+      mark_on(h, "convect_ts", 3);
     }
     HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
     if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
@@ -1743,6 +1838,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       h->src_from_prefetch = false;
     }
     launch_b(cr, br, (const double *)(S + 2 * N3), h->stream);
+    if (h->tsi_step) { mark(h, "colupd"); if (int rc = launch_tsi_rows(h, cr, h->stream, 0)) return rc; }
   } else {
     if (int rc = land_clean(h, c, h->stream)) return rc;
     mark(h, "begin");
@@ -1773,6 +1869,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       h->src_from_prefetch = false;
     }
     launch_b(cr, br, (const double *)(S + (size_t)n_ts * N3), h->stream);
+    if (h->tsi_step) { mark(h, "colupd"); if (int rc = launch_tsi_rows(h, c, h->stream, 0)) return rc; }
   }
   mark(h, "colupd");
   HIPCHK(hipGetLastError());
@@ -1811,6 +1908,13 @@ static int launch_convect(uvic_gpu *h) {
                        (size_t)(2 * h->flt_threads + 4) * 8, h->stream, cf, (const FilterItem *)h->flt_items,
                        (const double *)h->flt_mats, h->flt_nitems);
     mark(h, "filt");
+  }
+  if (h->tsi_step && h->tsi_ic14 > 0 && h->tsi_idic > 0) {   // delta 14C of the final t(tau+1), tracer.F:1329-1353
+    const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt;
+    const int nrows = h->ctx.je - h->ctx.js + 1;
+    hipLaunchKernelGGL(k_tsi_dc14, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, h->stream, h->ctx, h->tsi_ic14, h->tsi_idic, UV_RC14STD,
+                       h->tsi_acc + 3 * NA);
+    mark(h, "tsi_dc14");
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -2518,6 +2622,7 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->src_from_prefetch = true;
     h->ev_src_ready = h->ev_src_pending;
   }
+  h->tsi_step = false;
   h->step_no += 1;      // the T,S-derived fields of the new step live in set step_no % 3: current from now on, so that
   h->ts_final_valid = false;   // a diff_cbt uploaded for that step lands in it
   if (int rc = use_iso_set(h, (int)(h->step_no % 3))) return rc;
@@ -2757,6 +2862,62 @@ __global__ void __launch_bounds__(256) k_sbc_accumulate(const uvic_ctx c, const 
   if (zero_first && c.kmt[ij] != 0) a = 0.0;
   const size_t N3 = (size_t)c.imt * c.km * c.jmt;
   acc[gid] = a + c.t_taup1[(size_t)(tracers[q] - 1) * N3 + (size_t)i + (size_t)c.imt * c.km * j];
+}
+// The step that follows is a time-step-monitor step (tsiperts, source/common/switch.F:458-459): form tbar, travar, dtabs
+// (diagt1, u09/mom/tracer.F:1516-1537) and, when ic14 and idic are tracer numbers, the volume sum of delta 14C (:1329-1353)
+// on the device.  Holds until the next uvic_gpu_rotate.
+extern "C" int uvic_gpu_set_tsi(uvic_gpu *h, int on, int ic14, int idic) {
+  if (!h) return fail_msg("uvic_gpu_set_tsi: null handle");
+  if (ic14 < 0 || ic14 > h->d.nt || idic < 0 || idic > h->d.nt) return fail_msg("uvic_gpu_set_tsi: tracer number outside 1..nt");
+  HIPCHK(hipSetDevice(h->device));
+  if (on && !h->tsi_acc) {
+    const size_t bytes = ((size_t)3 * (h->d.km + 1) * h->d.nt * h->d.jmt + h->d.jmt) * 8;
+    HIPCHK(hipMalloc((void **)&h->tsi_acc, bytes));
+    HIPCHK(hipMemset(h->tsi_acc, 0, bytes));
+  }
+  h->tsi_step = on != 0;
+  h->tsi_ic14 = ic14; h->tsi_idic = idic;
+  return 0;
+}
+// ... and fetch them once the step is complete (waits for it): tbar, travar, dtabs as source/common/diag.h declares them,
+// (0:km, nt, jmt) each (rows and levels the step did not compute are zero, as diagi leaves them); dc14bar = the sum of the
+// rows' sums, rows ascending.  Call before the uvic_gpu_rotate that ends the step, or right after uvic_gpu_overlay_step.
+extern "C" int uvic_gpu_tsi_read(uvic_gpu *h, double *tbar, double *travar, double *dtabs, double *dc14bar) {
+  if (!h || !tbar || !travar || !dtabs) return fail_msg("uvic_gpu_tsi_read: null argument");
+  if (!h->tsi_acc) return fail_msg("uvic_gpu_tsi_read: no time-step-monitor step has run (uvic_gpu_set_tsi)");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = uvic_gpu_sync(h)) return rc;
+  const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt;
+  HIPCHK(hipMemcpy(tbar, h->tsi_acc, NA * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(travar, h->tsi_acc + NA, NA * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dtabs, h->tsi_acc + 2 * NA, NA * 8, hipMemcpyDeviceToHost));
+  if (dc14bar) {
+    std::vector<double> rows((size_t)h->d.jmt);
+    HIPCHK(hipMemcpy(rows.data(), h->tsi_acc + 3 * NA, rows.size() * 8, hipMemcpyDeviceToHost));
+    double sum = 0.0;
+    for (int j = h->ctx.js; j <= h->ctx.je; ++j) sum = sum + rows[(size_t)j - 1];
+    *dc14bar = sum;
+  }
+  return 0;
+}
+// ektot of O_time_step_monitor (clinic.F:616-630) from the u(tau) on the device (UVIC_F_U1, UVIC_F_U2), (0:km, jmt) as
+// source/common/diag.h declares it; rows and levels outside the window are zero.  Synchronous.
+extern "C" int uvic_gpu_tsi_ektot(uvic_gpu *h, double rho0, double *ektot) {
+  if (!h || !ektot) return fail_msg("uvic_gpu_tsi_ektot: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = mom_join(h)) return rc;
+  const size_t n = (size_t)(h->d.km + 1) * h->d.jmt;
+  double *dev;
+  HIPCHK(hipMalloc((void **)&dev, n * 8));
+  HIPCHK(hipMemsetAsync(dev, 0, n * 8, h->stream));
+  const int work = h->d.km * (h->ctx.je - h->ctx.js + 1);
+  hipLaunchKernelGGL(k_tsi_ektot, dim3((unsigned)((work + 63) / 64)), dim3(64), 0, h->stream, h->ctx, (const double *)h->buf[UVIC_F_U1],
+                     (const double *)h->buf[UVIC_F_U2], rho0, dev);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ektot, dev, n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipFree(dev));
+  return 0;
 }
 extern "C" int uvic_gpu_sbc_config(uvic_gpu *h, int count, const int32_t *tracers) {
   if (!h || count < 0 || (count > 0 && !tracers)) return fail_msg("uvic_gpu_sbc_config: bad argument");

@@ -210,6 +210,25 @@
           integer(c_int), value :: upload
           integer(c_int) :: rc
         end function
+        function uvic_gpu_set_tsi(h, on, ic14, idic) bind(C,name='uvic_gpu_set_tsi') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: on, ic14, idic
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_tsi_read(h, tbar, travar, dtabs, dc14bar) bind(C,name='uvic_gpu_tsi_read') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double) :: tbar(*), travar(*), dtabs(*), dc14bar
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_tsi_ektot(h, rho0, ektot) bind(C,name='uvic_gpu_tsi_ektot') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double), value :: rho0
+          real(c_double) :: ektot(*)
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_overlay_step(h, s, ts_host) bind(C,name='uvic_gpu_overlay_step') result(rc)
           import
           type(c_ptr), value :: h

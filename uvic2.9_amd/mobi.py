@@ -97,6 +97,7 @@ class MobiForcing(ctypes.Structure):
 
 
 def load_table(cfg_name: str, km: int) -> dict:
+    cfg_name = {"t30": "c30"}.get(cfg_name, cfg_name)     # (t30: option set C in the oracle/_ref build that also holds `clinic` and the time-step monitor)
     tab = json.loads((Path(__file__).resolve().parent / "data" / f"mobi_{cfg_name}.json").read_text())
     if str(km) not in tab:
         raise KeyError(f"no MOBI parameter table for {cfg_name} with km={km}; available: {sorted(tab)}")
