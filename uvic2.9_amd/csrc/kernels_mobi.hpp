@@ -66,14 +66,16 @@ struct mobi_dev {
 };
 enum { MP_BCT, MP_BCTZ, MP_NUD, MP_AOUT, MP_O2F, MP_AVEJ, MP_AVEJD, MP_AC13B, MP_COUNT };
 enum { MA_EXPO, MA_EXPOP, MA_RN15, MA_RC13, MA_CALPRO, MA_NFIX, MA_COUNT };
+#define UV_MOBI_WORK_PLANES 20   /* the most any option set's three passes use (kernels_mobi_gt.hpp: 11 + 9) */
+static_assert(MP_COUNT + MA_COUNT <= UV_MOBI_WORK_PLANES, "work planes of mobi_store");
 static inline void mobi_set_work(mobi_dev *m, double *w, int imt, int jmt, int km) {
   const size_t n3 = (size_t)imt * km * jmt;
   m->pre = w;
   m->aux = w + MP_COUNT * n3;
-  m->col = w + (MP_COUNT + MA_COUNT) * n3;
+  m->col = w + (size_t)UV_MOBI_WORK_PLANES * n3;
 }
 static inline size_t mobi_work_doubles(int imt, int jmt, int km) {
-  return (size_t)(MP_COUNT + MA_COUNT) * imt * km * jmt + (size_t)2 * imt * jmt;
+  return (size_t)UV_MOBI_WORK_PLANES * imt * km * jmt + (size_t)2 * imt * jmt;
 }
 
 // positions of the MOBI column tracers for option set C, fixed at compile time so that the

@@ -572,8 +572,8 @@ UVIC_DEV void mobig_src(mobi_params_cp P, mobi_options_cp O, const mobi_step &St
 }
 
 // work planes of the general kernel: (imt,km,jmt) each, in the space of the MP_* / MA_* planes of kernels_mobi.hpp
-enum { MPG_OMEGAC, MPG_AC13B, MPG_BCT, MPG_BCTZ, MPG_NUD, MPG_AOU, MPG_AVEJ, MPG_AVEJD, MPG_AVEJDIAT, MPG_COUNT };
-static_assert(MPG_COUNT <= MP_COUNT + MA_COUNT, "work planes of mobi_store");
+enum { MPG_OMEGAC, MPG_AC13B, MPG_BCT, MPG_BCTZ, MPG_NUD, MPG_AOU, MPG_AVEJ, MPG_AVEJD, MPG_AVEJDIAT, MPG_O2F, MPG_AOUT, MPG_COUNT };
+static_assert(MPG_COUNT <= UV_MOBI_WORK_PLANES, "work planes of mobi_store");
 /* What a level needs that depends on the level's own inputs (or, for the light, on the inputs above it) only -- one thread
    per (ocean column, level), as mobi_pre_cell does for set C: the carbonate chemistry (mobi.F:766-789: co2calc_SWS, the 13C
    fractionation factor of photosynthesis), the light that reaches the level (tracer.F:381-390, mobi.F:799-820: the running
@@ -633,6 +633,9 @@ UVIC_DEV void mobig_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k,
                        s_in * (-6.24523e-3 - 7.37614e-3 * f1 - 1.03410e-2 * f2 - 8.17083E-3 * f3) - 4.88682E-7 * s_in * s_in);
     o2sat = o2sat / 22391.6 * 1000.0 * 1000.;
     PREG(MPG_AOU) = o2sat - o2_in;
+    // (for the team form, kernels_mobi_gt.hpp: two functions of the level's inputs that mobi_src would form in every sub-step)
+    PREG(MPG_O2F) = tanh(g_max(o2_in, 0.));                                      // o2flag, mobi.F:2313
+    PREG(MPG_AOUT) = UV_DIVC(UV_POWP(g_max(o2sat - o2_in, 40.), 0.8), 66.);      // the AOU term of the ligand concentration, mobi.F:2316
   }
   /* the light-limited growth rates from the level's (clamped) pools, mobi.F:1961-2061 */
   const double biophyt = TN(k, X_phyt), biodiaz = TN(k, X_diaz), biodfe = TN(k, X_dfe), dzt = P->dzt[k - 1];

@@ -27,6 +27,7 @@
 #include "kernels_isopyc.hpp"
 #include "kernels_mobi.hpp"
 #include "kernels_mobi_gen.hpp"
+#include "kernels_mobi_gt.hpp"
 #include "uvic_ctx.h"
 
 using namespace uvic;
@@ -585,6 +586,40 @@ __global__ void __launch_bounds__(64) k_mobi_gen(const uvic_ctx c, const mobi_de
   if (gid >= w.count) return;
   WET_DECODE(w, gid);
   mobig_column<TN15, TC13, TCACO3, TSIL>(c, m, i, j);
+}
+// ... and the sets with prognostic CaCO3 (F, run/mk.in's) in the team form (kernels_mobi_gt.hpp)
+template <int R, int TN15, int TC13, int TCACO3, int TSIL>
+__device__ __forceinline__ void mobigt_team_role(const uvic_ctx &c, const mobi_dev &m, double *lds, int i, int j, bool live, int kmax) {
+  GpuTeam<R> T{(int)threadIdx.x, lds, 0u};
+  mobigt_column<GpuTeam<R>, TN15, TC13, TCACO3, TSIL>(T, c, m, i, j, live, kmax);
+}
+// (register budget: the nt = 37 set carries 32 pools; at set C's 168 registers it spills 92 of them, at 256 none, and a
+// 256-register team wave still shares its SIMD with one pass-A wave)
+template <int TN15, int TC13, int TCACO3, int TSIL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mobi_gteam(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int gid = blockIdx.x * 64 + threadIdx.x;
+  const bool live = gid < w.count;
+  WET_DECODE(w, live ? gid : 0);   // lanes beyond the list walk the first column and store nothing
+  int kmax = live ? c.kmt[(size_t)(i - 1) + (size_t)c.imt * (j - 1)] : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+  if (!(c.prio & 1)) __builtin_amdgcn_s_setprio(2);
+  switch (threadIdx.y) {   // wave-uniform: every wave runs the code specialised for its role
+    case 0: mobigt_team_role<0, TN15, TC13, TCACO3, TSIL>(c, m, lds, i, j, live, kmax); break;
+    case 1: mobigt_team_role<1, TN15, TC13, TCACO3, TSIL>(c, m, lds, i, j, live, kmax); break;
+    case 2: mobigt_team_role<2, TN15, TC13, TCACO3, TSIL>(c, m, lds, i, j, live, kmax); break;
+    default: mobigt_team_role<3, TN15, TC13, TCACO3, TSIL>(c, m, lds, i, j, live, kmax); break;
+  }
+}
+template <int TN15, int TC13, int TCACO3, int TSIL>
+__global__ void __launch_bounds__(128) k_mobi_gpost(const uvic_ctx c, const mobi_dev m, const WetCols w) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = gid / w.count + 1;
+  if (k > c.km) return;
+  WET_DECODE(w, gid % w.count);
+  mobigt_post_cell<TN15, TC13, TCACO3, TSIL>(c, m, i, k, j);
 }
 __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m, const WetCols w) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1944,6 +1979,21 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
     if (w.count > 0) {
       hipLaunchKernelGGL(k_mobi_gen_pre, dim3(cells), dim3(128), 0, st, c, m, w);   // carbonate chemistry, cell-parallel
       mark_on(h, "mobi_pre", sid);
+      if (h->mobi_team && (h->mobi_key == 4 || h->mobi_key == 15)) {   // sets F and run/mk.in's: four-wave teams, then the cell pass
+        const size_t lds = UV_MOBIGT_LDS_DOUBLES * 8;
+        if (h->mobi_key == 4) {
+          hipLaunchKernelGGL((k_mobi_gteam<0, 0, 1, 0>), dim3(cols), dim3(64, 4), lds, st, c, m, w);
+          mark_on(h, "mobi", sid);
+          hipLaunchKernelGGL((k_mobi_gpost<0, 0, 1, 0>), dim3(cells), dim3(128), 0, st, c, m, w);
+        } else {
+          hipLaunchKernelGGL((k_mobi_gteam<1, 1, 1, 1>), dim3(cols), dim3(64, 4), lds, st, c, m, w);
+          mark_on(h, "mobi", sid);
+          hipLaunchKernelGGL((k_mobi_gpost<1, 1, 1, 1>), dim3(cells), dim3(128), 0, st, c, m, w);
+        }
+        mark_on(h, "mobi_post", sid);
+        HIPCHK(hipGetLastError());
+        return 0;
+      }
       if (h->mobi_key == 4) hipLaunchKernelGGL((k_mobi_gen<0, 0, 1, 0>), dim3(cols), dim3(64), 0, st, c, m, w);         // set F
       else if (h->mobi_key == 15) hipLaunchKernelGGL((k_mobi_gen<1, 1, 1, 1>), dim3(cols), dim3(64), 0, st, c, m, w);   // run/mk.in's set
       else if (h->mobi_key == 3) hipLaunchKernelGGL((k_mobi_gen<1, 1, 0, 0>), dim3(cols), dim3(64), 0, st, c, m, w);    // set C (cross-check)
