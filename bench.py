@@ -9,9 +9,9 @@ set has them, FCT advection, isopycnal diffusion, explicit update, implicit
 vertical solve, convection) and the time-level rotation, with every input
 already resident in HBM.  Metric (BASELINE.json): imt*jmt*km*nt cell updates
 per completed step / wall time, whole job.  N > 1 (launched by
-torch.distributed.run, one rank per GPU, RCCL): latitude slabs with a 2-row halo
-exchange of t(tau+1) per step when every rank gets at least 12 rows, else tracer-index
-shards with an all-gather (--decomp overrides).
+torch.distributed.run, one rank per GPU, RCCL): tracer-index shards with an all-gather of
+t(tau+1) per step on the default grid (BASELINE configs 3-4), latitude slabs with a 2-row halo
+exchange on the refined 202x202x32 grid (config 5) (--decomp overrides).
 """
 from __future__ import annotations
 
@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--decomp", default="auto", choices=["auto", "tracer", "slab"],
                     help="N>1: tracer-index shards + all-gather, or latitude slabs + 2-row halo exchange "
                          "(auto: slabs when every rank gets at least 12 rows, SURVEY.md §8e)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "push", "rccl"],
+                    help="N>1: how t(tau+1) moves between ranks -- the library's direct push through hipIpc-mapped windows, "
+                         "or RCCL (all-gather / send-recv); auto = push if every rank can map its peers and a trial exchange arrives")
     ap.add_argument("--segment", type=int, default=0, metavar="NTSPOS",
                     help="ocean steps per coupling segment: the first step of a segment gets new surface forcing, so its MOBI "
                          "sources are not computed a step ahead (0 = the synthetic forcing is constant, the default)")
@@ -258,15 +261,20 @@ def main():
         src = np.asfortranarray(rng.standard_normal((imt, km, jmt, nsrc)) * 1e-10 * ocean.topo.tmask[..., None])
 
     from uvic29_amd.parallel import SlabShard, TracerShard
-    decomp = a.decomp
+    # BASELINE.json names the decomposition with the configuration: tracer-index shards on the default grid (configs 3
+    # and 4, the north star's primary scheme), latitude slabs with a 2-row halo exchange on the refined grid (config 5)
+    decomp, decomp_why = a.decomp, "--decomp"
     if decomp == "auto":
-        decomp = "slab" if world > 1 and (jmt - 2) // world >= 12 else "tracer"
+        refined = (imt, jmt, km) == (202, 202, 32)
+        decomp = "slab" if world > 1 and refined and (jmt - 2) // world >= 12 else "tracer"
+        decomp_why = ("BASELINE config 5 (refined grid): latitude slabs" if decomp == "slab"
+                      else "BASELINE configs 3-4: tracer-index shards (--decomp slab for the latitude-slab split)")
     if decomp == "slab" and world > 1:
-        shard = SlabShard(jmt, world, rank)
+        shard = SlabShard(jmt, world, rank, exchange=a.exchange)
         shard.nt_model, shard.nt_local = nt, nt
     else:
         decomp = "tracer"
-        shard = TracerShard(nt, world, rank)
+        shard = TracerShard(nt, world, rank, exchange=a.exchange)
     if shard.nt_model != nt:          # pad the tracer dimension with inert tracers (see parallel.py)
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, nsrc, cfg.ntnpzd, device=local_rank)
@@ -441,7 +449,10 @@ def main():
                                    f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",
                        "grid": a.grid, "nt": nt,
                        "forcing": ("constant: every leapfrog step looks one step ahead" if a.segment == 0 else
-                                   f"renewed every {a.segment} steps: the first step of a segment computes its MOBI sources in line"), "parallelism": (f"latitude-slab x{world}, 2-row halo exchange" if decomp == "slab" else f"tracer-shard x{world}")},
+                                   f"renewed every {a.segment} steps: the first step of a segment computes its MOBI sources in line"), "parallelism": (f"latitude-slab x{world}, 2-row halo exchange" if decomp == "slab" else f"tracer-shard x{world}"),
+                          "decomposition": decomp_why,
+                          **({"exchange": ("direct push (hipIpc-mapped windows, library kernels)" if shard.pushing else
+                                           "gloo through the host (rehearsal)" if rehearse else "RCCL")} if world > 1 else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          **({"peak_measured": hbm_meas, "frac_of_measured": ach / hbm_meas, "hbm_probe": hbm} if hbm_meas else {}),

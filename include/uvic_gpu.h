@@ -243,7 +243,8 @@ int uvic_gpu_set_exact(uvic_gpu *h, int exact);
  *   "nchunk" n: longitude chunks of the row kernels (0 = automatic);  "mobi_generic" 1: option set C through the
  *   general MOBI column kernel (call before uvic_gpu_set_mobi_opt);  "mobi_team" 0: one thread per column instead
  *   of four-wave teams;  "convect_onepass" 1: convct2 (convect.F:99-311) as one kernel over all tracers;
- *   "mobi_streams" 1: every look-ahead MOBI chain on one side stream.  Non-zero status for an unknown name.
+ *   "mobi_streams" 1: every look-ahead MOBI chain on one side stream;  "push_wait_ms" n: how long
+ *   uvic_gpu_push_exchange waits for a peer.  Non-zero status for an unknown name.
  * The shipped library reads no other environment variable than UVIC_EXACT. */
 int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value);
 /* work decomposition: this instance computes tracers n0+1..n0+nt_local and rows
@@ -343,6 +344,21 @@ int64_t uvic_gpu_halo_elems(uvic_gpu *h);
 void *uvic_gpu_halo_buffer(uvic_gpu *h, int which);
 int uvic_gpu_halo_pack(uvic_gpu *h, int south, int north);
 int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north);
+/* The same two exchanges -- the halo rows of a latitude slab, the all-gather of t(:,:,:,slice,tau+1) of tracer shards
+ * (the exchange where the reference's single process has none: tracer.F:902-1167 loops over n on one memory) -- as a
+ * direct push between the ranks of one node: every rank owns a receive window and arrival counters in device memory,
+ * its peers map them (hipIpcMemHandle_t, 64 bytes each) and write them with their own kernels; the data crosses each
+ * xGMI link once and no collective library is on the path.
+ *   uvic_gpu_push_setup     once per handle; mode 1: tracer shards (nt a multiple of world), 2: latitude slabs
+ *   uvic_gpu_push_export    128 bytes (window handle, counter handle) for the caller to pass to the peers
+ *   uvic_gpu_push_open      what rank `peer` exported (peer == own rank: no mapping, for a rank that neighbours itself)
+ *   uvic_gpu_push_exchange  per step, queued on the main stream after the step: push, signal, wait (on the device,
+ *                           at most "push_wait_ms" -- uvic_gpu_set_option, default 2000; a peer that never arrives
+ *                           makes the next uvic_gpu_sync fail), take.  south/north: neighbour ranks of a slab or -1. */
+int uvic_gpu_push_setup(uvic_gpu *h, int world, int rank, int mode);
+int uvic_gpu_push_export(uvic_gpu *h, void *handles128);
+int uvic_gpu_push_open(uvic_gpu *h, int peer, const void *handles128);
+int uvic_gpu_push_exchange(uvic_gpu *h, int south, int north);
 
 /* ---- producers of the step's shared inputs ------------------------------
  * replaces `call adv_vel (joff, js, je, is, ie)` (source/mom/mom.F:332; source/mom/adv_vel.F:63-131, the

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 NSTEP = 5
 
 
-def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
+def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer", exchange="rccl"):
     from uvic29_amd import OPTION_SETS, performance_set, synthetic
     from uvic29_amd.parallel import SlabShard, TracerShard
     from uvic29_amd.tracer import TimeLoop, TracerModel
@@ -26,10 +26,10 @@ def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
         rng = np.random.default_rng(2029)
         src = np.asfortranarray(rng.standard_normal((imt, km, jmt, cfg.nsrc)) * 1e-10 * ocean.topo.tmask[..., None])
     if decomp == "slab":
-        shard = SlabShard(jmt, world, rank)
+        shard = SlabShard(jmt, world, rank, exchange=exchange)
         shard.nt_model = cfg.nt
     else:
-        shard = TracerShard(cfg.nt, world, rank)
+        shard = TracerShard(cfg.nt, world, rank, exchange=exchange)
     if shard.nt_model != cfg.nt:
         ocean = synthetic.pad_tracers(ocean, shard.nt_model)
     m = TracerModel(imt, jmt, km, shard.nt_model, cfg.nsrc, cfg.ntnpzd, device=0)
@@ -47,14 +47,14 @@ def _run(cfg_name, imt, jmt, km, world, rank, decomp="tracer"):
     return out
 
 
-def _worker(rank, world, port, out_path, decomp="tracer", grid=(14, 14, 6), cfg="c30"):
+def _worker(rank, world, port, out_path, decomp="tracer", grid=(14, 14, 6), cfg="c30", exchange="rccl"):
     import torch.distributed as dist
     for p in (ROOT,):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    got = _run(cfg, *grid, world, rank, decomp)
+    got = _run(cfg, *grid, world, rank, decomp, exchange)
     np.save(f"{out_path}.{rank}.npy", got)
     if rank == 0:
         np.save(f"{out_path}.single.npy", _run(cfg, *grid, 1, 0))
@@ -135,6 +135,21 @@ def test_config3_tracer_shards_nt15_full_grid(tmp_path, world):
         assert np.array_equal(got[:, :, 1:-1], ref[:, :, 1:-1]), f"rank {r}"
 
 
+def test_config4_tracer_shards_nt30_mobi_full_grid(tmp_path):
+    """BASELINE config 4 as worded -- the nt = 30 MOBI-isotope set on 100x100x19 under tracer-index shards -- with as many
+    ranks as one GPU box admits beside the test process (four; the eight-rank split of the same schedule is rehearsed on
+    the CPU, tests/test_parallel_gloo.py): T and S (bit-exact kernels) on rank 0, MOBI and isopyc replicated, the padded
+    all-gather, replicated convection and filter; every rank ends with the single-rank result bit for bit."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ts4c30")
+    mp.spawn(_worker, args=(4, 29621, out, "tracer", (102, 102, 19), "c30"), nprocs=4, join=True)
+    ref = np.load(f"{out}.single.npy")
+    assert np.isfinite(ref).all() and ref.shape[3] == 30
+    for r in range(4):
+        got = np.load(f"{out}.{r}.npy")
+        assert np.array_equal(got[:, :, 1:-1], ref[:, :, 1:-1]), f"rank {r}"
+
+
 def test_config5_four_slabs_refined_grid_nt30(tmp_path):
     """BASELINE config 5 as worded: the refined 200x200x32 grid with nt = 30 and MOBI, latitude slabs (four here, ranks on
     one GPU) with the 2-row halo exchange: owned rows equal the single-rank run bit for bit over five steps."""
@@ -148,6 +163,55 @@ def test_config5_four_slabs_refined_grid_nt30(tmp_path):
         js, je = slab_rows(202, 4, r)
         got = np.load(f"{out}.{r}.npy")
         assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
+
+
+@pytest.mark.parametrize("decomp,world,grid", [("tracer", 2, (14, 14, 6)), ("slab", 2, (14, 14, 6)), ("slab", 4, (102, 102, 19)),
+                                               ("tracer", 4, (102, 102, 19))])
+def test_direct_push_between_processes_on_one_gpu(tmp_path, decomp, world, grid):
+    """The library's own exchange (uvic_gpu_push_*): each rank's pack kernel writes straight into the receive window its
+    peer exported through hipIpc, raises the peer's arrival counter, and waits on the device for its own -- no
+    torch.distributed call on the data path (gloo carries the 128-byte handles once).  Separate processes on one GPU
+    stand in for the GPUs of a node; owned rows / all tracers equal the single-rank run bit for bit over five steps,
+    a mixing step and the look-ahead chains included."""
+    import torch.multiprocessing as mp
+    from uvic29_amd.parallel import slab_rows
+    out = str(tmp_path / "push")
+    port = 29641 + 2 * world + (decomp == "slab")
+    mp.spawn(_worker, args=(world, port, out, decomp, grid, "c30", "push"), nprocs=world, join=True)
+    ref = np.load(f"{out}.single.npy")
+    assert np.isfinite(ref).all()
+    for r in range(world):
+        got = np.load(f"{out}.{r}.npy")
+        if decomp == "slab":
+            js, je = slab_rows(grid[1], world, r)
+            assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), f"rank {r}"
+        else:
+            assert np.array_equal(got[:, :, 1:-1], ref[:, :, 1:-1]), f"rank {r}"
+
+
+def test_direct_push_reports_a_peer_that_never_arrives():
+    """The wait for a peer is a kernel with a time limit: a slab whose northern neighbour never pushes ends with an error at
+    the next sync (naming the side), not with a hung queue."""
+    import time
+    from uvic29_amd import OPTION_SETS, synthetic
+    from uvic29_amd.capi import UvicGpuError
+    from uvic29_amd.tracer import TracerModel
+    cfg = OPTION_SETS["c30"]
+    ocean = synthetic.make_ocean(cfg, 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    m = TracerModel(14, 14, 6, cfg.nt, cfg.nsrc, cfg.ntnpzd, device=0)
+    m.load_ocean(ocean, to, so, c)
+    m.set_shard(js=4, je=9)
+    assert m.lib.uvic_gpu_push_setup(m.h, 1, 0, 2) == 0, m.last_error()
+    assert m.lib.uvic_gpu_push_open(m.h, 0, None) == 0, m.last_error()
+    m.set_option("push_wait_ms", 50)
+    t0 = time.perf_counter()
+    assert m.lib.uvic_gpu_push_exchange(m.h, -1, 0) == 0, m.last_error()    # pushes north (to itself, as "from the south"), waits for the north
+    with pytest.raises(UvicGpuError, match="north"):
+        m.sync()
+    assert time.perf_counter() - t0 < 5.0
+    m.sync()                      # the error is reported once
+    m.close()
 
 
 def _rccl_loop_worker(rank, port, out_path, backend):
@@ -273,15 +337,16 @@ def test_rccl_paths_single_rank(tmp_path):
     assert ok[1], "row blocks sent through RCCL did not arrive where expected"
 
 
-def test_bench_with_two_ranks_on_one_gpu_prints_one_json_line():
+@pytest.mark.parametrize("extra", [(), ("--decomp", "slab", "--exchange", "rccl")])
+def test_bench_with_two_ranks_on_one_gpu_prints_one_json_line(extra):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), with both ranks on
     the one GPU of this box and gloo standing in for RCCL (UVIC_BENCH_REHEARSAL=1): rank 0 prints exactly one JSON line
-    with the contract's keys, the whole-job value and the slab decomposition."""
+    with the contract's keys, the whole-job value, the decomposition and the exchange that ran."""
     import json
     import subprocess
     env = dict(os.environ, UVIC_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"]
+           "--master-port", "29571", str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", *extra]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -290,5 +355,11 @@ def test_bench_with_two_ranks_on_one_gpu_prints_one_json_line():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
-    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "latitude-slab x2" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0
+    # the decomposition follows the BASELINE configuration (default grid: tracer shards), the exchange is the library's own
+    if extra:
+        assert "latitude-slab x2" in d["config"]["parallelism"] and d["config"]["exchange"].startswith("gloo")
+    else:
+        assert "tracer-shard x2" in d["config"]["parallelism"] and "configs 3-4" in d["config"]["decomposition"]
+        assert d["config"]["exchange"].startswith("direct push")
     assert "cpu_baseline" not in d            # reported at N = 1 only

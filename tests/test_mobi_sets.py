@@ -121,9 +121,11 @@ def _table(cfg, km):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("team", [True, False])
 @pytest.mark.parametrize("cfg,dims", [("f18", (14, 14, 6)), ("s37", (14, 14, 6)), ("s37", (102, 102, 19)), ("f18", (102, 102, 19))])
-def test_gpu_sources_of_the_other_option_sets_vs_oracle(cfg, dims):
-    """uvic_gpu_set_mobi_opt + uvic_gpu_mobi (the general column kernel) against the run-time-flag oracle."""
+def test_gpu_sources_of_the_other_option_sets_vs_oracle(cfg, dims, team):
+    """uvic_gpu_set_mobi_opt + uvic_gpu_mobi against the run-time-flag oracle: the four-wave-team kernels of
+    csrc/kernels_mobi_gt.hpp (the default) and the one-thread-per-column kernel of kernels_mobi_gen.hpp (the cross-check)."""
     from uvic29_amd.tracer import TracerModel
     oc = synthetic.make_ocean(cfg, *dims)
     prm = _table(cfg, dims[2])
@@ -131,6 +133,7 @@ def test_gpu_sources_of_the_other_option_sets_vs_oracle(cfg, dims):
     want = mobi_gen_c.mobi_sources(oc, prm, oc.t_taum1, 2 * oc.params.dtts)
     m = TracerModel(*dims, oc.cfg.nt, oc.cfg.nsrc, oc.cfg.ntnpzd)
     m.load_ocean(oc, to, so, c)
+    m.set_option("mobi_team", 1 if team else 0)
     m.set_mobi(oc)
     m.mobi()
     got = m.download("src")

@@ -29,7 +29,7 @@ def test_slices_cover_all_tracers():
             assert seen == list(range(nt))
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, nt=5):
     for p in (ROOT, ROOT / "oracle", ROOT / "tests" / "hostemu"):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,8 +38,7 @@ def _worker(rank, world, port, out_path):
     from uvic29_amd import performance_set, synthetic
     from uvic29_amd.parallel import TracerShard
     import emu
-    nt = 5                                   # pads to 6 on two ranks
-    shard = TracerShard(nt, world, rank)
+    shard = TracerShard(nt, world, rank)     # (nt = 5 pads to 6 on two ranks, nt = 30 to 32 on eight)
     oc = synthetic.make_ocean(performance_set(nt), 14, 14, 6)
     oc = synthetic.pad_tracers(oc, shard.nt_model)
     to, so, c = synthetic.load_eos(6)
@@ -59,15 +58,16 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_rank_tracer_shard_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("world,nt,port", [(2, 5, 29511), (8, 30, 29531)])   # (8 x nt = 30: BASELINE config 4 as worded)
+def test_tracer_shards_equal_single_rank(tmp_path, world, nt, port):
     sys.path.insert(0, str(ROOT / "tests" / "hostemu"))
     from uvic29_amd import performance_set, synthetic
+    from uvic29_amd.parallel import padded_nt
     import emu
-    world = 2
     out = str(tmp_path / "shard")
-    mp.spawn(_worker, args=(world, 29511, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, nt), nprocs=world, join=True)
     # single-rank reference with the same padded tracer dimension
-    oc = synthetic.pad_tracers(synthetic.make_ocean(performance_set(5), 14, 14, 6), 6)
+    oc = synthetic.pad_tracers(synthetic.make_ocean(performance_set(nt), 14, 14, 6), padded_nt(nt, world))
     to, so, c = synthetic.load_eos(6)
     rng = np.random.default_rng(11)
     src = np.asfortranarray(rng.standard_normal((14, 6, 14, oc.cfg.nsrc)) * 1e-9 * oc.topo.tmask[..., None])
@@ -94,7 +94,7 @@ def _slab_steps(em, js, je, exchange):
     return em.a["t_tau"]
 
 
-def _slab_worker(rank, world, port, out_path):
+def _slab_worker(rank, world, port, out_path, jmt=14):
     for p in (ROOT, ROOT / "oracle", ROOT / "tests" / "hostemu"):
         sys.path.insert(0, str(p))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -103,10 +103,10 @@ def _slab_worker(rank, world, port, out_path):
     from uvic29_amd import performance_set, synthetic
     from uvic29_amd.parallel import HALO, slab_rows
     import emu
-    oc = synthetic.make_ocean(performance_set(3), 14, 14, 6)
+    oc = synthetic.make_ocean(performance_set(3), 14, jmt, 6)
     to, so, c = synthetic.load_eos(6)
     em = emu.EmuOcean(oc, to, so, c)
-    js, je = slab_rows(14, world, rank)
+    js, je = slab_rows(jmt, world, rank)
 
     def exchange(tp):                      # tp (imt,km,jmt,nt), F order; rows are axis 2
         ws, bufs = [], []
@@ -128,20 +128,20 @@ def _slab_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_two_latitude_slabs_equal_single_rank(tmp_path):
+@pytest.mark.parametrize("world,jmt,port", [(2, 14, 29517), (8, 98, 29537)])   # (8 slabs of 12 rows: the thinnest legal slab)
+def test_latitude_slabs_equal_single_rank(tmp_path, world, jmt, port):
     sys.path.insert(0, str(ROOT / "tests" / "hostemu"))
     from uvic29_amd import performance_set, synthetic
     from uvic29_amd.parallel import slab_rows
     import emu
-    world = 2
     out = str(tmp_path / "slab")
-    mp.spawn(_slab_worker, args=(world, 29517, out), nprocs=world, join=True)
-    oc = synthetic.make_ocean(performance_set(3), 14, 14, 6)
+    mp.spawn(_slab_worker, args=(world, port, out, jmt), nprocs=world, join=True)
+    oc = synthetic.make_ocean(performance_set(3), 14, jmt, 6)
     to, so, c = synthetic.load_eos(6)
-    ref = _slab_steps(emu.EmuOcean(oc, to, so, c), 2, 13, lambda tp: None)
+    ref = _slab_steps(emu.EmuOcean(oc, to, so, c), 2, jmt - 1, lambda tp: None)
     assert np.isfinite(ref).all()
     for r in range(world):
-        js, je = slab_rows(14, world, r)
+        js, je = slab_rows(jmt, world, r)
         got = np.load(f"{out}.{r}.npy")
         assert np.array_equal(got[:, :, js - 1:je], ref[:, :, js - 1:je]), r
     assert slab_rows(102, 8, 0) == (2, 14) and slab_rows(102, 8, 7)[1] == 101

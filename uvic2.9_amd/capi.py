@@ -45,6 +45,7 @@ EXPORTS = [
     "uvic_gpu_profile", "uvic_gpu_profile_live", "uvic_gpu_profile_read", "uvic_gpu_step_async", "uvic_gpu_step_pre_async", "uvic_gpu_convect_async", "uvic_gpu_set_mobi", "uvic_gpu_set_mobi_opt", "uvic_gpu_mobi_options_flat", "uvic_gpu_set_mobi_flat", "uvic_gpu_mobi", "uvic_gpu_prefetch_sources",
     "uvic_gpu_set_mixing", "uvic_gpu_set_exact", "uvic_gpu_adv_vel", "uvic_gpu_set_vmix_params", "uvic_gpu_vmixc", "uvic_gpu_set_filter", "uvic_gpu_prefetch_isopyc",
     "uvic_gpu_step_lookahead", "uvic_gpu_download_level", "uvic_gpu_set_mobi_step", "uvic_gpu_pin_host", "uvic_gpu_halo_elems", "uvic_gpu_halo_buffer", "uvic_gpu_halo_pack", "uvic_gpu_halo_unpack",
+    "uvic_gpu_push_setup", "uvic_gpu_push_export", "uvic_gpu_push_open", "uvic_gpu_push_exchange",
     "uvic_gpu_step_lookahead_at", "uvic_gpu_prefetch_sources_at", "uvic_gpu_set_host_sync", "uvic_gpu_sbc_config",
     "uvic_gpu_sbc_transfer", "uvic_gpu_overlay_step",
     "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
@@ -161,6 +162,10 @@ def load():
     lib.uvic_gpu_halo_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.uvic_gpu_halo_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.uvic_gpu_push_setup.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.uvic_gpu_push_export.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.uvic_gpu_push_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.uvic_gpu_push_exchange.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                           ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     _lib = lib

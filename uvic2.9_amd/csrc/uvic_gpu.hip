@@ -732,6 +732,44 @@ __global__ void __launch_bounds__(256) k_halo_rows(double *t, double *stage, int
   if (dir == 0) stage[gid] = *cell; else *cell = stage[gid];
 }
 
+// -- direct push between the ranks of a node (uvic_gpu_push_*).  Every rank owns a receive window and a
+// row of arrival counters in uncached device memory; its peers map both through hipIpc and write them with their own
+// kernels, so the data crosses xGMI once, on the link between the two ranks, with no collective library in the path.
+#define UVIC_PUSH_MAX 64
+struct PushTargets {
+  int n;
+  double *dst[8];
+  unsigned long long *flag[8];
+};
+// the rank's contiguous slice of t(tau+1), to up to 8 peers at once (blockIdx.y = peer: every link is driven together)
+__global__ void __launch_bounds__(256) k_push_slice(const double2 *src, const PushTargets tg, long long n2) {
+  double2 *dst = (double2 *)tg.dst[blockIdx.y];
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (long long)gridDim.x * blockDim.x) dst[q] = src[q];
+}
+// ... a kernel boundary later (the payload has left the chip), the peers' arrival counters
+__global__ void k_push_raise(const PushTargets tg, unsigned long long seq) {
+  if ((int)threadIdx.x < tg.n) __hip_atomic_store(tg.flag[threadIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wait until the counters named by `mask` (bit r: rank r or side r) have reached `seq`; gives up after `ticks` of the
+// 100 MHz wall clock and says so in *err, so that a lost peer ends in an error at the next sync, not in a hung GPU
+__global__ void k_push_wait(const unsigned long long *flags, unsigned long long mask, unsigned long long seq, long long ticks, int *err) {
+  const int r = threadIdx.x;
+  if (!((mask >> r) & 1ull)) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    if (wall_clock64() - t0 > ticks) { *err = r + 1; return; }
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+// the slices of the other ranks, window -> t(tau+1) (same layout: slice r at r * per)
+__global__ void __launch_bounds__(256) k_push_take(double2 *t, const double2 *win, long long per2, int world, int rank) {
+  const long long n2 = per2 * (world - 1);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n2; q += (long long)gridDim.x * blockDim.x) {
+    const long long g = q < per2 * rank ? q : q + per2;
+    t[g] = win[g];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -835,6 +873,21 @@ struct uvic_gpu {
   std::vector<void *> land_zeroed;
   // latitude-slab halo staging (uvic_gpu_halo_*): send south/north, receive south/north, each UVIC_HALO rows of every tracer
   double *halo[4];
+  // direct push (uvic_gpu_push_*): the receive window [2 parities][slots][slot_elems], the arrival counters [slots],
+  // and what the peers have let this rank map of theirs
+  struct {
+    int world = 0, rank = 0, mode = 0;
+    double *window = nullptr;
+    unsigned long long *flags = nullptr;
+    size_t slot_elems = 0;
+    int slots = 0;
+    double *peer_window[UVIC_PUSH_MAX] = {};
+    unsigned long long *peer_flags[UVIC_PUSH_MAX] = {};
+    bool mapped[UVIC_PUSH_MAX] = {};     // opened through hipIpc (to be closed), as opposed to the rank's own
+    unsigned long long seq = 0;
+    int *err = nullptr;                  // pinned host word the wait kernel writes when it gives up
+    double wait_ms = 2000.0;
+  } push;
   // source buffers known to hold zeros on land (MOBI writes ocean columns only): see src_clean()
   std::vector<void *> src_zeroed;
   uvic_ctx ctx;
@@ -1038,6 +1091,7 @@ extern "C" int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value) {
   if (n == "mobi_team") { h->mobi_team = value != 0; return 0; }         // 0: one thread per column instead of four-wave teams
   if (n == "convect_onepass") { h->exact_convect = value != 0; return 0; }   // convct2 as one kernel over all tracers
   if (n == "mobi_streams") { h->mobi_two_streams = value != 1 && h->side_m[1] != h->side_m[0]; return 0; }   // 1: every MOBI chain on the first side stream
+  if (n == "push_wait_ms") { h->push.wait_ms = value > 0 ? value : 2000.0; return 0; }   // how long an exchange waits for a peer before it reports it lost
   return fail_msg("uvic_gpu_set_option: unknown option " + n);
 }
 extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device) {
@@ -1183,6 +1237,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   return 0;
 }
 
+static void push_release(uvic_gpu *h);
 extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
@@ -1195,6 +1250,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->wet_dev);
   (void)hipFree(h->lanes_dev);
   for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
+  push_release(h);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   (void)hipFree(h->fltu_items);
@@ -2652,6 +2708,138 @@ extern "C" int uvic_gpu_halo_unpack(uvic_gpu *h, int south, int north) {
   if (north) if (int rc = halo_move(h, 3, h->ctx.je + 1, 1)) return rc;
   return 0;
 }
+// -- direct push: the exchange of t(tau+1) after a step without a collective library.  Setup, once:
+//   uvic_gpu_push_setup(world, rank, mode)   mode 1 tracer shards (every rank's slice to every other rank),
+//                                            mode 2 latitude slabs (UVIC_HALO edge rows to the two neighbours)
+//   uvic_gpu_push_export(handles)            2 x 64 bytes (hipIpcMemHandle_t of the window and of the counters) to hand to the peers
+//   uvic_gpu_push_open(peer, handles)        what `peer` exported (its own rank: no mapping, the rank's own window)
+// then per step uvic_gpu_push_exchange() on the main stream, where the RCCL collective would stand.
+static_assert(sizeof(hipIpcMemHandle_t) == 64, "uvic_gpu_push_export hands out 2 x 64 bytes");
+static void push_release(uvic_gpu *h) {
+  for (int r = 0; r < UVIC_PUSH_MAX; ++r) {
+    if (h->push.mapped[r]) { (void)hipIpcCloseMemHandle(h->push.peer_window[r]); (void)hipIpcCloseMemHandle(h->push.peer_flags[r]); }
+    h->push.mapped[r] = false; h->push.peer_window[r] = nullptr; h->push.peer_flags[r] = nullptr;
+  }
+  (void)hipFree(h->push.window); (void)hipFree(h->push.flags); (void)hipHostFree(h->push.err);
+  h->push.window = nullptr; h->push.flags = nullptr; h->push.err = nullptr; h->push.mode = 0; h->push.seq = 0;
+}
+extern "C" int uvic_gpu_push_setup(uvic_gpu *h, int world, int rank, int mode) {
+  if (!h) return fail_msg("null handle");
+  if (world < 1 || world > UVIC_PUSH_MAX || rank < 0 || rank >= world) return fail_msg("uvic_gpu_push_setup: rank outside the world, or more than 64 ranks");
+  if (mode != 1 && mode != 2) return fail_msg("uvic_gpu_push_setup: mode is 1 (tracer shards) or 2 (latitude slabs)");
+  if (mode == 1 && h->d.nt % world) return fail_msg("uvic_gpu_push_setup: tracer shards need nt padded to a multiple of the world size");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = uvic_gpu_sync(h)) return rc;
+  push_release(h);
+  h->push.world = world; h->push.rank = rank; h->push.mode = mode;
+  h->push.slots = mode == 1 ? world : 2;
+  h->push.slot_elems = mode == 1 ? (size_t)h->d.imt * h->d.km * h->d.jmt * (h->d.nt / world) : (size_t)uvic_gpu_halo_elems(h);
+  // uncached: written by another device (or another process), read here one kernel boundary after the counter says so
+  const size_t wbytes = 2 * h->push.slots * h->push.slot_elems * 8, fbytes = UVIC_PUSH_MAX * sizeof(unsigned long long);
+  HIPCHK(hipExtMallocWithFlags((void **)&h->push.window, wbytes, hipDeviceMallocUncached));
+  HIPCHK(hipExtMallocWithFlags((void **)&h->push.flags, fbytes, hipDeviceMallocUncached));
+  HIPCHK(hipMemset(h->push.window, 0, wbytes));
+  HIPCHK(hipMemset(h->push.flags, 0, fbytes));
+  HIPCHK(hipHostMalloc((void **)&h->push.err, sizeof(int), hipHostMallocDefault));
+  *h->push.err = 0;
+  return 0;
+}
+extern "C" int uvic_gpu_push_export(uvic_gpu *h, void *handles) {
+  if (!h || !handles) return fail_msg("uvic_gpu_push_export: null argument");
+  if (!h->push.mode) return fail_msg("uvic_gpu_push_export: uvic_gpu_push_setup first");
+  hipIpcMemHandle_t hw, hf;
+  HIPCHK(hipIpcGetMemHandle(&hw, h->push.window));
+  HIPCHK(hipIpcGetMemHandle(&hf, h->push.flags));
+  memcpy(handles, &hw, 64);
+  memcpy((char *)handles + 64, &hf, 64);
+  return 0;
+}
+extern "C" int uvic_gpu_push_open(uvic_gpu *h, int peer, const void *handles) {
+  if (!h) return fail_msg("null handle");
+  if (!h->push.mode) return fail_msg("uvic_gpu_push_open: uvic_gpu_push_setup first");
+  if (peer < 0 || peer >= h->push.world) return fail_msg("uvic_gpu_push_open: peer outside the world");
+  if (h->push.peer_window[peer]) return fail_msg("uvic_gpu_push_open: peer already open");
+  if (peer == h->push.rank) {   // a rank that is its own neighbour (cyclic tests at world size 1): no mapping
+    h->push.peer_window[peer] = h->push.window; h->push.peer_flags[peer] = h->push.flags;
+    return 0;
+  }
+  if (!handles) return fail_msg("uvic_gpu_push_open: null handles");
+  HIPCHK(hipSetDevice(h->device));
+  hipIpcMemHandle_t hw, hf;
+  memcpy(&hw, handles, 64);
+  memcpy(&hf, (const char *)handles + 64, 64);
+  void *w = nullptr, *f = nullptr;
+  HIPCHK(hipIpcOpenMemHandle(&w, hw, hipIpcMemLazyEnablePeerAccess));
+  if (hipError_t e = hipIpcOpenMemHandle(&f, hf, hipIpcMemLazyEnablePeerAccess)) { (void)hipIpcCloseMemHandle(w); return fail("hipIpcOpenMemHandle", e, __LINE__); }
+  h->push.peer_window[peer] = (double *)w; h->push.peer_flags[peer] = (unsigned long long *)f; h->push.mapped[peer] = true;
+  return 0;
+}
+// One exchange, queued on the main stream: push to the peers' windows (parity seq & 1: a peer may run one exchange
+// ahead of this rank, never two, because its next push waits for this rank's), raise their counters, wait for this
+// rank's own, take what has arrived.  south/north: the neighbour ranks of a slab (-1: none); ignored for tracer shards.
+extern "C" int uvic_gpu_push_exchange(uvic_gpu *h, int south, int north) {
+  if (!h) return fail_msg("null handle");
+  h->idle_until_next = false;   // something is queued on the main stream between two steps
+  auto &P = h->push;
+  if (!P.mode) return fail_msg("uvic_gpu_push_exchange: uvic_gpu_push_setup first");
+  const unsigned long long seq = ++P.seq;
+  const size_t half = (size_t)P.slots * P.slot_elems, par = (seq & 1) * half;
+  const long long ticks = (long long)(P.wait_ms * 1e5);
+  double *tp = (double *)h->buf[UVIC_F_T_TAUP1];
+  unsigned long long mask = 0;
+  if (P.mode == 2) {
+    const int peer[2] = {south, north};
+    const int rowlen = h->d.imt * h->d.km;
+    const long long n = (long long)UVIC_HALO * rowlen * h->d.nt;
+    PushTargets tg; tg.n = 0;
+    for (int side = 0; side < 2; ++side) {
+      const int p = peer[side];
+      if (p < 0) continue;
+      if (p >= P.world || !P.peer_window[p]) return fail_msg("uvic_gpu_push_exchange: neighbour not open");
+      // the rows this rank sends south arrive in the neighbour's slot 1 ("from the north"), and the other way round
+      double *dst = P.peer_window[p] + par + (size_t)(1 - side) * P.slot_elems;
+      const int j0 = side == 0 ? h->ctx.js : h->ctx.je - UVIC_HALO + 1;
+      hipLaunchKernelGGL(k_halo_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, tp, dst, rowlen, h->d.jmt, h->d.nt, j0, UVIC_HALO, 0);
+      tg.flag[tg.n++] = P.peer_flags[p] + (1 - side);
+      mask |= 1ull << side;
+    }
+    if (!tg.n) return 0;
+    hipLaunchKernelGGL(k_push_raise, dim3(1), dim3(64), 0, h->stream, tg, seq);
+    hipLaunchKernelGGL(k_push_wait, dim3(1), dim3(64), 0, h->stream, P.flags, mask, seq, ticks, P.err);
+    for (int side = 0; side < 2; ++side) {
+      if (peer[side] < 0) continue;
+      const int j0 = side == 0 ? h->ctx.js - UVIC_HALO : h->ctx.je + 1;
+      if (j0 < 1 || j0 + UVIC_HALO - 1 > h->d.jmt) return fail_msg("uvic_gpu_push_exchange: halo rows outside 1..jmt");
+      hipLaunchKernelGGL(k_halo_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, tp, P.window + par + (size_t)side * P.slot_elems,
+                         rowlen, h->d.jmt, h->d.nt, j0, UVIC_HALO, 1);
+    }
+  } else {
+    if (P.world == 1) return 0;
+    const long long per2 = (long long)(P.slot_elems / 2);
+    if (P.slot_elems & 1) return fail_msg("uvic_gpu_push_exchange: odd slice length");
+    const double2 *mine = (const double2 *)(tp + (size_t)P.rank * P.slot_elems);
+    for (int p0 = 0; p0 < P.world; p0 += 8) {
+      PushTargets tg; tg.n = 0;
+      for (int p = p0; p < P.world && p < p0 + 8; ++p) {
+        if (p == P.rank) continue;
+        if (!P.peer_window[p]) return fail_msg("uvic_gpu_push_exchange: peer not open");
+        tg.dst[tg.n] = P.peer_window[p] + par + (size_t)P.rank * P.slot_elems;
+        tg.flag[tg.n++] = P.peer_flags[p] + P.rank;
+        mask |= 1ull << p;
+      }
+      if (!tg.n) continue;
+      const unsigned nb = (unsigned)std::min<long long>((per2 + 255) / 256, 2048 / tg.n + 1);
+      hipLaunchKernelGGL(k_push_slice, dim3(nb, tg.n), dim3(256), 0, h->stream, mine, tg, per2);
+      hipLaunchKernelGGL(k_push_raise, dim3(1), dim3(64), 0, h->stream, tg, seq);
+    }
+    hipLaunchKernelGGL(k_push_wait, dim3(1), dim3(64), 0, h->stream, P.flags, mask, seq, ticks, P.err);
+    const long long n2 = per2 * (P.world - 1);
+    hipLaunchKernelGGL(k_push_take, dim3((unsigned)std::min<long long>((n2 + 255) / 256, 4096)), dim3(256), 0, h->stream, (double2 *)tp,
+                       (const double2 *)(P.window + par), per2, P.world, P.rank);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   h->step_begun = false;
@@ -2686,6 +2874,12 @@ extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   HIPCHK(hipStreamSynchronize(h->side2));
   HIPCHK(hipStreamSynchronize(h->side_ts));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->push.err && *h->push.err) {
+    const int who = *h->push.err - 1;
+    *h->push.err = 0;
+    return fail_msg("uvic_gpu_push_exchange: nothing arrived from " + (h->push.mode == 2 ? std::string(who ? "the north" : "the south") : "rank " + std::to_string(who)) +
+                    " within the waiting time: t(tau+1) is incomplete");
+  }
   return 0;
 }
 

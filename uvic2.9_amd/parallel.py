@@ -50,13 +50,68 @@ class _DevArray:
                                          "strides": None}
 
 
+def open_direct_push(model, world: int, rank: int, mode: int, peers=None) -> bool:
+    """Set up the library's direct push (include/uvic_gpu.h uvic_gpu_push_*): every rank exports the hipIpc handles
+    of its receive window and arrival counters, the handles go round through torch.distributed (128 bytes per rank,
+    once), and each rank maps those of the peers it writes to.  True if EVERY rank succeeded -- the ranks agree, so
+    that all of them take the same path afterwards; on False the caller keeps the RCCL exchange."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    ok, mine = 1, bytes(128)
+    if model.lib.uvic_gpu_push_setup(model.h, world, rank, mode) == 0:
+        buf = ctypes.create_string_buffer(128)
+        if model.lib.uvic_gpu_push_export(model.h, buf) == 0:
+            mine = buf.raw
+        else:
+            ok = 0
+    else:
+        ok = 0
+    everyone = [None] * world
+    dist.all_gather_object(everyone, (ok, mine))
+    if not all(o for o, _ in everyone):
+        return False
+    for peer in (range(world) if peers is None else peers):
+        if peer == rank and peers is None:
+            continue
+        if model.lib.uvic_gpu_push_open(model.h, peer, everyone[peer][1]) != 0:
+            ok = 0
+            break
+    agreed = [None] * world
+    dist.all_gather_object(agreed, ok)
+    if not all(agreed):
+        return False
+    # one exchange of whatever t(tau+1) holds now (the step's own exchange overwrites it), waited for: a link that maps
+    # but does not deliver shows up here, before anything is measured or trusted
+    if mode == 2:
+        ok = int(model.lib.uvic_gpu_push_exchange(model.h, rank - 1 if rank > 0 else -1, rank + 1 if rank + 1 < world else -1) == 0)
+    else:
+        ok = int(model.lib.uvic_gpu_push_exchange(model.h, -1, -1) == 0)
+    ok = int(ok and model.lib.uvic_gpu_sync(model.h) == 0)
+    dist.all_gather_object(agreed, ok)
+    return all(agreed)
+
+
 class TracerShard:
-    def __init__(self, nt: int, world: int = 1, rank: int = 0):
+    def __init__(self, nt: int, world: int = 1, rank: int = 0, exchange: str = "rccl"):
+        """exchange: "rccl" (torch.distributed collective), "push" (the library's direct push; an error if it cannot
+        be set up), "auto" (push if every rank can set it up, else rccl)."""
         self.nt, self.world, self.rank = nt, world, rank
         self.nt_model = padded_nt(nt, world) if world > 1 else nt
         self.n0, self.nt_local, self.chunk = slice_of(nt, world, rank)
         self._views = {}
         self._stream = None
+        self.exchange_kind = exchange
+        self.pushing = None        # decided at the first exchange
+
+    def _decide(self, model):
+        if self.pushing is None:
+            self.pushing = False
+            if self.exchange_kind in ("push", "auto") and self.world > 1:
+                self.pushing = open_direct_push(model, self.world, self.rank, 1)
+                if not self.pushing and self.exchange_kind == "push":
+                    raise RuntimeError("direct push could not be set up on every rank: " + model.last_error())
+        return self.pushing
 
     def apply(self, model):
         model.set_shard(n0=self.n0, nt_local=self.nt_local)
@@ -87,6 +142,10 @@ class TracerShard:
         """All-gather of t(:,:,:,slice,tau+1), in place on the device buffer, on the library's stream."""
         import torch
         import torch.distributed as dist
+        from .capi import check
+        if self._decide(model):
+            check(model.lib.uvic_gpu_push_exchange(model.h, -1, -1), "push_exchange")
+            return
         if self._stream is None:
             self._stream = torch.cuda.ExternalStream(model.lib.uvic_gpu_stream(model.h), device=f"cuda:{model.device}")
         full = self._tensor(model, "t_taup1")
@@ -119,8 +178,10 @@ def slab_rows(jmt: int, world: int, rank: int):
 class SlabShard:
     """Latitude-slab decomposition with a 2-row halo exchange of t(tau+1) per step."""
 
-    def __init__(self, jmt: int, world: int = 1, rank: int = 0):
+    def __init__(self, jmt: int, world: int = 1, rank: int = 0, exchange: str = "rccl"):
         self.jmt, self.world, self.rank = jmt, world, rank
+        self.exchange_kind = exchange   # "rccl" | "push" | "auto", as for TracerShard
+        self.pushing = None
         self.js, self.je = slab_rows(jmt, world, rank)
         if world > 1 and self.je - self.js + 1 < HALO:
             raise ValueError(f"slab of {self.je - self.js + 1} rows is thinner than the halo ({HALO}): use fewer ranks")
@@ -207,6 +268,19 @@ class SlabShard:
         if self.world == 1:
             return
         import torch
+        if self.pushing is None:
+            self.pushing = False
+            if self.exchange_kind in ("push", "auto"):
+                near = [r for r in (self.rank - 1, self.rank + 1) if 0 <= r < self.world]
+                self.pushing = open_direct_push(model, self.world, self.rank, 2, peers=near)
+                if not self.pushing and self.exchange_kind == "push":
+                    raise RuntimeError("direct push could not be set up on every rank: " + model.last_error())
+        if self.pushing:
+            from .capi import check
+            south = self.rank - 1 if self.rank > 0 else -1
+            north = self.rank + 1 if self.rank + 1 < self.world else -1
+            check(model.lib.uvic_gpu_push_exchange(model.h, south, north), "push_exchange")
+            return
         if self._stream is None:
             self._stream = torch.cuda.ExternalStream(model.lib.uvic_gpu_stream(model.h), device=f"cuda:{model.device}")
         with torch.cuda.stream(self._stream):

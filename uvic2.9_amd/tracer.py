@@ -311,6 +311,9 @@ class TracerModel:
         """cross-check and tuning switches of the library (include/uvic_gpu.h: uvic_gpu_set_option)"""
         check(self.lib.uvic_gpu_set_option(self.h, name.encode(), int(value)), f"set_option {name}")
 
+    def last_error(self):
+        return self.lib.uvic_gpu_last_error().decode()
+
     def set_mixing(self, on):
         check(self.lib.uvic_gpu_set_mixing(self.h, 1 if on else 0), "set_mixing")
 
