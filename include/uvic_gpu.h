@@ -335,6 +335,15 @@ typedef struct uvic_overlay_step {
   int32_t mixing, mobi_ahead, iso_ahead, sbc_zero, sbc_accumulate, pad;
 } uvic_overlay_step;
 int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_host);
+/* The inputs `tracer` reads from the memory window on every step (mw.h: adv_vet, adv_vnt, adv_vbt; vmixc.h: diff_cbt;
+ * csbc/mw.h: stf, btf) in one call, for a caller that keeps t on the device: replaces six uvic_gpu_upload_rows.  Host
+ * arrays as the window holds them -- adv_vet (imt,km,jsmw:jmt), adv_vnt (imt,km,1:jmt), adv_vbt (imt,0:km,jsmw:jmt),
+ * diff_cbt (imt,km,jsmw:jemw), stf and btf (imt,jmt,nt) -- page-locked (uvic_gpu_pin_host) and left alone until the
+ * step's uvic_gpu_overlay_step returns.  The copies run beside the main stream into the device copy the previous step
+ * does not read, what T and S need first; the step waits for each group where it reads it.  adv_vbt may be null: it is
+ * then formed on the device from adv_vet and adv_vnt as source/mom/adv_vel.F:98-127 does (rigid lid, zero at the surface). */
+int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
+                            const double *diff_cbt, const double *stf, const double *btf);
 /* latitude-slab decomposition (uvic_gpu_set_shard js..je): the two outermost owned rows of t(tau+1) of every tracer
  * go to the neighbour's halo after each step (reach of the FCT stencil, u09/mom/tracer_adv_flx.F:553-555).  The library
  * packs them into contiguous staging buffers and unpacks what was received, both on its main stream; the caller moves

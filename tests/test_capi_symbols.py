@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 20
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/uvic_gpu.h but not exported"
-    assert lib.uvic_gpu_abi_version() == 10
+    assert lib.uvic_gpu_abi_version() == 11
 
 
 def test_field_table_matches_header():

@@ -39,11 +39,15 @@ print(f"overlay tracer call, {'resident' if os.environ.get('UVIC_RESIDENT') == '
       f"(PCIe included)")
 # the calls alone, back to back (the device never idles)
 t0 = time.perf_counter()
+each = []
 for k in range(n):
     it += 1
     shim.ref.set("itt", it)
     shim.ref.set("osegs", 1 if (it - 1) % seg == 0 else 0)
     shim.ref.set("osege", 1 if it % seg == 0 else 0)
+    t1 = time.perf_counter()
     shim.tracer()        # (no host rotation here: the harness rotates by copying 2 x 47 MB, the model by permuting indices)
+    each.append(time.perf_counter() - t1)
 el = time.perf_counter() - t0
-print(f"back to back: {el / n * 1e3:.3f} ms per step")
+print(f"back to back: {el / n * 1e3:.3f} ms per step; calls by position in the segment (ms): "
+      + ", ".join(f"{sum(each[q::seg]) / len(each[q::seg]) * 1e3:.3f}" for q in range(seg)) + f"; slowest {max(each) * 1e3:.3f}")

@@ -193,6 +193,49 @@ __global__ void __launch_bounds__(256) k_vmixc(const uvic_ctx c) {
   if (j < 2 || j > c.jmt - 1 || i < 2 || i > c.imt - 1) return;
   vmixc_cell(c, i, k, j);
 }
+// What a step whose T,S-derived fields were computed ahead has to do once its inputs have arrived from the host
+// (uvic_gpu_overlay_inputs without adv_vbt): adv_vbt by continuity (adv_vel_vert_column), the total velocities
+// (k_tot_vel) and the vertical-diffusion coefficient from the step's diff_cbt (coef_bv_cell) -- three short kernels of
+// the T,S chain, each ~10 us of launch latency plus a walk down the column -- as one cell-parallel kernel: every cell sums
+// the divergences of the levels above it itself, in the order of the downward integration (the same bits, ~km/2 extra
+// cached loads per cell instead of a serial walk); i = 1 and imt sum their cyclic images.
+__global__ void __launch_bounds__(256) k_inputs_cell(const uvic_ctx c, double *cf) {
+  if (c.prio & 4) __builtin_amdgcn_s_setprio(3);
+  CELL_DECODE(c);
+  if (j > c.jmt) return;
+  const int imt = c.imt, km = c.km, jmt = c.jmt;
+  const size_t N3 = (size_t)imt * km * jmt;
+  const long long rowstride = (long long)imt * km;
+  const int is = (i == 1) ? imt - 1 : ((i == imt) ? 2 : i);
+  double *vbt = const_cast<double *>(c.adv_vbt);
+  const size_t f0 = (size_t)(i - 1) + (size_t)imt * ((size_t)(km + 1) * (j - 1));   // face 0 of the column
+  const size_t q = (size_t)gid, fq = f0 + (size_t)imt * k;
+  double acc;
+  if (j >= 2) {
+    const double dx = c.dxtr[is - 1], dy = c.dytr[j - 1], cs = c.cstr[j - 1];
+    size_t qs = (size_t)(is - 1) + (size_t)imt * ((size_t)km * (j - 1));
+    acc = 0.0;
+    for (int kk = 1; kk <= k; ++kk, qs += imt) {
+      const double div = ((c.adv_vet[qs] - c.adv_vet[qs - 1]) * dx + (c.adv_vnt[qs] - c.adv_vnt[qs - rowstride]) * dy) * cs * c.dzt[kk - 1];
+      acc = div + acc;
+    }
+    vbt[fq] = acc;
+    if (k == 1) { vbt[f0] = 0.0; c.tot_b[f0] = 0.0 + c.adv_vbtiso[f0]; }
+  } else {   // row 1: adv_vel leaves adv_vbt alone there
+    acc = vbt[fq];
+    if (k == 1) c.tot_b[f0] = vbt[f0] + c.adv_vbtiso[f0];
+  }
+  const double e = c.adv_vet[q] + c.adv_vetiso[q], n = c.adv_vnt[q] + c.adv_vntiso[q];
+  c.tot_e[q] = e;
+  c.tot_n[q] = n;
+  c.tot_b[fq] = acc + c.adv_vbtiso[fq];
+  cf[CF_IDX(CF_VE, q, N3)] = e;
+  cf[CF_IDX(CF_VN, q, N3)] = n;
+  cf[CF_IDX(CF_VB, q, N3)] = (k < km) ? acc + c.adv_vbtiso[fq] : acc;
+  cf[CF_IDX(CF_VS, q, N3)] = (j >= 2) ? c.adv_vnt[q - rowstride] + c.adv_vntiso[q - rowstride] : 0.0;
+  if (j >= 2 && j <= jmt - 1 && i >= 2 && i <= imt - 1 && !SLAB_OUT(c, j) && k <= km - 1)
+    cf[CF_IDX(CF_BV, q, N3)] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
+}
 // ---- baroclinic momentum step (kernels_clinic.hpp) -----------------------------------
 #define COL_DECODE(m)                                                 \
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;              \
@@ -944,6 +987,23 @@ struct uvic_gpu {
   double *ts_host;              // where T,S of this step's t(tau+1) go (null: nowhere); set for one step by overlay_step
   hipEvent_t ev_ts_host;
   bool ts_host_queued;
+  // the step's inputs from the host (uvic_gpu_overlay_inputs): two device copies of the velocities and fluxes, filled in
+  // turn by copies on streams of their own; a step waits for the group of copies it needs, where it needs it
+  struct {
+    double *set[2][5] = {};       // adv_vet, adv_vnt, adv_vbt, stf, btf
+    int cur = 0;
+    bool used = true;             // a step has been queued on the current set
+    hipStream_t st[2] = {nullptr, nullptr};
+    int nstreams = 2;
+    hipEvent_t ev_first = nullptr, ev_rest = nullptr, ev_link[2] = {nullptr, nullptr};
+    bool first_pending = false, rest_pending = false;   // queued, and the main stream has not been told to wait for them yet
+    bool waited = false;          // this step's main stream began with a wait for them (the T,S stream starts behind it)
+    bool derive_vbt = false;      // adv_vbt was not sent: formed from adv_vet, adv_vnt on the device (adv_vel.F:98-127)
+    hipEvent_t ev_forcing = nullptr;   // MOBI's light, ice and snow fields of the segment, copied on st[1] (uvic_gpu_set_mobi_step)
+    bool forcing_sent = false;
+  } in;
+  bool prep_deferred;             // launch_isopyc left k_inputs_cell (and the wait for the inputs) to launch_transport
+  hipEvent_t ev_src_inline;       // sources of the current step computed on a MOBI side stream (launch_mobi)
   int sbc_count;                // tracers whose surface level is accumulated
   int *sbc_tracer;              // device: their 1-based tracer numbers
   double *sbc_acc;              // device (imt, jmt, sbc_count)
@@ -1010,7 +1070,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 10; }   // 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 11; }   // 11: uvic_gpu_overlay_inputs, uvic_gpu_push_*; 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -1048,6 +1108,7 @@ static void bind_ctx(uvic_gpu *h) {
 static const int ISO_FIELDS[16] = {UVIC_F_ALPHAI, UVIC_F_BETAI, UVIC_F_DDXT, UVIC_F_DDYT, UVIC_F_DDZT, UVIC_F_AI_EZ, UVIC_F_AI_NZ,
                                    UVIC_F_AI_BX, UVIC_F_AI_BY, UVIC_F_K11, UVIC_F_K22, UVIC_F_K33, UVIC_F_ADV_VETISO,
                                    UVIC_F_ADV_VNTISO, UVIC_F_ADV_VBTISO, UVIC_F_DIFF_CBT};
+static const int IN_FIELDS[5] = {UVIC_F_ADV_VET, UVIC_F_ADV_VNT, UVIC_F_ADV_VBT, UVIC_F_STF, UVIC_F_BTF};
 static int make_tmask(uvic_gpu *h);
 static void iso_set_adopt(uvic_gpu *h);
 static void iso_set_release(uvic_gpu *h);
@@ -1091,6 +1152,10 @@ extern "C" int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value) {
   if (n == "mobi_team") { h->mobi_team = value != 0; return 0; }         // 0: one thread per column instead of four-wave teams
   if (n == "convect_onepass") { h->exact_convect = value != 0; return 0; }   // convct2 as one kernel over all tracers
   if (n == "mobi_streams") { h->mobi_two_streams = value != 1 && h->side_m[1] != h->side_m[0]; return 0; }   // 1: every MOBI chain on the first side stream
+  if (n == "upload_streams") {   // copy streams of uvic_gpu_overlay_inputs (before its first call)
+    if (h->in.st[0]) return fail_msg("uvic_gpu_set_option: upload_streams after the first uvic_gpu_overlay_inputs");
+    h->in.nstreams = value == 1 ? 1 : 2; return 0;
+  }
   if (n == "push_wait_ms") { h->push.wait_ms = value > 0 ? value : 2000.0; return 0; }   // how long an exchange waits for a peer before it reports it lost
   return fail_msg("uvic_gpu_set_option: unknown option " + n);
 }
@@ -1103,7 +1168,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   uvic_gpu *h = new uvic_gpu();
   h->d = *dims;
   h->device = device;
-  h->profiling = false;
+  h->profiling = false; h->prep_deferred = false;
   h->have_mobi = false;
   h->have_vmix = false;
   h->tmm_ncols = 0;
@@ -1163,6 +1228,7 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->idle_until_next = false;
   h->ts_waited_begin = -1;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&h->ev_src_inline, hipEventDisableTiming));
   h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_step_end[q], hipEventDisableTiming));
   h->ev_end_ready = h->ev_end_pending = h->ev_step_end[0];
@@ -1243,6 +1309,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipSetDevice(h->device);
   (void)uvic_gpu_sync(h);   // every stream, the momentum side stream included: it may still be copying into a pinned host range
   iso_set_release(h);   // the three sets of T,S-derived fields; clears their views in buf[], work[0..2], coef
+  if (h->in.set[1][0]) for (int q = 0; q < 5; ++q) h->buf[IN_FIELDS[q]] = h->in.set[0][q];   // set 1 is freed below
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
@@ -1251,6 +1318,11 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->lanes_dev);
   for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
   push_release(h);
+  if (h->in.st[0]) {
+    for (int q = 0; q < 5; ++q) (void)hipFree(h->in.set[1][q]);   // (set[0] are the buffers of buf[], freed above)
+    for (int q = 0; q < 2; ++q) { if (h->in.st[q]) (void)hipStreamDestroy(h->in.st[q]); (void)hipEventDestroy(h->in.ev_link[q]); }
+    (void)hipEventDestroy(h->in.ev_first); (void)hipEventDestroy(h->in.ev_rest); (void)hipEventDestroy(h->in.ev_forcing);
+  }
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   (void)hipFree(h->fltu_items);
@@ -1274,6 +1346,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
   for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(h->ev_src_next[q]); (void)hipEventDestroy(h->ev_step_end[q]); }
+  (void)hipEventDestroy(h->ev_src_inline);
   for (void *q : h->pinned) (void)hipHostUnregister(q);
   h->pinned.clear();
   if (h->side_mom) { (void)hipStreamSynchronize(h->side_mom); (void)hipStreamDestroy(h->side_mom); (void)hipEventDestroy(h->ev_mom_in); (void)hipEventDestroy(h->ev_mom_done); }
@@ -1712,6 +1785,8 @@ static unsigned col_blocks(const uvic_gpu *h, int bs) {
 
 // the T,S-derived fields of a step (mixing tensor, GM velocities, folded coefficients): ctx `c` says what is read
 // (t_taum1) and where the products go; `sid` 0 = main stream, 2 = the isopyc side stream
+static int inputs_first(uvic_gpu *h, bool vbt_follows = false);
+static int inputs_rest(uvic_gpu *h);
 static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStream_t st, int sid) {
   mark_on(h, "begin", sid);
   hipLaunchKernelGGL(k_isopyc_elements, dim3(cell_blocks(h, 256)), dim3(256), 0, st, c);
@@ -1728,8 +1803,16 @@ static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStr
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int launch_isopyc(uvic_gpu *h) {
+static int launch_isopyc(uvic_gpu *h, bool may_defer = false) {
   h->iso_waited = false;
+  h->prep_deferred = false;
+  // velocities and diff_cbt queued by uvic_gpu_overlay_inputs: when the fields were computed ahead, one kernel forms
+  // adv_vbt, the total velocities and the vertical-diffusion coefficient from them
+  const int ahead_set = (int)(h->step_no % 3);
+  const bool fuse = h->in.first_pending && h->in.derive_vbt && !h->exact && h->ctx.diff_cbt_given && !h->mixing &&
+                    h->iso_set[ahead_set].for_step == h->step_no && h->iso_set[ahead_set].vel_stale;
+  if (fuse && may_defer) h->in.used = true;   // (the wait goes to the stream that runs k_inputs_cell)
+  else if (int rc = inputs_first(h, fuse)) return rc;
   const int set = (int)(h->step_no % 3);
   if (int rc = use_iso_set(h, set)) return rc;
   if (h->iso_set[set].for_step == h->step_no && h->mixing) {
@@ -1741,6 +1824,15 @@ static int launch_isopyc(uvic_gpu *h) {
     HIPCHK(hipStreamWaitEvent(h->stream, h->iso_set[set].ev, 0));
     h->iso_set[set].for_step = -1;
     h->iso_waited = true;
+    if (fuse) {
+      h->iso_set[set].vel_stale = false;
+      h->iso_waited = false;
+      if (may_defer) { h->prep_deferred = true; return 0; }   // launch_transport puts it at the head of the T,S stream
+      hipLaunchKernelGGL(k_inputs_cell, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
+      mark(h, "inputs_cell");
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     if (h->iso_set[set].vel_stale) {   // this step's velocities arrived after the chain ran
       const long long nf = (long long)h->d.imt * (h->d.km + 1) * h->d.jmt;
       hipLaunchKernelGGL(k_tot_vel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
@@ -1823,7 +1915,40 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   const uvic_ctx &c = h->ctx;
   if (c.nt_local <= 0) return 0;
   if (c.c2dtts == 0.0) return fail_msg("uvic_gpu_transport: c2dtts not set (uvic_gpu_set_params)");
+  // T and S first, on the side stream: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both
+  // passes and the walk run there while the main stream works on the other tracers; the mixed ranges the walk lists are
+  // replayed on those by k_convect_apply_list afterwards (launch_convect).  Not under tracer sharding, where convection
+  // follows the exchange.
+  const bool split = !h->exact && convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 && h->ts_no_src;
+  bool ts_stream_ready = false;
+  if (h->prep_deferred) {
+    // the inputs have been queued beside the main stream and the T,S-derived fields were computed ahead: what is left to
+    // form from them (k_inputs_cell) goes to the head of the stream whose chain the host waits for -- one hop between
+    // streams less on it (a hop costs ~25 us); the other stream follows by an event
+    h->prep_deferred = false;
+    hipStream_t st = split && h->step_begun ? h->side_ts : h->stream;
+    const int sid = st == h->stream ? 0 : 3;
+    if (st != h->stream) {
+      HIPCHK(hipStreamWaitEvent(st, h->ev_begin_cur, 0));
+      h->ts_waited_begin = h->step_no;
+      if (h->iso_set[h->iso_cur].st != st) HIPCHK(hipStreamWaitEvent(st, h->iso_set[h->iso_cur].ev, 0));
+    }
+    HIPCHK(hipStreamWaitEvent(st, h->in.ev_first, 0));
+    h->in.first_pending = false; h->in.waited = true;
+    uvic_ctx cp = c;
+    cp.prio |= 4;
+    mark_on(h, "begin", sid);
+    hipLaunchKernelGGL(k_inputs_cell, dim3(cell_blocks(h, 256)), dim3(256), 0, st, cp, h->coef);
+    mark_on(h, "inputs_cell", sid);
+    if (st != h->stream) {
+      HIPCHK(hipEventRecord(h->ev_fct_done, st));
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fct_done, 0));
+      ts_stream_ready = true;
+    }
+  }
+  if (int rc = inputs_first(h)) return rc;
   if (h->exact) {
+    if (int rc = inputs_rest(h)) return rc;
     mark(h, "begin");
     if (int rc = launch_rows(h, c, h->stream, 0, nullptr, "fct_rows", "update_rows")) return rc;
     return launch_tsi_rows(h, c, h->stream, 0);
@@ -1866,15 +1991,12 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       mark_on(h, "colupd_ts", sid);
     }
   };
-  // T and S first, on the side stream: they have no source terms, and their t(tau+1) is all the convective walk needs.  Both
-  // passes and the walk run there while the main stream works on the other tracers; the mixed ranges the walk lists are
-  // replayed on those by k_convect_apply_list afterwards (launch_convect).  Not under tracer sharding, where convection
-  // follows the exchange.
-  const bool split = convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 && h->ts_no_src;
   if (split) {
     // the side stream may start when the previous step is complete and this step's T,S-derived fields are: both
     // have events already when the fields came from the look-ahead chain (no extra packet on the main stream)
-    if (h->iso_waited && h->step_begun) {
+    if (ts_stream_ready) {
+      // (k_inputs_cell ran at its head, behind the same events)
+    } else if (h->iso_waited && h->step_begun && !h->in.waited) {
       HIPCHK(hipStreamWaitEvent(h->side_ts, h->ev_begin_cur, 0));
       h->ts_waited_begin = h->step_no;
       if (h->iso_set[h->iso_cur].st != h->side_ts)   // (the chain ran on this very stream: nothing to wait for, and a wait packet costs ~6 us)
@@ -1921,6 +2043,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     ColGrid br = b;
     br.total = br.nwaves * cr.nt_local;
     if (int rc = land_clean(h, c, h->stream)) return rc;
+    if (int rc = inputs_rest(h)) return rc;   // the fluxes of the other tracers (pass A applies them at the surface and the bottom)
     mark(h, "begin");
     launch_a(cr, a, S + 2 * N3, h->stream);
     mark(h, "colfct");
@@ -1932,6 +2055,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     if (h->tsi_step) { mark(h, "colupd"); if (int rc = launch_tsi_rows(h, cr, h->stream, 0)) return rc; }
   } else {
     if (int rc = land_clean(h, c, h->stream)) return rc;
+    if (int rc = inputs_rest(h)) return rc;
     mark(h, "begin");
     // the local tracers among T and S take their own kernels first (bit-exact in the production step), the others the bulk passes
     const int n_ts = c.n0 < 2 ? std::min(c.n0 + c.nt_local, 2) - c.n0 : 0;
@@ -2088,6 +2212,22 @@ static int launch_mobi(uvic_gpu *h) {
     h->src_from_prefetch = false;
   }
   if (int rc = mobi_step_scalars(h, h->ctx.c2dtts, h->mobi.relyr, h->mobi.S)) return rc;
+  if (h->step_begun && !h->serial) {
+    // Not computed ahead (the first step of an ocean segment, a forward step): on a MOBI side stream all the same.  Neither
+    // pass A nor the T,S passes read the sources; pass B of the other tracers waits for them as it does for a chain that
+    // ran ahead.  The buffer was last read by a pass B before this step's begin.
+    const int q = h->mobi_flip;
+    if (h->mobi_two_streams) h->mobi_flip ^= 1;
+    hipStream_t st = h->side_m[q];
+    HIPCHK(hipStreamWaitEvent(st, h->ev_begin_cur, 0));
+    if (h->in.forcing_sent) HIPCHK(hipStreamWaitEvent(st, h->in.ev_forcing, 0));
+    if (int rc = launch_mobi_on(h, h->ctx, h->mobi, st, q ? 4 : 1)) return rc;
+    HIPCHK(hipEventRecord(h->ev_src_inline, st));
+    h->ev_src_ready = h->ev_src_inline;
+    h->src_from_prefetch = true;
+    return 0;
+  }
+  if (h->in.forcing_sent) HIPCHK(hipStreamWaitEvent(h->stream, h->in.ev_forcing, 0));
   return launch_mobi_on(h, h->ctx, h->mobi, h->stream, 0);
 }
 
@@ -2512,6 +2652,7 @@ static int step_begin(uvic_gpu *h) {
 // queues the halo exchange.  The MOBI chain of the step after next is column-local and waits for this, not for the
 // exchange (on a 12-row slab the chain is the critical path and the exchange costs 0.06 ms).
 static int step_end(uvic_gpu *h) {
+  h->in.waited = false;
   h->ev_end_pending = h->ev_step_end[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_end_pending, h->stream));
   h->end_pending = true;
@@ -2521,7 +2662,7 @@ static int step_end(uvic_gpu *h) {
 extern "C" int uvic_gpu_step_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   if (int rc = step_begin(h)) return rc;
-  if (int rc = launch_isopyc(h)) return rc;
+  if (int rc = launch_isopyc(h, true)) return rc;
   if (int rc = launch_tracer(h)) return rc;
   return step_end(h);
 }
@@ -2593,6 +2734,7 @@ extern "C" int uvic_gpu_prefetch_sources_at(uvic_gpu *h, double c2dtts_next, dou
   // src_alt was read last by pass B of the previous step (before ev_step_begin); the other chain writes the other buffer
   // (the end of the previous step's own work is enough: MOBI is column-local, the halo rows do not matter to it)
   HIPCHK(hipStreamWaitEvent(st, h->end_ready ? h->ev_end_ready : h->ev_begin_cur, 0));
+  if (h->in.forcing_sent) HIPCHK(hipStreamWaitEvent(st, h->in.ev_forcing, 0));
   if (int rc = launch_mobi_on(h, c, m, st, sid)) return rc;
   h->ev_src_pending = h->ev_src_next[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_src_pending, st));
@@ -2656,7 +2798,7 @@ extern "C" int uvic_gpu_set_mixing(uvic_gpu *h, int on) {
 extern "C" int uvic_gpu_step_pre_async(uvic_gpu *h) {
   if (!h) return fail_msg("null handle");
   if (int rc = step_begin(h)) return rc;
-  if (int rc = launch_isopyc(h)) return rc;
+  if (int rc = launch_isopyc(h, true)) return rc;
   if (int rc = launch_mobi(h)) return rc;
   return launch_transport(h, false);
 }
@@ -2873,6 +3015,7 @@ extern "C" int uvic_gpu_sync(uvic_gpu *h) {
   for (int q = 0; q < 2; ++q) HIPCHK(hipStreamSynchronize(h->side_m[q]));
   HIPCHK(hipStreamSynchronize(h->side2));
   HIPCHK(hipStreamSynchronize(h->side_ts));
+  for (int q = 0; q < 2; ++q) if (h->in.st[q]) HIPCHK(hipStreamSynchronize(h->in.st[q]));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->push.err && *h->push.err) {
     const int who = *h->push.err - 1;
@@ -3055,8 +3198,17 @@ extern "C" int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, 
       h->src_from_prefetch = false;
     }
     const size_t bytes = (size_t)h->d.imt * h->d.jmt * 8;
-    for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, h->stream));
-    if (h->host_sync) HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->in.st[0] && !h->host_sync) {
+      // beside the main stream, like the step's other inputs (uvic_gpu_overlay_inputs): every MOBI chain from now on waits
+      // for them; the chains that read the old fields have ended (synchronised above, and in-line ones with their step)
+      hipStream_t st = h->in.st[1] ? h->in.st[1] : h->in.st[0];
+      for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, st));
+      HIPCHK(hipEventRecord(h->in.ev_forcing, st));
+      h->in.forcing_sent = true;
+    } else {
+      for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, h->stream));
+      if (h->host_sync) HIPCHK(hipStreamSynchronize(h->stream));
+    }
   }
   h->mobi.relyr = relyr;
   h->mobi.co2ccn = co2ccn;
@@ -3193,6 +3345,88 @@ extern "C" int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload) {
 // `ts_host` (imt, km, jmt, 2) as soon as they are final, the surface sums are updated behind the step, the time levels
 // rotate -- and the call returns when T,S are on the host, while pass B of the other tracers may still be running
 // (the next call queues behind it).
+// The step's inputs from the host in one call (the resident overlay: tracer_gpu.F), replacing six uvic_gpu_upload_rows.
+// Host arrays as the memory window holds them: adv_vet (imt,km,jsmw:jmt), adv_vnt (imt,km,1:jmt), adv_vbt
+// (imt,0:km,jsmw:jmt) or null, diff_cbt (imt,km,jsmw:jemw), stf and btf (imt,jmt,nt); page-locked (uvic_gpu_pin_host).
+// The copies do not go through the main stream: they run on two streams of their own into the device copy the previous
+// step does not read, T and S first -- the horizontal velocities, diff_cbt and the T,S planes of the fluxes, after which
+// the T,S passes may start -- then the fluxes of the other tracers, which the bulk pass A waits for.  A null adv_vbt is
+// formed on the device from adv_vet and adv_vnt, as adv_vel.F:98-127 does on the host (rigid lid: zero at the surface).
+extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
+                                       const double *diff_cbt, const double *stf, const double *btf) {
+  if (!h || !adv_vet || !adv_vnt || !diff_cbt || !stf || !btf) return fail_msg("uvic_gpu_overlay_inputs: null argument");
+  const uvic_dims &d = h->d;
+  if (jsmw < 1 || jsmw > 2 || jemw < jsmw || jemw > d.jmt) return fail_msg("uvic_gpu_overlay_inputs: window rows outside 1..jmt");
+  h->idle_until_next = false;
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = mom_host_join(h)) return rc;
+  auto &I = h->in;
+  const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt, N2 = (size_t)d.imt * d.jmt;
+  const size_t bytes[5] = {N3 * 8, N3 * 8, NF * 8, N2 * d.nt * 8, N2 * d.nt * 8};
+  if (!I.st[0]) {   // first call: the second copy starts as an image of the first (rows no upload covers keep their values)
+    for (int q = 0; q < 5; ++q) {
+      I.set[0][q] = (double *)h->buf[IN_FIELDS[q]];
+      HIPCHK(hipMalloc((void **)&I.set[1][q], bytes[q]));
+      HIPCHK(hipMemcpyAsync(I.set[1][q], I.set[0][q], bytes[q], hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < I.nstreams; ++q) HIPCHK(hipStreamCreateWithFlags(&I.st[q], hipStreamNonBlocking));
+    if (I.nstreams == 1) I.st[1] = nullptr;
+    for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&I.ev_link[q], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&I.ev_first, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&I.ev_rest, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&I.ev_forcing, hipEventDisableTiming));
+    I.cur = 0; I.used = true;
+  }
+  if (I.used) {   // the steps queued so far read the current copy: fill the other one
+    I.cur ^= 1; I.used = false;
+    for (int q = 0; q < 5; ++q) h->buf[IN_FIELDS[q]] = I.set[I.cur][q];
+    bind_ctx(h);
+  }
+  hipStream_t sa = I.st[0], sb = I.st[1] ? I.st[1] : I.st[0];
+  const size_t row = (size_t)d.imt * d.km * 8, rowf = (size_t)d.imt * (d.km + 1) * 8;
+  double **dev = I.set[I.cur];
+  auto up = [&](hipStream_t st, void *dst, const void *src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st); };
+  // (two copies at a time move 59 GB/s where one moves 47; each copy costs ~10 us of latency on its stream: the two
+  // long ones on one stream, the third long one and the two short ones on the other)
+  HIPCHK(up(sa, (char *)dev[0] + (size_t)(jsmw - 1) * row, adv_vet, (size_t)(d.jmt - jsmw + 1) * row));
+  HIPCHK(up(sb, dev[1], adv_vnt, (size_t)d.jmt * row));
+  HIPCHK(up(sa, (char *)h->buf[UVIC_F_DIFF_CBT] + (size_t)(jsmw - 1) * row, diff_cbt, (size_t)(jemw - jsmw + 1) * row));
+  HIPCHK(up(sb, dev[3], stf, 2 * N2 * 8));
+  HIPCHK(up(sb, dev[4], btf, 2 * N2 * 8));
+  if (adv_vbt) HIPCHK(up(sb, (char *)dev[2] + (size_t)(jsmw - 1) * rowf, adv_vbt, (size_t)(d.jmt - jsmw + 1) * rowf));
+  if (sb != sa) { HIPCHK(hipEventRecord(I.ev_link[0], sb)); HIPCHK(hipStreamWaitEvent(sa, I.ev_link[0], 0)); }
+  HIPCHK(hipEventRecord(I.ev_first, sa));
+  if (d.nt > 2) {
+    HIPCHK(up(sa, dev[3] + 2 * N2, stf + 2 * N2, (size_t)(d.nt - 2) * N2 * 8));
+    HIPCHK(up(sb, dev[4] + 2 * N2, btf + 2 * N2, (size_t)(d.nt - 2) * N2 * 8));
+    if (sb != sa) { HIPCHK(hipEventRecord(I.ev_link[1], sb)); HIPCHK(hipStreamWaitEvent(sa, I.ev_link[1], 0)); }
+  }
+  HIPCHK(hipEventRecord(I.ev_rest, sa));
+  I.first_pending = I.rest_pending = true;
+  I.derive_vbt = adv_vbt == nullptr;
+  velocity_touched(h, UVIC_F_ADV_VET);
+  return 0;
+}
+// the main stream waits for the inputs a step is about to read (every other stream of the step starts behind the main one)
+static int inputs_first(uvic_gpu *h, bool vbt_follows) {
+  h->in.used = true;
+  if (!h->in.first_pending) return 0;
+  HIPCHK(hipStreamWaitEvent(h->stream, h->in.ev_first, 0));
+  h->in.first_pending = false;
+  h->in.waited = true;
+  if (h->in.derive_vbt && !vbt_follows) {
+    hipLaunchKernelGGL(k_adv_vel_vert, dim3(col_blocks(h, 64)), dim3(64), 0, h->stream, h->ctx);
+    mark(h, "adv_vel_vert");
+  }
+  return 0;
+}
+static int inputs_rest(uvic_gpu *h) {
+  if (!h->in.rest_pending) return 0;
+  HIPCHK(hipStreamWaitEvent(h->stream, h->in.ev_rest, 0));
+  h->in.rest_pending = false;
+  return 0;
+}
 extern "C" int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_host) {
   if (!h || !s) return fail_msg("uvic_gpu_overlay_step: null argument");
   HIPCHK(hipSetDevice(h->device));

@@ -229,6 +229,25 @@
           real(c_double) :: ektot(*)
           integer(c_int) :: rc
         end function
+        function uvic_gpu_overlay_inputs(h, jsmw, jemw, adv_vet, adv_vnt, adv_vbt, diff_cbt, stf, btf)       &
+     &      bind(C,name='uvic_gpu_overlay_inputs') result(rc)
+!         adv_vbt = c_null_ptr: formed on the device from adv_vet, adv_vnt (rigid lid)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: jsmw, jemw
+          real(c_double) :: adv_vet(*), adv_vnt(*), diff_cbt(*), stf(*), btf(*)
+          type(c_ptr), value :: adv_vbt
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_overlay_inputs_vbt(h, jsmw, jemw, adv_vet, adv_vnt, adv_vbt, diff_cbt, stf, btf)   &
+     &      bind(C,name='uvic_gpu_overlay_inputs') result(rc)
+!         the same entry point with adv_vbt sent as well (free surface: not zero at the top)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: jsmw, jemw
+          real(c_double) :: adv_vet(*), adv_vnt(*), adv_vbt(*), diff_cbt(*), stf(*), btf(*)
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_overlay_step(h, s, ts_host) bind(C,name='uvic_gpu_overlay_step') result(rc)
           import
           type(c_ptr), value :: h
