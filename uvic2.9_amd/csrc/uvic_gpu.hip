@@ -236,6 +236,13 @@ __global__ void __launch_bounds__(256) k_inputs_cell(const uvic_ctx c, double *c
   if (j >= 2 && j <= jmt - 1 && i >= 2 && i <= imt - 1 && !SLAB_OUT(c, j) && k <= km - 1)
     cf[CF_IDX(CF_BV, q, N3)] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
 }
+// MOBI's four forcing planes of an ocean segment (light, ice cover, ice and snow thickness) straight out of the caller's
+// page-locked arrays: 4 x imt*jmt doubles at the head of the chain that needs them -- no copy engine, no event between streams
+struct Pull4 { const double *src[4]; double *dst[4]; };
+__global__ void __launch_bounds__(256) k_pull4(const Pull4 p, int n) {
+  const int q = blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) p.dst[q][e] = p.src[q][e];
+}
 // ---- baroclinic momentum step (kernels_clinic.hpp) -----------------------------------
 #define COL_DECODE(m)                                                 \
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;              \
@@ -895,7 +902,11 @@ struct uvic_gpu {
   void *buf[UVIC_F_COUNT];
   double *work[8];  // tot_e, tot_n, tot_b, adv_x (also S of the column path), adv_z, RpY, RmY
   int *cv_int[3];   // convection segments: nseg, kt, kb
+  int *cv_int2[3];  // the second set of the segment arrays and of cv_z (see cv_lists)
+  double *cv_z2;
   int *cv_list;     // [0] number of columns the T,S walk of this step mixed, [1..] their ids (k_convect_list)
+  int *cv_lists[2]; // ... two of them, taken in turn (uvic_gpu_rotate): the next step's T,S passes may begin before this
+                    // step's k_convect_apply_list has read its list (the resident overlay's T,S chain, launch_transport)
   double *cv_z;
   bool exact_convect;  // single-kernel convct2 (debug: UVIC_CONVECT_ONEPASS=1)
   double *coef;     // folded isopycnal coefficients, CF_PAIRS pair planes (kernels_col.hpp)
@@ -987,10 +998,12 @@ struct uvic_gpu {
   double *ts_host;              // where T,S of this step's t(tau+1) go (null: nowhere); set for one step by overlay_step
   hipEvent_t ev_ts_host;
   bool ts_host_queued;
-  // the step's inputs from the host (uvic_gpu_overlay_inputs): two device copies of the velocities and fluxes, filled in
-  // turn by copies on streams of their own; a step waits for the group of copies it needs, where it needs it
+  // the step's inputs from the host (uvic_gpu_overlay_inputs): three device copies of the velocities and fluxes, filled in
+  // turn by copies on streams of their own (the caller has T,S of step n back while the other tracers of step n-1 may
+  // still be in their pass B: the copy step n+1 fills is that of step n-2); a step waits for the group of copies it
+  // needs, where it needs it
   struct {
-    double *set[2][5] = {};       // adv_vet, adv_vnt, adv_vbt, stf, btf
+    double *set[3][5] = {};       // adv_vet, adv_vnt, adv_vbt, stf, btf
     int cur = 0;
     bool used = true;             // a step has been queued on the current set
     hipStream_t st[2] = {nullptr, nullptr};
@@ -999,9 +1012,19 @@ struct uvic_gpu {
     bool first_pending = false, rest_pending = false;   // queued, and the main stream has not been told to wait for them yet
     bool waited = false;          // this step's main stream began with a wait for them (the T,S stream starts behind it)
     bool derive_vbt = false;      // adv_vbt was not sent: formed from adv_vet, adv_vnt on the device (adv_vel.F:98-127)
-    hipEvent_t ev_forcing = nullptr;   // MOBI's light, ice and snow fields of the segment, copied on st[1] (uvic_gpu_set_mobi_step)
-    bool forcing_sent = false;
+    // MOBI's light, ice and snow fields of the segment (uvic_gpu_set_mobi_step): fetched from the caller's page-locked
+    // arrays by the first MOBI chain that follows (forcing_pull), which the other chains then wait for (forcing_sent)
+    hipEvent_t ev_forcing = nullptr;
+    const double *forcing_src[4] = {};
+    bool forcing_pull = false, forcing_sent = false, forcing_inflight = false;
+    bool rest_inflight = false;   // copies the caller's arrays must outlast: overlay_step returns behind them
   } in;
+  // the event behind which the MOBI sources of a step are complete (its chain has read t(tau-1), T and S included), by step
+  // parity: the T,S passes of the NEXT step write that buffer (launch_transport)
+  hipEvent_t ev_mobi_of[2];
+  long long mobi_ev_step[2];
+  hipEvent_t ev_src_inline2[2];
+  long long end_step_of[2];       // the step that recorded ev_step_end[q]
   bool prep_deferred;             // launch_isopyc left k_inputs_cell (and the wait for the inputs) to launch_transport
   hipEvent_t ev_src_inline;       // sources of the current step computed on a MOBI side stream (launch_mobi)
   int sbc_count;                // tracers whose surface level is accumulated
@@ -1159,8 +1182,19 @@ extern "C" int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value) {
   if (n == "push_wait_ms") { h->push.wait_ms = value > 0 ? value : 2000.0; return 0; }   // how long an exchange waits for a peer before it reports it lost
   return fail_msg("uvic_gpu_set_option: unknown option " + n);
 }
+// The step runs on four streams and the resident overlay adds two for its copies; the HIP runtime maps streams onto four
+// hardware queues unless told otherwise, and a copy stream that shares a queue with a MOBI chain has its event markers
+// held up behind a 0.3 ms kernel (0.15 ms per overlay call, measured).  Ask for more queues while the runtime has not
+// read its settings yet (its first call in the process: the Fortran driver's case); a value the user has set stands.
+static void want_hw_queues() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device) {
   if (!out || !dims) return fail_msg("uvic_gpu_create: null argument");
+  want_hw_queues();
   if (dims->imt < 6 || dims->jmt < 6 || dims->km < 2 || dims->nt < 2)
     return fail_msg("uvic_gpu_create: dimensions too small (need imt,jmt >= 6, km >= 2, nt >= 2)");
   if (dims->km > 64) return fail_msg("uvic_gpu_create: km > 64 not supported (per-level metrics are held one per lane of a wave)");
@@ -1229,6 +1263,10 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->ts_waited_begin = -1;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&h->ev_src_inline, hipEventDisableTiming));
+  for (int q = 0; q < 2; ++q) {
+    HIPCHK(hipEventCreateWithFlags(&h->ev_src_inline2[q], hipEventDisableTiming));
+    h->mobi_ev_step[q] = h->end_step_of[q] = -1; h->ev_mobi_of[q] = nullptr;
+  }
   h->ev_src_ready = h->ev_src_pending = h->ev_src_next[0];
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_step_end[q], hipEventDisableTiming));
   h->ev_end_ready = h->ev_end_pending = h->ev_step_end[0];
@@ -1255,11 +1293,18 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
     for (int q = 0; q < 3; ++q) {
       HIPCHK(hipMalloc((void **)&h->cv_int[q], isz[q] * 4));
       HIPCHK(hipMemset(h->cv_int[q], 0, isz[q] * 4));
+      HIPCHK(hipMalloc((void **)&h->cv_int2[q], isz[q] * 4));
+      HIPCHK(hipMemset(h->cv_int2[q], 0, isz[q] * 4));
     }
-    HIPCHK(hipMalloc((void **)&h->cv_list, (NS + 1) * 4));
-    HIPCHK(hipMemset(h->cv_list, 0, (NS + 1) * 4));
+    for (int q = 0; q < 2; ++q) {
+      HIPCHK(hipMalloc((void **)&h->cv_lists[q], (NS + 1) * 4));
+      HIPCHK(hipMemset(h->cv_lists[q], 0, (NS + 1) * 4));
+    }
+    h->cv_list = h->cv_lists[0];
     HIPCHK(hipMalloc((void **)&h->cv_z, N3 * 8));
     HIPCHK(hipMemset(h->cv_z, 0, N3 * 8));
+    HIPCHK(hipMalloc((void **)&h->cv_z2, N3 * 8));
+    HIPCHK(hipMemset(h->cv_z2, 0, N3 * 8));
     h->exact_convect = false;
     if (const char *e = uv_env("UVIC_CONVECT_ONEPASS")) h->exact_convect = atoi(e) != 0;
   }
@@ -1309,7 +1354,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipSetDevice(h->device);
   (void)uvic_gpu_sync(h);   // every stream, the momentum side stream included: it may still be copying into a pinned host range
   iso_set_release(h);   // the three sets of T,S-derived fields; clears their views in buf[], work[0..2], coef
-  if (h->in.set[1][0]) for (int q = 0; q < 5; ++q) h->buf[IN_FIELDS[q]] = h->in.set[0][q];   // set 1 is freed below
+  if (h->in.set[1][0]) for (int q = 0; q < 5; ++q) h->buf[IN_FIELDS[q]] = h->in.set[0][q];   // sets 1 and 2 are freed below
   for (int f = 0; f < UVIC_F_COUNT; ++f) (void)hipFree(h->buf[f]);
   for (int w = 0; w < 7; ++w) (void)hipFree(h->work[w]);
   (void)hipFree((void *)h->ctx.tmask);
@@ -1319,18 +1364,19 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int q = 0; q < 4; ++q) (void)hipFree(h->halo[q]);
   push_release(h);
   if (h->in.st[0]) {
-    for (int q = 0; q < 5; ++q) (void)hipFree(h->in.set[1][q]);   // (set[0] are the buffers of buf[], freed above)
+    for (int q = 0; q < 5; ++q) { (void)hipFree(h->in.set[1][q]); (void)hipFree(h->in.set[2][q]); }   // (set[0] are the buffers of buf[], freed above)
     for (int q = 0; q < 2; ++q) { if (h->in.st[q]) (void)hipStreamDestroy(h->in.st[q]); (void)hipEventDestroy(h->in.ev_link[q]); }
-    (void)hipEventDestroy(h->in.ev_first); (void)hipEventDestroy(h->in.ev_rest); (void)hipEventDestroy(h->in.ev_forcing);
+    (void)hipEventDestroy(h->in.ev_first); (void)hipEventDestroy(h->in.ev_rest);
   }
+  if (h->in.ev_forcing) (void)hipEventDestroy(h->in.ev_forcing);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   (void)hipFree(h->fltu_items);
   (void)hipFree(h->fltu_mats);
   (void)hipFree(h->fltu_rows);
-  for (int q = 0; q < 3; ++q) (void)hipFree(h->cv_int[q]);
-  (void)hipFree(h->cv_z);
-  (void)hipFree(h->cv_list);
+  for (int q = 0; q < 3; ++q) { (void)hipFree(h->cv_int[q]); (void)hipFree(h->cv_int2[q]); }
+  (void)hipFree(h->cv_z); (void)hipFree(h->cv_z2);
+  for (int q = 0; q < 2; ++q) (void)hipFree(h->cv_lists[q]);
   (void)hipFree(h->sbc_tracer);
   (void)hipFree(h->sbc_acc);
   (void)hipFree(h->tsi_acc);
@@ -1347,6 +1393,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipEventDestroy(h->ev_step_begin);
   for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(h->ev_src_next[q]); (void)hipEventDestroy(h->ev_step_end[q]); }
   (void)hipEventDestroy(h->ev_src_inline);
+  for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_src_inline2[q]);
   for (void *q : h->pinned) (void)hipHostUnregister(q);
   h->pinned.clear();
   if (h->side_mom) { (void)hipStreamSynchronize(h->side_mom); (void)hipStreamDestroy(h->side_mom); (void)hipEventDestroy(h->ev_mom_in); (void)hipEventDestroy(h->ev_mom_done); }
@@ -1885,7 +1932,8 @@ static int launch_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid, 
 }
 // T and S (the local tracers among them: c.n0 < 2, c.nt_local <= 2) through the exact column kernels on stream `st`.
 // `walk`: pass B and the convective T,S walk in one launch (both tracers local, the whole `tracer` step)
-static int launch_colx(uvic_gpu *h, const uvic_ctx &c, const ColGrid &a, const ColGrid &b, hipStream_t st, int sid, bool walk) {
+static int launch_colx(uvic_gpu *h, const uvic_ctx &c, const ColGrid &a, const ColGrid &b, hipStream_t st, int sid, bool walk,
+                       hipEvent_t update_after = nullptr) {
   if (c.nt_local <= 0) return 0;
   ColxOut o;
   o.adv_x = h->work[3]; o.adv_z = h->work[4]; o.fn = h->work[5]; o.dif = h->work[6];
@@ -1898,6 +1946,7 @@ static int launch_colx(uvic_gpu *h, const uvic_ctx &c, const ColGrid &a, const C
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
     h->src_from_prefetch = false;
   }
+  if (update_after) HIPCHK(hipStreamWaitEvent(st, update_after, 0));   // what still reads the buffer t(tau+1) goes to
   if (gb.nwaves > 0) {
     if (walk) {
       const size_t lds_b = ((size_t)2 * 2 * (c.km + 1) * 64 + (size_t)12 * c.km) * 8;
@@ -1921,6 +1970,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   // follows the exchange.
   const bool split = !h->exact && convect_follows && !h->serial && !h->exact_convect && c.n0 == 0 && c.nt_local == c.nt && c.nt > 2 && h->ts_no_src;
   bool ts_stream_ready = false;
+  hipEvent_t ts_update_after = nullptr;
   if (h->prep_deferred) {
     // the inputs have been queued beside the main stream and the T,S-derived fields were computed ahead: what is left to
     // form from them (k_inputs_cell) goes to the head of the stream whose chain the host waits for -- one hop between
@@ -1929,8 +1979,27 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     hipStream_t st = split && h->step_begun ? h->side_ts : h->stream;
     const int sid = st == h->stream ? 0 : 3;
     if (st != h->stream) {
-      HIPCHK(hipStreamWaitEvent(st, h->ev_begin_cur, 0));
-      h->ts_waited_begin = h->step_no;
+      // What T and S of this step must not overtake.  For a caller that waits for them (the resident overlay) the other
+      // tracers of the PREVIOUS step are not among it: their passes read none of what the T,S chain writes -- its planes of
+      // t(tau+1) and of the work arrays, this step's set of T,S-derived fields, its copy of the inputs and its set of the
+      // convective walk's arrays, all of which were last read two or three steps ago -- except the MOBI chain of the
+      // previous step, which reads T and S of what is now the t(tau+1) buffer.  So: the end of the step before the previous
+      // one and that chain, when both are known; the previous step's end otherwise.
+      const int par = (int)(h->step_no & 1);
+      const bool mobi_known = !h->have_mobi || h->mobi_ev_step[par ^ 1] == h->step_no - 1;
+      // (and every time level has had its land columns cleared: land_clean runs on the main stream)
+      const bool relaxed = h->ts_host && h->flt_nitems == 0 && !h->tsi_step && !h->mixing && mobi_known &&
+                           h->end_step_of[h->ev_flip] == h->step_no - 2 && h->land_zeroed.size() >= 3;
+      if (relaxed) {
+        HIPCHK(hipStreamWaitEvent(st, h->ev_step_end[h->ev_flip], 0));
+        if (h->have_mobi) {   // (only the update writes that buffer: pass A may run beside the chain)
+          if (h->ts_exact && !h->ts_rows) ts_update_after = h->ev_mobi_of[par ^ 1];
+          else HIPCHK(hipStreamWaitEvent(st, h->ev_mobi_of[par ^ 1], 0));
+        }
+      } else {
+        HIPCHK(hipStreamWaitEvent(st, h->ev_begin_cur, 0));
+        h->ts_waited_begin = h->step_no;
+      }
       if (h->iso_set[h->iso_cur].st != st) HIPCHK(hipStreamWaitEvent(st, h->iso_set[h->iso_cur].ev, 0));
     }
     HIPCHK(hipStreamWaitEvent(st, h->in.ev_first, 0));
@@ -2017,7 +2086,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     } else if (h->ts_exact) {
       // T and S in the reference's own order of operations (kernels_colx.hpp): every convective adjustment is decided on
       // their bits (convect.F:189-255), and a density comparison of rounding size flips on a 1-ulp difference
-      if (int rc = launch_colx(h, cts, a, b, h->side_ts, 3, walk_fused)) return rc;
+      if (int rc = launch_colx(h, cts, a, b, h->side_ts, 3, walk_fused, ts_update_after)) return rc;
     } else {
       launch_ts_columns(cts, h->side_ts, 3, walk_fused);
     }
@@ -2197,8 +2266,25 @@ static int launch_mobi_on(uvic_gpu *h, const uvic_ctx &c, const mobi_dev &m, hip
   HIPCHK(hipGetLastError());
   return 0;
 }
+// at the head of a MOBI chain on stream `st`: the segment's forcing fields are there, or on their way on another stream
+static int forcing_on(uvic_gpu *h, hipStream_t st) {
+  auto &I = h->in;
+  if (I.forcing_pull) {
+    Pull4 p;
+    for (int q = 0; q < 4; ++q) { p.src[q] = I.forcing_src[q]; p.dst[q] = (double *)h->mobi_st.f[1 + q]; }
+    const int n = h->d.imt * h->d.jmt;
+    hipLaunchKernelGGL(k_pull4, dim3((unsigned)((n + 255) / 256), 4), dim3(256), 0, st, p, n);
+    HIPCHK(hipEventRecord(I.ev_forcing, st));
+    I.forcing_pull = false; I.forcing_sent = true; I.forcing_inflight = true;
+    return 0;
+  }
+  if (I.forcing_sent) HIPCHK(hipStreamWaitEvent(st, I.ev_forcing, 0));
+  return 0;
+}
 static int launch_mobi(uvic_gpu *h) {
   if (!h->have_mobi) return 0;
+  const int par = (int)(h->step_no & 1);
+  h->mobi_ev_step[par] = -1;
   if (h->src_from_prefetch) {   // computed one step ahead on the side stream; launch_transport waits for it
     // The chain assumed a leapfrog step with c2dtts_next and named a clock and a CO2 value.  The bit-exact path takes its
     // sources only if all of that came true to the bit; the production path also when the clock it was promised differs
@@ -2206,7 +2292,10 @@ static int launch_mobi(uvic_gpu *h) {
     auto month_of = [](double relyr) { const double y = fmod(relyr, 1.); int mo = 12; for (int q = 1; q <= 12; ++q) if (y <= q / 12.) { mo = q; break; } return mo; };
     const bool clock_ok = h->src_relyr == h->mobi.relyr ||
                           (!h->exact && fabs(h->src_relyr - h->mobi.relyr) <= 1e-9 && month_of(h->src_relyr) == month_of(h->mobi.relyr));
-    if (!h->mixing && h->src_c2dtts == h->ctx.c2dtts && clock_ok && h->src_co2ccn == h->mobi.co2ccn) return 0;
+    if (!h->mixing && h->src_c2dtts == h->ctx.c2dtts && clock_ok && h->src_co2ccn == h->mobi.co2ccn) {
+      h->ev_mobi_of[par] = h->ev_src_ready; h->mobi_ev_step[par] = h->step_no;
+      return 0;
+    }
     // otherwise its sources are void: recompute in line, behind the chain (it wrote the buffer this step reads)
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
     h->src_from_prefetch = false;
@@ -2216,18 +2305,20 @@ static int launch_mobi(uvic_gpu *h) {
     // Not computed ahead (the first step of an ocean segment, a forward step): on a MOBI side stream all the same.  Neither
     // pass A nor the T,S passes read the sources; pass B of the other tracers waits for them as it does for a chain that
     // ran ahead.  The buffer was last read by a pass B before this step's begin.
+    // (the chain that computes the NEXT step's sources, queued later in this step, takes the same stream: side by side the
+    // two would share the chip and this one, which pass B is waiting for, would take 100 us longer)
     const int q = h->mobi_flip;
-    if (h->mobi_two_streams) h->mobi_flip ^= 1;
     hipStream_t st = h->side_m[q];
     HIPCHK(hipStreamWaitEvent(st, h->ev_begin_cur, 0));
-    if (h->in.forcing_sent) HIPCHK(hipStreamWaitEvent(st, h->in.ev_forcing, 0));
+    if (int rc = forcing_on(h, st)) return rc;
     if (int rc = launch_mobi_on(h, h->ctx, h->mobi, st, q ? 4 : 1)) return rc;
-    HIPCHK(hipEventRecord(h->ev_src_inline, st));
-    h->ev_src_ready = h->ev_src_inline;
+    HIPCHK(hipEventRecord(h->ev_src_inline2[par], st));
+    h->ev_src_ready = h->ev_src_inline2[par];
     h->src_from_prefetch = true;
+    h->ev_mobi_of[par] = h->ev_src_ready; h->mobi_ev_step[par] = h->step_no;
     return 0;
   }
-  if (h->in.forcing_sent) HIPCHK(hipStreamWaitEvent(h->stream, h->in.ev_forcing, 0));
+  if (int rc = forcing_on(h, h->stream)) return rc;
   return launch_mobi_on(h, h->ctx, h->mobi, h->stream, 0);
 }
 
@@ -2655,6 +2746,7 @@ static int step_end(uvic_gpu *h) {
   h->in.waited = false;
   h->ev_end_pending = h->ev_step_end[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_end_pending, h->stream));
+  h->end_step_of[h->ev_flip] = h->step_no;
   h->end_pending = true;
   if (!h->ts_final_valid) { h->ev_ts_final = h->ev_end_pending; h->ts_final_valid = true; }
   return 0;
@@ -2734,7 +2826,7 @@ extern "C" int uvic_gpu_prefetch_sources_at(uvic_gpu *h, double c2dtts_next, dou
   // src_alt was read last by pass B of the previous step (before ev_step_begin); the other chain writes the other buffer
   // (the end of the previous step's own work is enough: MOBI is column-local, the halo rows do not matter to it)
   HIPCHK(hipStreamWaitEvent(st, h->end_ready ? h->ev_end_ready : h->ev_begin_cur, 0));
-  if (h->in.forcing_sent) HIPCHK(hipStreamWaitEvent(st, h->in.ev_forcing, 0));
+  if (int rc = forcing_on(h, st)) return rc;
   if (int rc = launch_mobi_on(h, c, m, st, sid)) return rc;
   h->ev_src_pending = h->ev_src_next[h->ev_flip];
   HIPCHK(hipEventRecord(h->ev_src_pending, st));
@@ -3003,6 +3095,12 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->ev_src_ready = h->ev_src_pending;
   }
   h->tsi_step = false;
+  if (h->cv_lists[0]) {   // the convective walk's arrays of the step that starts now
+    const int odd = (int)((h->step_no + 1) & 1);
+    h->cv_list = h->cv_lists[odd];
+    int **ci = odd ? h->cv_int2 : h->cv_int;
+    h->ctx.cv_nseg = ci[0]; h->ctx.cv_kt = ci[1]; h->ctx.cv_kb = ci[2]; h->ctx.cv_z = odd ? h->cv_z2 : h->cv_z;
+  }
   h->step_no += 1;      // the T,S-derived fields of the new step live in set step_no % 3: current from now on, so that
   h->ts_final_valid = false;   // a diff_cbt uploaded for that step lands in it
   if (int rc = use_iso_set(h, (int)(h->step_no % 3))) return rc;
@@ -3198,16 +3296,26 @@ extern "C" int uvic_gpu_set_mobi_step(uvic_gpu *h, double relyr, double co2ccn, 
       h->src_from_prefetch = false;
     }
     const size_t bytes = (size_t)h->d.imt * h->d.jmt * 8;
-    if (h->in.st[0] && !h->host_sync) {
-      // beside the main stream, like the step's other inputs (uvic_gpu_overlay_inputs): every MOBI chain from now on waits
-      // for them; the chains that read the old fields have ended (synchronised above, and in-line ones with their step)
-      hipStream_t st = h->in.st[1] ? h->in.st[1] : h->in.st[0];
-      for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, st));
-      HIPCHK(hipEventRecord(h->in.ev_forcing, st));
-      h->in.forcing_sent = true;
+    // page-locked arrays of a caller that does not wait for its uploads (the resident overlay): the first MOBI chain that
+    // follows fetches them itself (forcing_on); the chains that read the old fields have ended (synchronised above, the
+    // in-line ones with their step).  The arrays must stay as they are until the step's uvic_gpu_overlay_step returns.
+    void *dp[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool mapped = !h->host_sync;
+    for (int q = 0; q < 4 && mapped; ++q)
+      if (hipHostGetDevicePointer(&dp[q], (void *)src[q], 0) != hipSuccess) { (void)hipGetLastError(); mapped = false; }
+    if (mapped) {
+      if (!h->in.ev_forcing) HIPCHK(hipEventCreateWithFlags(&h->in.ev_forcing, hipEventDisableTiming));
+      for (int q = 0; q < 4; ++q) h->in.forcing_src[q] = (const double *)dp[q];
+      h->in.forcing_pull = true; h->in.forcing_sent = false;
     } else {
+      h->in.forcing_pull = false;
       for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(h->mobi_st.f[1 + q], src[q], bytes, hipMemcpyHostToDevice, h->stream));
       if (h->host_sync) HIPCHK(hipStreamSynchronize(h->stream));
+      else {   // MOBI chains run on side streams: they wait for these copies
+        if (!h->in.ev_forcing) HIPCHK(hipEventCreateWithFlags(&h->in.ev_forcing, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->in.ev_forcing, h->stream));
+        h->in.forcing_sent = true;
+      }
     }
   }
   h->mobi.relyr = relyr;
@@ -3363,11 +3471,13 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
   auto &I = h->in;
   const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt, N2 = (size_t)d.imt * d.jmt;
   const size_t bytes[5] = {N3 * 8, N3 * 8, NF * 8, N2 * d.nt * 8, N2 * d.nt * 8};
-  if (!I.st[0]) {   // first call: the second copy starts as an image of the first (rows no upload covers keep their values)
+  if (!I.st[0]) {   // first call: the other copies start as images of the first (rows no upload covers keep their values)
     for (int q = 0; q < 5; ++q) {
       I.set[0][q] = (double *)h->buf[IN_FIELDS[q]];
-      HIPCHK(hipMalloc((void **)&I.set[1][q], bytes[q]));
-      HIPCHK(hipMemcpyAsync(I.set[1][q], I.set[0][q], bytes[q], hipMemcpyDeviceToDevice, h->stream));
+      for (int z = 1; z < 3; ++z) {
+        HIPCHK(hipMalloc((void **)&I.set[z][q], bytes[q]));
+        HIPCHK(hipMemcpyAsync(I.set[z][q], I.set[0][q], bytes[q], hipMemcpyDeviceToDevice, h->stream));
+      }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int q = 0; q < I.nstreams; ++q) HIPCHK(hipStreamCreateWithFlags(&I.st[q], hipStreamNonBlocking));
@@ -3375,11 +3485,10 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
     for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&I.ev_link[q], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&I.ev_first, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&I.ev_rest, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&I.ev_forcing, hipEventDisableTiming));
     I.cur = 0; I.used = true;
   }
-  if (I.used) {   // the steps queued so far read the current copy: fill the other one
-    I.cur ^= 1; I.used = false;
+  if (I.used) {   // the steps queued so far read the current copy and the one before: fill the third
+    I.cur = (I.cur + 1) % 3; I.used = false;
     for (int q = 0; q < 5; ++q) h->buf[IN_FIELDS[q]] = I.set[I.cur][q];
     bind_ctx(h);
   }
@@ -3404,6 +3513,7 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
   }
   HIPCHK(hipEventRecord(I.ev_rest, sa));
   I.first_pending = I.rest_pending = true;
+  I.rest_inflight = true;
   I.derive_vbt = adv_vbt == nullptr;
   velocity_touched(h, UVIC_F_ADV_VET);
   return 0;
@@ -3452,6 +3562,10 @@ extern "C" int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, do
       HIPCHK(hipStreamSynchronize(h->stream));
     }
   }
+  // the caller's arrays are its own again when this returns: the last copies out of them and MOBI's fetch of its forcing
+  // fields ended long before T and S came back, but nothing said so yet
+  if (h->in.rest_inflight) { HIPCHK(hipEventSynchronize(h->in.ev_rest)); h->in.rest_inflight = false; }
+  if (h->in.forcing_inflight) { HIPCHK(hipEventSynchronize(h->in.ev_forcing)); h->in.forcing_inflight = false; }
   if (timing) {
     const auto tq2 = std::chrono::steady_clock::now();
     fprintf(stderr, "overlay_step: queueing %.3f ms, wait for T,S %.3f ms; row transfers before it %.3f ms\n",
