@@ -344,6 +344,22 @@ int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_ho
  * then formed on the device from adv_vet and adv_vnt as source/mom/adv_vel.F:98-127 does (rigid lid, zero at the surface). */
 int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
                             const double *diff_cbt, const double *stf, const double *btf);
+/* (adv_vet and adv_vnt may both be null after uvic_gpu_overlay_velocities, which has formed the step's velocities on the device.)
+ *
+ * For a caller that keeps u on the device, on the momentum stream beside the main stream; uvic_gpu_momentum_wait
+ * returns when what they send to the host has arrived.  Host arrays page-locked and left alone until then.
+ *
+ * uvic_gpu_overlay_velocities -- the start of a leapfrog step, before `tracer`: what `loadmw` does to u with the memory
+ *   window wide open (u09/mom/loadmw.F:86-99: rotation of the time levels, add_ext_mode from psi(,,1) on tau, and from
+ *   psi(,,2) on tau-1 if `ext_taum1`), then `adv_vel` (source/mom/adv_vel.F:63-131) into the inputs of the tracer step.
+ * uvic_gpu_overlay_momentum -- where the reference calls `clinic` (after `tracer`, source/mom/mom.F:389-395): the
+ *   time-step monitor's kinetic energy of u(tau) (clinic.F:616-630; ektot (0:km, jmt) if ektot_host is given), `state`
+ *   (loadmw.F:154) from T,S of UVIC_F_T_TAU (t_level 0) or UVIC_F_T_TAUM1 (-1: the tracer step has rotated the levels
+ *   already) unless rho_host (imt,km,2:jmt) is given, `clinic` with sbc_flags/rts as uvic_gpu_clinic, zu to zu_host.
+ *   `fresh`: u(tau), u(tau-1) were uploaded on the main stream just now.  u(tau+1) stays in UVIC_F_UP1/UP2. */
+int uvic_gpu_overlay_velocities(uvic_gpu *h, int ext_taum1, const double *psi);
+int uvic_gpu_overlay_momentum(uvic_gpu *h, int fresh, int t_level, int sbc_flags, double rts, double rho0, const double *smf,
+                              const double *rho_host, double *zu_host, double *ektot_host);
 /* latitude-slab decomposition (uvic_gpu_set_shard js..je): the two outermost owned rows of t(tau+1) of every tracer
  * go to the neighbour's halo after each step (reach of the FCT stencil, u09/mom/tracer_adv_flx.F:553-555).  The library
  * packs them into contiguous staging buffers and unpacks what was received, both on its main stream; the caller moves

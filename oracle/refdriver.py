@@ -45,6 +45,10 @@ class RefOcean:
         self.ref = RefLib(cfg.name, g.imt, g.jmt, g.km, shim=shim)
         self.v = self.ref.v
         self.quiet = quiet
+        if shim and hasattr(self.ref.lib, "tracer_gpu_close_"):
+            # the library is loaded once per process and the overlays keep their device instance and what they know about
+            # it in module variables: a new model instance starts from nothing (environment switches are read again)
+            self.ref.call("tracer_gpu_close")
         self._init(ocean)
 
     # -- helpers ---------------------------------------------------------------

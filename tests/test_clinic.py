@@ -256,12 +256,15 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
-    isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does."""
+    isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
+    shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
+    run, as in the model, on whatever the host arrays hold).  on_host: steps with a diagnostic switch set, which the
+    overlays hand to the reference routines.  segment: ocean steps per coupling segment (isbcu/asbcu sums of clinic)."""
     import refdriver
     g = oc.grid
-    R = refdriver.RefOcean(oc)
+    R = refdriver.RefOcean(oc, shim=shim)
     R.set_momentum(mom)
     if filters:
         from uvic29_amd import synthetic
@@ -273,8 +276,18 @@ def _reference_loop(oc, mom, nsteps, filters):
     S("ihflx", np_ - 3); S("isflx", np_ - 2)
     v["sbc"][:, :, np_ - 4] = oc.stf[:, :, 0]
     v["sbc"][:, :, np_ - 3] = oc.stf[:, :, 1]
+    if segment:
+        S("igu", np_ - 9); S("igv", np_ - 8); S("isu", np_ - 7); S("isv", np_ - 6); S("ntspos", segment)
+        v["sbc"][:, :, np_ - 10:np_ - 6] = np.random.default_rng(3).standard_normal((g.imt, g.jmt, 4))
+    R.set_step_kind(False)          # leapfrog steps throughout (switch.h)
+    v["u"][..., 2] = 0.0            # (the COMMON blocks outlive a model instance in this process)
     zus = []
     for n in range(1, nsteps + 1):
+        S("itt", n)
+        if segment:
+            S("osegs", 1 if (n - 1) % segment == 0 else 0); S("osege", 1 if n % segment == 0 else 0)
+        if on_host:
+            S("timavgperts", 1 if n in on_host else 0)
         R.add_ext_mode(_psi(g, n), "tau")
         if n == 1:
             R.add_ext_mode(_psi(g, 0), "tau-1")
@@ -285,10 +298,21 @@ def _reference_loop(oc, mom, nsteps, filters):
         R.tracer()
         _, zu, _ = R.clinic()
         zus.append(zu)
+        if segment and n % segment == 0:
+            zus.append(np.array(v["sbc"][:, :, np_ - 10:np_ - 6], order="F"))     # the averages the atmosphere reads
         R.rotate()
         u = v["u"]
         u[..., 0] = u[..., 1]
         u[..., 1] = u[..., 2]
+    if shim and hasattr(R.ref.lib, "clinic_gpu_flush_"):
+        # resident overlays: what the device holds for the coming step, into the host's (already rotated) slots
+        stale = np.array(v["u"][..., 1], order="F")
+        R.ref.call("tracer_gpu_flush")
+        v["u"][..., 2] = 0.0
+        R.ref.call("clinic_gpu_flush")      # u(tau+1), u(tau), u(tau-1) of the last step
+        u = v["u"]
+        last_tau, last_taup1 = np.array(u[..., 1], order="F"), np.array(u[..., 2], order="F")
+        return np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale
     return np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus
 
 
@@ -336,6 +360,40 @@ def test_gpu_memory_window_loop_equals_reference(imt, jmt, km, nsteps):
     um = np.stack([m.download("um1"), m.download("um2")], axis=-1)
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("imt,jmt,km,nsteps", [(14, 14, 6, 9), (102, 102, 19, 4)])
+def test_fortran_overlays_keep_the_velocities_on_the_device(imt, jmt, km, nsteps, exact, monkeypatch):
+    """The same loop through the Fortran boundary (tracer_gpu.F + clinic_gpu.F, UVIC_RESIDENT=2): after the first `clinic`
+    on the device u stays there -- rotation of the levels, add_ext_mode and adv_vel happen on the device at the start of
+    the next step, per step psi and the wind stress go up and zu comes back -- while the host-side routines of the loop
+    (loadmw's add_ext_mode, state, adv_vel, setvbc) keep running on the host's stale copy as they would in the model.
+    zu of every step, the isbcu/asbcu averages at the end of every segment, and T, S, u after the last step equal the
+    reference's own loop bit for bit; one step in the middle carries a diagnostic switch and goes through the reference
+    routines (u comes down, adv_vel and setvbc are redone on the host, u(tau+1) goes back up)."""
+    import refmodel
+    if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
+    monkeypatch.setenv("UVIC_RESIDENT", "2")
+    if exact:
+        monkeypatch.setenv("UVIC_EXACT", "1")
+    else:       # the production default: T and S still go through the bit-exact kernels
+        monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc, mom, _, _ = _setup(imt, jmt, km)
+    on_host = (nsteps - 3,) if nsteps > 5 else ()
+    t_ref, u_ref, um_ref, zus = _reference_loop(oc, mom, nsteps, True, on_host=on_host, segment=3)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, on_host=on_host, segment=3)
+    if len(out) != 5:
+        pytest.skip("oracle/_ref shim predates the resident velocities")
+    t, u, um, got, stale = out
+    assert len(got) == len(zus)
+    for n, (a, b) in enumerate(zip(got, zus)):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
+    assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
+    assert not np.array_equal(stale[:, :, 1:-1], u_ref[:, :, 1:-1])     # resident for real: the host's copy was stale
 
 
 @pytest.mark.gpu

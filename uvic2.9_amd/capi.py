@@ -47,7 +47,7 @@ EXPORTS = [
     "uvic_gpu_step_lookahead", "uvic_gpu_download_level", "uvic_gpu_set_mobi_step", "uvic_gpu_pin_host", "uvic_gpu_halo_elems", "uvic_gpu_halo_buffer", "uvic_gpu_halo_pack", "uvic_gpu_halo_unpack",
     "uvic_gpu_push_setup", "uvic_gpu_push_export", "uvic_gpu_push_open", "uvic_gpu_push_exchange",
     "uvic_gpu_step_lookahead_at", "uvic_gpu_prefetch_sources_at", "uvic_gpu_set_host_sync", "uvic_gpu_sbc_config",
-    "uvic_gpu_sbc_transfer", "uvic_gpu_overlay_step", "uvic_gpu_overlay_inputs",
+    "uvic_gpu_sbc_transfer", "uvic_gpu_overlay_step", "uvic_gpu_overlay_inputs", "uvic_gpu_overlay_velocities", "uvic_gpu_overlay_momentum",
     "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
     "uvic_gpu_state_async", "uvic_gpu_clinic_async",
     "uvic_gpu_tmm_create", "uvic_gpu_tmm_set_mobi", "uvic_gpu_tmm_sources", "uvic_gpu_rotate_u", "uvic_gpu_add_ext_mode", "uvic_gpu_adv_vel_async",
@@ -163,6 +163,8 @@ def load():
     lib.uvic_gpu_halo_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_overlay_inputs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+    lib.uvic_gpu_overlay_velocities.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.uvic_gpu_overlay_momentum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 4
     lib.uvic_gpu_push_setup.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_push_export.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.uvic_gpu_push_open.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]

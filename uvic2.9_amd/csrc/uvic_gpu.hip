@@ -1018,6 +1018,11 @@ struct uvic_gpu {
     const double *forcing_src[4] = {};
     bool forcing_pull = false, forcing_sent = false, forcing_inflight = false;
     bool rest_inflight = false;   // copies the caller's arrays must outlast: overlay_step returns behind them
+    // the velocities of the coming step formed on the device from u (uvic_gpu_overlay_momentum) into the copy the next
+    // uvic_gpu_overlay_inputs then completes; the step's streams start behind ev_vel
+    hipEvent_t ev_vel = nullptr;
+    bool vel_pending = false;
+    double *ektot_dev = nullptr;
   } in;
   // the event behind which the MOBI sources of a step are complete (its chain has read t(tau-1), T and S included), by step
   // parity: the T,S passes of the NEXT step write that buffer (launch_transport)
@@ -1093,7 +1098,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 11; }   // 11: uvic_gpu_overlay_inputs, uvic_gpu_push_*; 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 11; }   // 11: uvic_gpu_overlay_inputs, uvic_gpu_overlay_velocities, uvic_gpu_overlay_momentum, uvic_gpu_push_*; 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -1369,6 +1374,8 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
     (void)hipEventDestroy(h->in.ev_first); (void)hipEventDestroy(h->in.ev_rest);
   }
   if (h->in.ev_forcing) (void)hipEventDestroy(h->in.ev_forcing);
+  if (h->in.ev_vel) (void)hipEventDestroy(h->in.ev_vel);
+  (void)hipFree(h->in.ektot_dev);
   (void)hipFree(h->flt_items);
   (void)hipFree(h->flt_mats);
   (void)hipFree(h->fltu_items);
@@ -1832,6 +1839,7 @@ static unsigned col_blocks(const uvic_gpu *h, int bs) {
 
 // the T,S-derived fields of a step (mixing tensor, GM velocities, folded coefficients): ctx `c` says what is read
 // (t_taum1) and where the products go; `sid` 0 = main stream, 2 = the isopyc side stream
+static int inputs_next_copy(uvic_gpu *h);
 static int inputs_first(uvic_gpu *h, bool vbt_follows = false);
 static int inputs_rest(uvic_gpu *h);
 static int launch_isopyc_on(uvic_gpu *h, const uvic_ctx &c, double *coef, hipStream_t st, int sid) {
@@ -2003,6 +2011,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (h->iso_set[h->iso_cur].st != st) HIPCHK(hipStreamWaitEvent(st, h->iso_set[h->iso_cur].ev, 0));
     }
     HIPCHK(hipStreamWaitEvent(st, h->in.ev_first, 0));
+    if (h->in.vel_pending) { HIPCHK(hipStreamWaitEvent(st, h->in.ev_vel, 0)); h->in.vel_pending = false; }
     h->in.first_pending = false; h->in.waited = true;
     uvic_ctx cp = c;
     cp.prio |= 4;
@@ -2612,14 +2621,18 @@ extern "C" int uvic_gpu_clinic_async(uvic_gpu *h, int sbc_flags, double rts) {
 // behind what the main stream holds now (add_ext_mode, adv_vel); zu is copied to `zu_host` (imt,jmt,2; may be null) and
 // uvic_gpu_momentum_wait returns when it has arrived -- long before the tracer step ends, so that the host's `tropic` runs
 // beside it.  The next uvic_gpu_add_ext_mode / uvic_gpu_adv_vel / state / clinic on the main stream wait for it by event.
-extern "C" int uvic_gpu_momentum_async(uvic_gpu *h, int sbc_flags, double rts, double *zu_host) {
-  if (!h) return fail_msg("null handle");
-  HIPCHK(hipSetDevice(h->device));
+static int momentum_stream(uvic_gpu *h) {
   if (!h->side_mom) {
     HIPCHK(hipStreamCreateWithFlags(&h->side_mom, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_mom_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_mom_done, hipEventDisableTiming));
   }
+  return 0;
+}
+extern "C" int uvic_gpu_momentum_async(uvic_gpu *h, int sbc_flags, double rts, double *zu_host) {
+  if (!h) return fail_msg("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = momentum_stream(h)) return rc;
   if (int rc = mom_join(h)) return rc;
   HIPCHK(hipEventRecord(h->ev_mom_in, h->stream));
   HIPCHK(hipStreamWaitEvent(h->side_mom, h->ev_mom_in, 0));
@@ -2629,6 +2642,84 @@ extern "C" int uvic_gpu_momentum_async(uvic_gpu *h, int sbc_flags, double rts, d
     HIPCHK(hipMemcpyAsync(zu_host, h->buf[UVIC_F_ZU], (size_t)2 * h->d.imt * h->d.jmt * 8, hipMemcpyDeviceToHost, h->side_mom));
   HIPCHK(hipEventRecord(h->ev_mom_done, h->side_mom));
   h->mom_pending = true;
+  return 0;
+}
+// For a caller that keeps u on the device (the resident overlays tracer_gpu.F + clinic_gpu.F), on the momentum stream,
+// beside whatever the main stream still does; nothing is waited for until uvic_gpu_momentum_wait.
+//
+// uvic_gpu_overlay_velocities: the start of a leapfrog step, before `tracer` -- what loadmw does to u with the memory
+// window wide open (u09/mom/loadmw.F:86-99): the time levels rotate, the external mode of psi(,,1) is added to u(tau) (of
+// psi(,,2) to u(tau-1) as well if `ext_taum1`: the first time step); then adv_vel (source/mom/adv_vel.F:63-131) into the
+// copy of the step's inputs the tracer step will read: the uvic_gpu_overlay_inputs that follows leaves adv_vet, adv_vnt out.
+extern "C" int uvic_gpu_overlay_velocities(uvic_gpu *h, int ext_taum1, const double *psi) {
+  if (!h || !psi) return fail_msg("uvic_gpu_overlay_velocities: null argument");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = momentum_stream(h)) return rc;
+  if (int rc = mom_host_join(h)) return rc;
+  const uvic_dims &d = h->d;
+  const size_t N2 = (size_t)d.imt * d.jmt;
+  hipStream_t st = h->side_mom;
+  if (int rc = uvic_gpu_rotate_u(h)) return rc;
+  HIPCHK(hipMemcpyAsync(h->buf[UVIC_F_PSI], psi, 2 * N2 * 8, hipMemcpyHostToDevice, st));
+  // the copy of the inputs the coming tracer step reads (it was the copy of the step three back: nothing reads it any more)
+  if (int rc = inputs_next_copy(h)) return rc;
+  const uvic_mom_ctx m = mom_ctx(h);
+  for (int level = 0; level >= (ext_taum1 ? -1 : 0); --level) {
+    const double *ps = (const double *)h->buf[UVIC_F_PSI] + (level == 0 ? 0 : N2);
+    double *u1 = (double *)h->buf[level == 0 ? UVIC_F_U1 : UVIC_F_UM1], *u2 = (double *)h->buf[level == 0 ? UVIC_F_U2 : UVIC_F_UM2];
+    hipLaunchKernelGGL(k_add_ext_mode, dim3(col_blocks(h, 64)), dim3(64), 0, st, m, ps, u1, u2);
+  }
+  hipLaunchKernelGGL(k_adv_vel_hor, dim3(cell_blocks(h, 256)), dim3(256), 0, st, h->ctx);
+  hipLaunchKernelGGL(k_adv_vel_vert, dim3(col_blocks(h, 64)), dim3(64), 0, st, h->ctx);
+  HIPCHK(hipEventRecord(h->in.ev_vel, st));
+  h->in.vel_pending = true;
+  velocity_touched(h, UVIC_F_ADV_VET);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// uvic_gpu_overlay_momentum: the momentum row itself, where the reference calls `clinic` (after `tracer`, mom.F:389-395) --
+// the time-step monitor's kinetic energy of u(tau) (clinic.F:616-630; ektot (0:km, jmt)) if ektot_host is given; `state`
+// (loadmw.F:154) from T,S of the level the step began with as t(tau) -- t_level 0: UVIC_F_T_TAU, -1: UVIC_F_T_TAUM1 (the
+// tracer step of this time step has rotated the levels already) -- unless rho_host (imt,km,2:jmt) is given; `clinic` with
+// sbc_flags/rts as uvic_gpu_clinic; zu (imt,jmt,2) to zu_host.  `fresh`: u(tau), u(tau-1) have just been uploaded on the
+// main stream.  u(tau+1) stays on the device (UVIC_F_UP1/UP2).
+// smf, rho_host, zu_host, ektot_host: page-locked, left alone until uvic_gpu_momentum_wait returns.
+extern "C" int uvic_gpu_overlay_momentum(uvic_gpu *h, int fresh, int t_level, int sbc_flags, double rts, double rho0, const double *smf,
+                                         const double *rho_host, double *zu_host, double *ektot_host) {
+  if (!h || !smf || !zu_host) return fail_msg("uvic_gpu_overlay_momentum: null argument");
+  if (!h->have_clinic) return fail_msg("uvic_gpu_overlay_momentum: call uvic_gpu_set_clinic_params first");
+  if (t_level != 0 && t_level != -1) return fail_msg("uvic_gpu_overlay_momentum: t_level is 0 or -1");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = momentum_stream(h)) return rc;
+  if (int rc = mom_host_join(h)) return rc;
+  const uvic_dims &d = h->d;
+  const size_t N2 = (size_t)d.imt * d.jmt, N3 = N2 * d.km, row = (size_t)d.imt * d.km;
+  hipStream_t st = h->side_mom;
+  if (fresh) {   // the levels (and whatever else the caller uploaded) came up on the main stream just now
+    HIPCHK(hipEventRecord(h->ev_mom_in, h->stream));
+    HIPCHK(hipStreamWaitEvent(st, h->ev_mom_in, 0));
+  }
+  HIPCHK(hipMemcpyAsync(h->buf[UVIC_F_SMF], smf, 2 * N2 * 8, hipMemcpyHostToDevice, st));
+  if (rho_host) HIPCHK(hipMemcpyAsync((char *)h->buf[UVIC_F_RHO] + row * 8, rho_host, (N3 - row) * 8, hipMemcpyHostToDevice, st));
+  if (ektot_host) {
+    const size_t n = (size_t)(d.km + 1) * d.jmt;
+    if (!h->in.ektot_dev) HIPCHK(hipMalloc((void **)&h->in.ektot_dev, n * 8));
+    HIPCHK(hipMemsetAsync(h->in.ektot_dev, 0, n * 8, st));
+    const int work = d.km * (h->ctx.je - h->ctx.js + 1);
+    hipLaunchKernelGGL(k_tsi_ektot, dim3((unsigned)((work + 63) / 64)), dim3(64), 0, st, h->ctx, (const double *)h->buf[UVIC_F_U1],
+                       (const double *)h->buf[UVIC_F_U2], rho0, h->in.ektot_dev);
+    HIPCHK(hipMemcpyAsync(ektot_host, h->in.ektot_dev, n * 8, hipMemcpyDeviceToHost, st));
+  }
+  if (!rho_host) {
+    uvic_mom_ctx m = mom_ctx(h);
+    if (t_level == -1) { m.t_tau = h->ctx.t_taum1; m.s_tau = h->ctx.t_taum1 + N3; }
+    hipLaunchKernelGGL(k_state, dim3(cell_blocks(h, 256)), dim3(256), 0, st, m);
+  }
+  if (int rc = launch_clinic(h, sbc_flags, rts, st)) return rc;
+  HIPCHK(hipMemcpyAsync(zu_host, h->buf[UVIC_F_ZU], 2 * N2 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(h->ev_mom_done, st));
+  h->mom_pending = true;
+  HIPCHK(hipGetLastError());
   return 0;
 }
 extern "C" int uvic_gpu_momentum_wait(uvic_gpu *h) {
@@ -3453,25 +3544,14 @@ extern "C" int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload) {
 // `ts_host` (imt, km, jmt, 2) as soon as they are final, the surface sums are updated behind the step, the time levels
 // rotate -- and the call returns when T,S are on the host, while pass B of the other tracers may still be running
 // (the next call queues behind it).
-// The step's inputs from the host in one call (the resident overlay: tracer_gpu.F), replacing six uvic_gpu_upload_rows.
-// Host arrays as the memory window holds them: adv_vet (imt,km,jsmw:jmt), adv_vnt (imt,km,1:jmt), adv_vbt
-// (imt,0:km,jsmw:jmt) or null, diff_cbt (imt,km,jsmw:jemw), stf and btf (imt,jmt,nt); page-locked (uvic_gpu_pin_host).
-// The copies do not go through the main stream: they run on two streams of their own into the device copy the previous
-// step does not read, T and S first -- the horizontal velocities, diff_cbt and the T,S planes of the fluxes, after which
-// the T,S passes may start -- then the fluxes of the other tracers, which the bulk pass A waits for.  A null adv_vbt is
-// formed on the device from adv_vet and adv_vnt, as adv_vel.F:98-127 does on the host (rigid lid: zero at the surface).
-extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
-                                       const double *diff_cbt, const double *stf, const double *btf) {
-  if (!h || !adv_vet || !adv_vnt || !diff_cbt || !stf || !btf) return fail_msg("uvic_gpu_overlay_inputs: null argument");
-  const uvic_dims &d = h->d;
-  if (jsmw < 1 || jsmw > 2 || jemw < jsmw || jemw > d.jmt) return fail_msg("uvic_gpu_overlay_inputs: window rows outside 1..jmt");
-  h->idle_until_next = false;
-  HIPCHK(hipSetDevice(h->device));
-  if (int rc = mom_host_join(h)) return rc;
+// the device copy of the step's inputs that the coming step will read: the one after the current one if a step has been
+// queued on that (three copies, made on the first call as images of the fields a plain upload fills)
+static int inputs_next_copy(uvic_gpu *h) {
   auto &I = h->in;
+  const uvic_dims &d = h->d;
   const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt, N2 = (size_t)d.imt * d.jmt;
   const size_t bytes[5] = {N3 * 8, N3 * 8, NF * 8, N2 * d.nt * 8, N2 * d.nt * 8};
-  if (!I.st[0]) {   // first call: the other copies start as images of the first (rows no upload covers keep their values)
+  if (!I.st[0]) {   // (rows no upload covers keep their values)
     for (int q = 0; q < 5; ++q) {
       I.set[0][q] = (double *)h->buf[IN_FIELDS[q]];
       for (int z = 1; z < 3; ++z) {
@@ -3485,25 +3565,51 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
     for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&I.ev_link[q], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&I.ev_first, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&I.ev_rest, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&I.ev_vel, hipEventDisableTiming));
     I.cur = 0; I.used = true;
   }
-  if (I.used) {   // the steps queued so far read the current copy and the one before: fill the third
+  if (I.used) {
     I.cur = (I.cur + 1) % 3; I.used = false;
     for (int q = 0; q < 5; ++q) h->buf[IN_FIELDS[q]] = I.set[I.cur][q];
     bind_ctx(h);
   }
+  return 0;
+}
+// The step's inputs from the host in one call (the resident overlay: tracer_gpu.F), replacing six uvic_gpu_upload_rows.
+// Host arrays as the memory window holds them: adv_vet (imt,km,jsmw:jmt), adv_vnt (imt,km,1:jmt), adv_vbt
+// (imt,0:km,jsmw:jmt) or null, diff_cbt (imt,km,jsmw:jemw), stf and btf (imt,jmt,nt); page-locked (uvic_gpu_pin_host).
+// The copies do not go through the main stream: they run on two streams of their own into the device copy the previous
+// step does not read, T and S first -- the horizontal velocities, diff_cbt and the T,S planes of the fluxes, after which
+// the T,S passes may start -- then the fluxes of the other tracers, which the bulk pass A waits for.  A null adv_vbt is
+// formed on the device from adv_vet and adv_vnt, as adv_vel.F:98-127 does on the host (rigid lid: zero at the surface).
+extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
+                                       const double *diff_cbt, const double *stf, const double *btf) {
+  if (!h || !diff_cbt || !stf || !btf || (!adv_vet) != (!adv_vnt)) return fail_msg("uvic_gpu_overlay_inputs: null argument");
+  if (!adv_vet && !(h->in.vel_pending && !h->in.used))
+    return fail_msg("uvic_gpu_overlay_inputs: no velocities given and none formed on the device for this step (uvic_gpu_overlay_momentum)");
+  const uvic_dims &d = h->d;
+  if (jsmw < 1 || jsmw > 2 || jemw < jsmw || jemw > d.jmt) return fail_msg("uvic_gpu_overlay_inputs: window rows outside 1..jmt");
+  h->idle_until_next = false;
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = mom_host_join(h)) return rc;
+  auto &I = h->in;
+  const size_t N3 = (size_t)d.imt * d.km * d.jmt, NF = (size_t)d.imt * (d.km + 1) * d.jmt, N2 = (size_t)d.imt * d.jmt;
+  if (int rc = inputs_next_copy(h)) return rc;
   hipStream_t sa = I.st[0], sb = I.st[1] ? I.st[1] : I.st[0];
   const size_t row = (size_t)d.imt * d.km * 8, rowf = (size_t)d.imt * (d.km + 1) * 8;
   double **dev = I.set[I.cur];
   auto up = [&](hipStream_t st, void *dst, const void *src, size_t n) { return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st); };
   // (two copies at a time move 59 GB/s where one moves 47; each copy costs ~10 us of latency on its stream: the two
   // long ones on one stream, the third long one and the two short ones on the other)
-  HIPCHK(up(sa, (char *)dev[0] + (size_t)(jsmw - 1) * row, adv_vet, (size_t)(d.jmt - jsmw + 1) * row));
-  HIPCHK(up(sb, dev[1], adv_vnt, (size_t)d.jmt * row));
+  if (adv_vet) {
+    HIPCHK(up(sa, (char *)dev[0] + (size_t)(jsmw - 1) * row, adv_vet, (size_t)(d.jmt - jsmw + 1) * row));
+    HIPCHK(up(sb, dev[1], adv_vnt, (size_t)d.jmt * row));
+    I.vel_pending = false;
+  }
   HIPCHK(up(sa, (char *)h->buf[UVIC_F_DIFF_CBT] + (size_t)(jsmw - 1) * row, diff_cbt, (size_t)(jemw - jsmw + 1) * row));
   HIPCHK(up(sb, dev[3], stf, 2 * N2 * 8));
   HIPCHK(up(sb, dev[4], btf, 2 * N2 * 8));
-  if (adv_vbt) HIPCHK(up(sb, (char *)dev[2] + (size_t)(jsmw - 1) * rowf, adv_vbt, (size_t)(d.jmt - jsmw + 1) * rowf));
+  if (adv_vbt && adv_vet) HIPCHK(up(sb, (char *)dev[2] + (size_t)(jsmw - 1) * rowf, adv_vbt, (size_t)(d.jmt - jsmw + 1) * rowf));
   if (sb != sa) { HIPCHK(hipEventRecord(I.ev_link[0], sb)); HIPCHK(hipStreamWaitEvent(sa, I.ev_link[0], 0)); }
   HIPCHK(hipEventRecord(I.ev_first, sa));
   if (d.nt > 2) {
@@ -3514,7 +3620,7 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
   HIPCHK(hipEventRecord(I.ev_rest, sa));
   I.first_pending = I.rest_pending = true;
   I.rest_inflight = true;
-  I.derive_vbt = adv_vbt == nullptr;
+  I.derive_vbt = adv_vbt == nullptr || adv_vet == nullptr;
   velocity_touched(h, UVIC_F_ADV_VET);
   return 0;
 }
@@ -3523,6 +3629,7 @@ static int inputs_first(uvic_gpu *h, bool vbt_follows) {
   h->in.used = true;
   if (!h->in.first_pending) return 0;
   HIPCHK(hipStreamWaitEvent(h->stream, h->in.ev_first, 0));
+  if (h->in.vel_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->in.ev_vel, 0)); h->in.vel_pending = false; }
   h->in.first_pending = false;
   h->in.waited = true;
   if (h->in.derive_vbt && !vbt_follows) {

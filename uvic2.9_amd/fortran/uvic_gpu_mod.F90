@@ -44,6 +44,8 @@
       integer(c_int), parameter :: F_DIFF_CBT_BG=38, F_STF=39, F_BTF=40
       integer(c_int), parameter :: F_SRC=41, F_ITRC=42
       integer(c_int), parameter :: F_DIFF_CBT=58
+!     adv_vel on the device (uvic_gpu_overlay_velocities)
+      integer(c_int), parameter :: F_DXT2R=61, F_DYT2R=62
 !     baroclinic momentum step (clinic_gpu.F)
       integer(c_int), parameter :: F_U1=59, F_U2=60, F_RHO=69
       integer(c_int), parameter :: F_UM1=70, F_UM2=71, F_UP1=72, F_UP2=73
@@ -57,7 +59,7 @@
       integer(c_int), parameter :: F_ADVMET=93, F_AM3=94, F_AM4=95
       integer(c_int), parameter :: F_SBC_GU=96, F_SBC_GV=97, F_SBC_SU=98
       integer(c_int), parameter :: F_SBC_SV=99, F_SPSIN=100, F_SPCOS=101
-      integer(c_int), parameter :: F_PHI=102
+      integer(c_int), parameter :: F_PHI=102, F_PSI=103
 
 !     scalars of clinic (include/uvic_gpu.h: uvic_clinic_params)
       type, bind(C) :: uvic_clinic_params
@@ -239,6 +241,16 @@
           type(c_ptr), value :: adv_vbt
           integer(c_int) :: rc
         end function
+        function uvic_gpu_overlay_inputs_dev(h, jsmw, jemw, p1, p2, p3, diff_cbt, stf, btf)                   &
+     &      bind(C,name='uvic_gpu_overlay_inputs') result(rc)
+!         the same entry point with no velocities (p1 = p2 = p3 = c_null_ptr): uvic_gpu_overlay_velocities made them
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: jsmw, jemw
+          type(c_ptr), value :: p1, p2, p3
+          real(c_double) :: diff_cbt(*), stf(*), btf(*)
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_overlay_inputs_vbt(h, jsmw, jemw, adv_vet, adv_vnt, adv_vbt, diff_cbt, stf, btf)   &
      &      bind(C,name='uvic_gpu_overlay_inputs') result(rc)
 !         the same entry point with adv_vbt sent as well (free surface: not zero at the top)
@@ -246,6 +258,40 @@
           type(c_ptr), value :: h
           integer(c_int), value :: jsmw, jemw
           real(c_double) :: adv_vet(*), adv_vnt(*), adv_vbt(*), diff_cbt(*), stf(*), btf(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_overlay_velocities(h, ext_taum1, psi) bind(C,name='uvic_gpu_overlay_velocities') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: ext_taum1
+          real(c_double) :: psi(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_overlay_momentum(h, fresh, t_level, sbc_flags, rts, rho0, smf, rho_host, zu_host, ektot_host)   &
+     &      bind(C,name='uvic_gpu_overlay_momentum') result(rc)
+!         rho_host, ektot_host: c_loc of the array or c_null_ptr
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: fresh, t_level, sbc_flags
+          real(c_double), value :: rts, rho0
+          real(c_double) :: smf(*), zu_host(*)
+          type(c_ptr), value :: rho_host, ektot_host
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_momentum_wait(h) bind(C,name='uvic_gpu_momentum_wait') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_rotate_u(h) bind(C,name='uvic_gpu_rotate_u') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_add_ext_mode(h, level) bind(C,name='uvic_gpu_add_ext_mode') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: level
           integer(c_int) :: rc
         end function
         function uvic_gpu_overlay_step(h, s, ts_host) bind(C,name='uvic_gpu_overlay_step') result(rc)
@@ -296,6 +342,10 @@
       end interface
 
       type(c_ptr), save :: uvic_handle = c_null_ptr
+!     what the overlays have set up on the device instance (module state, so that tracer_gpu_close can start over):
+!     static fields of `tracer` / of `clinic` uploaded, MOBI bound, the filter rows the operators were built for
+      logical, save :: uvic_tracer_ready = .false., uvic_clinic_ready = .false., uvic_mobi_set = .false.
+      integer, save :: uvic_flt_rows(4) = (/ -1, -1, -1, -1 /), uvic_fltu_rows(4) = (/ -1, -1, -1, -1 /)
 !     time step (itt) whose adv_vet/adv_vnt/adv_vbt the tracer overlay has put on the device: clinic_gpu.F, called
 !     later in the same step (source/mom/mom.F:389-395), need not send them again
       integer, save :: uvic_adv_itt = -1
@@ -303,12 +353,31 @@
 !     the device from step to step; uvic_dev_state says that the device holds t(tau-1), t(tau) of the coming step
       logical, save :: uvic_resident = .false.
       logical, save :: uvic_dev_state = .false.
+!     ... and so do the velocities (UVIC_RESIDENT=2: uvic_resident_u) once clinic_gpu.F has made a time step on the
+!     device: uvic_u_dev says that the device
+!     holds the internal mode of u(tau+1) of step uvic_u_itt (and u(tau), u(tau-1) of that step, external mode included);
+!     uvic_u_rot_itt is the step for which the device has rotated the levels and added the external mode (done by the
+!     first overlay called in a step), uvic_u_host_itt the step for which the host's u(tau), u(tau-1) are what the
+!     device holds; uvic_vel_dev_itt the step whose adv_v?t were formed on the device
+      logical, save :: uvic_resident_u = .false.
+      logical, save :: uvic_u_dev = .false.
+      integer, save :: uvic_u_itt = -1, uvic_u_rot_itt = -1, uvic_u_host_itt = -1, uvic_vel_dev_itt = -1
+!     the step after which the device holds the running sums of isbcu/asbcu (clinic.F:729-895)
+      integer, save :: uvic_sbcu_itt = -1
+      real(c_double), allocatable, target, save :: uvic_zu(:,:,:)
 !     resident mode keeps the surface sums of set_sbc on the device for these tracers (n >= 3 with trsbcindex(n) /= 0)
       integer, save :: uvic_nsbc = 0
       integer(c_int32_t), allocatable, save :: uvic_sbc_tracer(:)
       real(c_double), allocatable, save :: uvic_sbc_plane(:,:,:)
 
       contains
+
+      function uvic_addr(a) result(p)
+!       the address of a COMMON array (which has no TARGET attribute of its own) for an optional argument of the C ABI
+        real(c_double), target :: a(*)
+        type(c_ptr) :: p
+        p = c_loc(a)
+      end function
 
       subroutine uvic_check(rc, where)
         integer(c_int), intent(in) :: rc
