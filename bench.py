@@ -224,6 +224,8 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "push", "rccl"],
                     help="N>1: how t(tau+1) moves between ranks -- the library's direct push through hipIpc-mapped windows, "
                          "or RCCL (all-gather / send-recv); auto = push if every rank can map its peers and a trial exchange arrives")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a diagnostic switch of the library (uvic_gpu_set_option), e.g. close_step=1; not the measured configuration")
     ap.add_argument("--segment", type=int, default=0, metavar="NTSPOS",
                     help="ocean steps per coupling segment: the first step of a segment gets new surface forcing, so its MOBI "
                          "sources are not computed a step ahead (0 = the synthetic forcing is constant, the default)")
@@ -290,6 +292,8 @@ def main():
     if cfg.ntnpzd:
         m.set_mobi(ocean)
     shard.apply(m)
+    for kv in a.option:
+        m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if a.one_slab_of > 1 and world == 1:
         from uvic29_amd.parallel import slab_rows
         js, je = slab_rows(jmt, a.one_slab_of, a.one_slab_of // 2)
@@ -444,6 +448,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             **({"diagnosis": f"one middle slab of {a.one_slab_of}: rows {js}..{je} only, no exchange; not the metric"} if a.one_slab_of > 1 and world == 1 else {}),
+            **({"diagnosis_options": a.option} if a.option else {}),
             "config": {"workload": f"{cfg.name} nt={nt} nsrc={nsrc} {imt}x{jmt}x{km}: isopyc + tracer step "
                                    f"(FCT adv_flux, isoflux, explicit update, invtri, convct2"
                                    f"{', MOBI sources (mobi_driver/mobi_src/co2calc_SWS)' if m_has_mobi(m) else ', source term given'})",

@@ -1030,6 +1030,7 @@ struct uvic_gpu {
   long long mobi_ev_step[2];
   hipEvent_t ev_src_inline2[2];
   long long end_step_of[2];       // the step that recorded ev_step_end[q]
+  bool close_step = false;        // uvic_gpu_set_option "close_step"
   bool prep_deferred;             // launch_isopyc left k_inputs_cell (and the wait for the inputs) to launch_transport
   hipEvent_t ev_src_inline;       // sources of the current step computed on a MOBI side stream (launch_mobi)
   int sbc_count;                // tracers whose surface level is accumulated
@@ -1180,6 +1181,7 @@ extern "C" int uvic_gpu_set_option(uvic_gpu *h, const char *name, int value) {
   if (n == "mobi_team") { h->mobi_team = value != 0; return 0; }         // 0: one thread per column instead of four-wave teams
   if (n == "convect_onepass") { h->exact_convect = value != 0; return 0; }   // convct2 as one kernel over all tracers
   if (n == "mobi_streams") { h->mobi_two_streams = value != 1 && h->side_m[1] != h->side_m[0]; return 0; }   // 1: every MOBI chain on the first side stream
+  if (n == "close_step") { h->close_step = value != 0; return 0; }   // diagnosis: no chain crosses a step boundary (see uvic_gpu_step_lookahead_at)
   if (n == "upload_streams") {   // copy streams of uvic_gpu_overlay_inputs (before its first call)
     if (h->in.st[0]) return fail_msg("uvic_gpu_set_option: upload_streams after the first uvic_gpu_overlay_inputs");
     h->in.nstreams = value == 1 ? 1 : 2; return 0;
@@ -2881,6 +2883,14 @@ extern "C" int uvic_gpu_step_lookahead_at(uvic_gpu *h, double c2dtts, int mixing
     if (int rc = prefetch_isopyc_ahead(h, 1)) return rc;
   if ((iso_ahead & 2) && !h->ctx.diff_cbt_given)
     if (int rc = prefetch_isopyc_ahead(h, 2)) return rc;
+  if (h->close_step) {
+    // diagnosis (uvic_gpu_set_option "close_step"): every chain queued in this step ends before the step does -- what a
+    // step captured as one HIP graph would impose, since a graph launch ends before the next one in its stream begins
+    if (h->prefetch_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_pending, 0));
+    for (int q = 0; q < 3; ++q)
+      if (h->iso_set[q].for_step > h->step_no) HIPCHK(hipStreamWaitEvent(h->stream, h->iso_set[q].ev, 0));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
+  }
   h->unmix_at_rotate = mixing != 0;
   static const bool fewer = uv_env("UVIC_MAIN_ALIAS") && atoi(uv_env("UVIC_MAIN_ALIAS")) != 0;
   h->idle_until_next = fewer && (iso_ahead & 4) != 0;   // bit 2: the caller queues nothing on the main stream before the next step
