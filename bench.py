@@ -143,6 +143,38 @@ def cpu_baseline(ocean, to, so, c, src, budget_s=20.0):
                       f"oracle (gcc -O2 -ffp-contract=off), {cfg.name} {g.imt}x{g.jmt}x{g.km}"}
 
 
+def cpu_baseline_ncore(ocean, to, so, c, src, budget_s=8.0):
+    """A courtesy figure beside `cpu_baseline`: the C oracle with its independent pieces shared out over this box's cores
+    (OpenMP: the tracers of the transport, the rows of convct2 and of the MOBI sources; isopyc stays on one).  The same
+    arithmetic as on one core; what a maintainer could get from the host without touching the algorithm."""
+    import oracle_c
+    g, cfg = ocean.grid, ocean.cfg
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    lib = oracle_c.lib()
+    lib.orc_set_threads(cores)
+    try:
+        orc = oracle_c.Oracle(ocean, to=to, so=so, c=c, src=src)
+        prm = None
+        if cfg.ntnpzd:
+            import mobi_c
+            from uvic29_amd import mobi as pm
+            prm = pm.load_table(cfg.name, g.km)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            if prm is not None:
+                orc.set_src(mobi_c.mobi_sources(ocean, prm, ocean.t_taum1, 2.0 * ocean.params.dtts))
+            orc.isopyc(); orc.add_k33(); orc.transport()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 20:
+                break
+    finally:
+        lib.orc_set_threads(1)
+    return {"value": g.imt * g.jmt * g.km * cfg.nt * n / el, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full steps of the C oracle (gcc -O2 -ffp-contract=off -fopenmp), tracers / rows shared out over "
+                      f"{cores} threads, {cfg.name} {g.imt}x{g.jmt}x{g.km}"}
+
+
 def clinic_cpu_baseline(imt, jmt, km, ncall=5):
     """The reference's own state + clinic (with filuv) on one host core (oracle/_ref build "m2"), ms per call."""
     import refmodel
@@ -487,6 +519,10 @@ def main():
                     out["overlay_ms_per_step"] = ov["loop_ms"]
         if not a.no_cpu_baseline and world == 1:      # the CPU baseline is reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(ocean, to, so, c, src)
+            try:
+                out["cpu_baseline_ncore"] = cpu_baseline_ncore(ocean, to, so, c, src)
+            except Exception as e:      # a courtesy figure: never let it break the bench line
+                out["cpu_baseline_ncore"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     m.close()
     if world > 1:

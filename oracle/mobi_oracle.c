@@ -713,13 +713,15 @@ void orc_mobi_sources(const orc_mobi *P, const orc_mobi_forcing *F, int imt, int
   for (int m = 1; m <= 12; ++m)
     if (yrtime <= m / 12.) { mi = m; break; }
   const double declin = sin((fmod(F->relyr, 1.) - 0.22) * 2. * pi) * 0.4;
-  double tnpzd[ORC_MOBI_MAXK * ORC_MOBI_MAXT], col_src[ORC_MOBI_MAXK * ORC_MOBI_MAXT];
-  double t_in[ORC_MOBI_MAXK], o2_in[ORC_MOBI_MAXK], aou_in[ORC_MOBI_MAXK], s_in[ORC_MOBI_MAXK], dic_in[ORC_MOBI_MAXK];
-  double alk_in[ORC_MOBI_MAXK], sgb_in[ORC_MOBI_MAXK];
 #define T4(i, k, j, n) t_taum1[(size_t)((i)-1) + (size_t)imt * ((size_t)((k)-1) + (size_t)km * ((j)-1)) + (size_t)((n)-1) * N3]
 #define SRC4(i, k, j, s) src[(size_t)((i)-1) + (size_t)imt * ((size_t)((k)-1) + (size_t)km * ((j)-1)) + (size_t)((s)-1) * N3]
+  extern int orc_threads; /* uvic_oracle.c: > 1 for the N-core timing of bench.py only (columns are independent) */
+#pragma omp parallel for if (orc_threads > 1) num_threads(orc_threads) schedule(dynamic)
   for (int j = 2; j <= jmt - 1; ++j)
     for (int i = 2; i <= imt - 1; ++i) {
+      double tnpzd[ORC_MOBI_MAXK * ORC_MOBI_MAXT], col_src[ORC_MOBI_MAXK * ORC_MOBI_MAXT];
+      double t_in[ORC_MOBI_MAXK], o2_in[ORC_MOBI_MAXK], aou_in[ORC_MOBI_MAXK], s_in[ORC_MOBI_MAXK], dic_in[ORC_MOBI_MAXK];
+      double alk_in[ORC_MOBI_MAXK], sgb_in[ORC_MOBI_MAXK];
       const int kmx = kmt[(i - 1) + (size_t)imt * (j - 1)];
       if (kmx <= 0) continue;
       const size_t ij = (size_t)(i - 1) + (size_t)imt * (j - 1);

@@ -42,7 +42,7 @@ def build(force: bool = False) -> Path:
     srcs = [s for s in SOURCES if s.exists()]
     if LIB.exists() and not force and all(LIB.stat().st_mtime >= s.stat().st_mtime for s in srcs + list(HERE.glob("*.h"))):
         return LIB
-    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=gnu99", "-o", str(LIB)] + [str(s) for s in srcs] + ["-lm"]
+    cmd = ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-std=gnu99", "-o", str(LIB)] + [str(s) for s in srcs] + ["-lm"]
     subprocess.run(cmd, check=True)
     return LIB
 

@@ -12,6 +12,15 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads for the courtesy N-core timing of bench.py (cpu_baseline_ncore): the tracers of orc_tracer_transport, the rows of
+ * convct2 and the rows of orc_mobi_sources are independent, so they are shared out; every value is computed by the same
+ * expressions as with one thread (the default, which the parity tests use). */
+int orc_threads = 1;
+void orc_set_threads(int n) { orc_threads = n > 1 ? n : 1; }
 
 #define EPSLN 1.0e-20 /* source/common/pconst.h:20 */
 #define P5 0.5
@@ -833,17 +842,39 @@ void orc_tracer_transport(orc_ctx *c) {
   DIMS;
   double *twodt = (double *)malloc(sizeof(double) * km);
   for (int k = 1; k <= km; ++k) twodt[k - 1] = c->c2dtts * c->dtxcel[k - 1];
-  for (int n = 1; n <= c->nt; ++n) {
-    orc_adv_flux(c, n);
-    orc_diff_flux(c, n);
-    orc_isoflux(c, n);
-    orc_explicit_update(c, n);
-    double *tp = c->t_taup1 + (size_t)(n - 1) * N3;
-    orc_invtri(c, tp, c->stf + (size_t)(n - 1) * imt * jmt, c->btf + (size_t)(n - 1) * imt * jmt, c->diff_cbt, twodt, 2,
-               imt - 1, 2, jmt - 1);
-    for (int j = 2; j <= jmt - 1; ++j) orc_setbcx(&tp[X3(1, 1, j)], imt, km);
+#pragma omp parallel if (orc_threads > 1) num_threads(orc_threads)
+  {
+    orc_ctx lc = *c; /* with several threads: the per-tracer work arrays are each thread's own */
+    int mine = 0;
+#ifdef _OPENMP
+    mine = omp_in_parallel();
+#endif
+    if (mine) {
+      lc.adv_fe = (double *)calloc(N3, sizeof(double)); lc.adv_fn = (double *)calloc(N3, sizeof(double));
+      lc.adv_fb = (double *)calloc(NF, sizeof(double)); lc.diff_fe = (double *)calloc(N3, sizeof(double));
+      lc.diff_fn = (double *)calloc(N3, sizeof(double)); lc.diff_fb = (double *)calloc(NF, sizeof(double));
+      lc.diff_fbiso = (double *)calloc(NF, sizeof(double));
+    }
+#pragma omp for schedule(dynamic)
+    for (int n = 1; n <= c->nt; ++n) {
+      orc_adv_flux(&lc, n);
+      orc_diff_flux(&lc, n);
+      orc_isoflux(&lc, n);
+      orc_explicit_update(&lc, n);
+      double *tp = c->t_taup1 + (size_t)(n - 1) * N3;
+      orc_invtri(&lc, tp, c->stf + (size_t)(n - 1) * imt * jmt, c->btf + (size_t)(n - 1) * imt * jmt, c->diff_cbt, twodt, 2,
+                 imt - 1, 2, jmt - 1);
+      for (int j = 2; j <= jmt - 1; ++j) orc_setbcx(&tp[X3(1, 1, j)], imt, km);
+    }
+    if (mine) {
+      free(lc.adv_fe); free(lc.adv_fn); free(lc.adv_fb); free(lc.diff_fe); free(lc.diff_fn); free(lc.diff_fb); free(lc.diff_fbiso);
+    }
   }
-  orc_convct2(c, c->t_taup1, 2, imt - 1, 2, jmt - 1);
+  if (orc_threads > 1) {
+#pragma omp parallel for num_threads(orc_threads) schedule(dynamic)
+    for (int j = 2; j <= jmt - 1; ++j) orc_convct2(c, c->t_taup1, 2, imt - 1, j, j);
+  } else
+    orc_convct2(c, c->t_taup1, 2, imt - 1, 2, jmt - 1);
   for (int n = 1; n <= c->nt; ++n)
     for (int j = 2; j <= jmt - 1; ++j) orc_setbcx(&c->t_taup1[(size_t)(n - 1) * N3 + X3(1, 1, j)], imt, km);
   free(twodt);
