@@ -198,7 +198,7 @@ def clinic_cpu_baseline(imt, jmt, km, ncall=5):
 def overlay_baseline(ocean, steps=40, segment=4):
     """The path the north star names: the reference's own call sequence with `tracer` replaced by the Fortran overlay
     (uvic2.9_amd/fortran/tracer_gpu.F -> ISO_C_BINDING -> libuvic_gpu.so), resident mode, driven through the compiled
-    reference's COMMON blocks (oracle/_ref/libuvicshim_*; a second model instance on the same GPU).  PCIe included:
+    reference's COMMON blocks (oracle/_ref/libuvicshim_*; tools/overlay_time.py in a process of its own).  PCIe included:
     velocities, diff_cbt, stf, btf up and T,S down every step; ocean segments of `segment` steps (run/control.in:
     segtim 5 d / dtts 1.25 d), whose first step computes its MOBI sources in line.
       call_ms      median wall time of one `tracer` call when the host does its own work between calls (here: the host
@@ -206,39 +206,36 @@ def overlay_baseline(ocean, steps=40, segment=4):
       loop_ms      wall time per step of the calls alone, back to back (the device never idles)"""
     import refmodel
     g, cfg = ocean.grid, ocean.cfg
-    if cfg.name not in ("p2", "c30") or not refmodel.available(cfg.name, g.imt, g.jmt, g.km, shim=True):
+    if cfg.name != "c30" or (g.imt, g.jmt, g.km) != (102, 102, 19) or not refmodel.available(cfg.name, g.imt, g.jmt, g.km, shim=True):
         return None
-    os.environ["UVIC_RESIDENT"] = "1"
-    import refdriver
-    shim = refdriver.RefOcean(ocean, shim=True)
-    shim.set_step_kind(False)
-    shim.ref.set("nmix", 0)
-    shim.ref.set("ntspos", segment)
-    shim.ref.set("prelyr", float(shim.v["relyr"][0]))
+    return _tool_json("overlay_time.py", [str(steps)], {"UVIC_RESIDENT": "1", "OVERLAY_SEGMENT": str(segment)})
 
-    def switches(it):
-        shim.ref.set("itt", it)
-        shim.ref.set("osegs", 1 if (it - 1) % segment == 0 else 0)
-        shim.ref.set("osege", 1 if it % segment == 0 else 0)
 
-    it, calls = 0, []
-    for _ in range(steps + 4):
-        it += 1
-        switches(it)
-        shim.isopyc(); shim.add_k33()
-        t0 = time.perf_counter()
-        shim.tracer()
-        calls.append(time.perf_counter() - t0)
-        shim.rotate()
-    calls = sorted(calls[4:])
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        it += 1
-        switches(it)
-        shim.tracer()           # (no host rotation: the harness rotates by copying 2 x 47 MB, the model by permuting indices;
-    shim.ref.call("tracer_gpu_sync") if hasattr(shim.ref.lib, "tracer_gpu_sync_") else shim.flush()   # the state is on the device)
-    loop = (time.perf_counter() - t0) / steps
-    return {"call_ms": calls[len(calls) // 2] * 1e3, "loop_ms": loop * 1e3, "segment": segment, "steps": steps}
+def _tool_json(script, args, env):
+    """Run one of the Fortran-boundary timing tools in a process of its own -- as the Fortran driver is: no PyTorch, the
+    library the first user of the HIP runtime (it then asks for the hardware queues its streams need) -- and read the JSON
+    line it prints."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / script), *args, "--json"], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError((r.stderr or r.stdout)[-400:])
+    return json.loads(lines[-1])
+
+
+def ocean_overlay_baseline(imt, jmt, km, steps=32):
+    """Both Fortran overlays in the reference's own order (`tracer` then `clinic`, source/mom/mom.F:389-395) on option set C
+    built as run/mk.in builds it (oracle/_ref shim "t30": + O_stream_function, O_anisotropic_viscosity, O_ice_evp,
+    O_time_step_monitor) with the switches the shipped run/control.in gives: tsiperts on every step (the time-step
+    integrals are formed on the device), ocean segments of four steps; tracers and velocities resident (UVIC_RESIDENT=2).
+    The host routines of the loop run between the calls and are not timed.  Medians, ms per call (tools/ocean_overlay_time.py)."""
+    import refmodel
+    if (imt, jmt, km) != (102, 102, 19) or not refmodel.available("t30", imt, jmt, km, shim=True):
+        return None
+    out = _tool_json("ocean_overlay_time.py", [str(steps), "t30"], {"UVIC_RESIDENT": "2"})
+    out["switches"] = "tsiperts every step (run/control.in: tsiint = tsiper), segments of 4 steps, UVIC_RESIDENT=2"
+    return out
 
 
 def main():
@@ -517,6 +514,12 @@ def main():
                 out["overlay"] = ov
                 if "loop_ms" in ov:
                     out["overlay_ms_per_step"] = ov["loop_ms"]
+            try:
+                oo = ocean_overlay_baseline(imt, jmt, km) if a.cfg == "c30" else None
+            except Exception as e:
+                oo = {"error": str(e)}
+            if oo is not None:
+                out["overlay_ocean_loop"] = oo
         if not a.no_cpu_baseline and world == 1:      # the CPU baseline is reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(ocean, to, so, c, src)
             try:

@@ -233,7 +233,8 @@ DEFAULT_BUILDS = [
 
 
 SHIM_BUILDS = [("p2", 14, 14, 6), ("c30", 14, 14, 6), ("c30", 102, 102, 19), ("f18", 14, 14, 6), ("s37", 14, 14, 6),
-               ("m2", 14, 14, 6), ("m2", 102, 102, 19), ("m2i", 14, 14, 6), ("t30", 14, 14, 6)]
+               ("m2", 14, 14, 6), ("m2", 102, 102, 19), ("m2i", 14, 14, 6), ("t30", 14, 14, 6),
+               ("t30", 102, 102, 19)]     # bench.py: both overlays with the shipped switches (overlay_baseline(..., ocean_loop=True))
 
 
 def build_default(force: bool = False, verbose: bool = False, jobs: int = 4):

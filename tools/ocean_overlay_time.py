@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Wall time per time step of the two Fortran overlays together -- `tracer` then `clinic`, as source/mom/mom.F:389-395
-calls them -- on the 102x102x19 grid (oracle/_ref build "m2": T and S only), PCIe included, with the velocities shipped on
+calls them -- on the 102x102x19 grid (oracle/_ref shim "m2": T and S only; or "t30": option set C built as run/mk.in builds it, with tsiperts on every step
+and ocean segments of four steps), PCIe included, with the velocities shipped on
 every call (UVIC_RESIDENT=1) or resident on the device (UVIC_RESIDENT=2: psi and the wind stress up, zu down).  The host
 routines of the loop (loadmw's add_ext_mode, state, adv_vel, isopyc, setvbc) are run but not timed.
-usage: UVIC_RESIDENT=1|2 python tools/ocean_overlay_time.py [nsteps]"""
+usage: UVIC_RESIDENT=1|2 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--json]"""
 import os
 import sys
 import time
@@ -17,10 +18,13 @@ from uvic29_amd import synthetic  # noqa: E402
 import refdriver  # noqa: E402
 from test_clinic import _psi  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 24
+cfg = args[1] if len(args) > 1 else "m2"       # "t30": option set C built as run/mk.in builds it, tsiperts on every step
+as_json, seg = "--json" in sys.argv, 4
 dims = (102, 102, 19)
-oc = synthetic.make_ocean("m2", *dims)
-mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u)
+oc = synthetic.make_ocean(cfg, *dims)
+mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
 g = oc.grid
 R = refdriver.RefOcean(oc, shim=True)
 R.set_momentum(mom)
@@ -31,9 +35,15 @@ S("ihflx", np_ - 3); S("isflx", np_ - 2)
 v["sbc"][:, :, np_ - 4] = oc.stf[:, :, 0]; v["sbc"][:, :, np_ - 3] = oc.stf[:, :, 1]
 R.set_step_kind(False)
 v["u"][..., 2] = 0.0
+if cfg == "t30":
+    S("nmix", 0); S("ntspos", seg); S("prelyr", float(v["relyr"][0])); S("tsiperts", 1)
 tt, tc = [], []
 for it in range(1, n + 1):
     S("itt", it)
+    if cfg == "t30":
+        S("osegs", 1 if (it - 1) % seg == 0 else 0); S("osege", 1 if it % seg == 0 else 0)
+        for nm in ("tbar", "travar", "dtabs", "ektot"):      # diagi zeroes them at the start of every step
+            v[nm][...] = 0.0
     R.add_ext_mode(_psi(g, it), "tau")
     if it == 1:
         R.add_ext_mode(_psi(g, 0), "tau-1")
@@ -49,4 +59,9 @@ for it in range(1, n + 1):
     R.rotate()
     u = v["u"]; u[..., 0] = u[..., 1]; u[..., 1] = u[..., 2]
 med = lambda x: sorted(x[4:])[len(x[4:]) // 2] * 1e3
+if as_json:
+    import json
+    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "steps": n, "cfg": cfg,
+                      "resident": os.environ.get("UVIC_RESIDENT", "")}))
+    sys.exit(0)
 print(f"UVIC_RESIDENT={os.environ.get('UVIC_RESIDENT', '')}: tracer call {med(tt):.3f} ms, clinic call {med(tc):.3f} ms (medians over {n - 4} steps, PCIe included)")

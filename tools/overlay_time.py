@@ -11,7 +11,9 @@ sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "oracle"))
 from uvic29_amd import synthetic  # noqa: E402
 import refdriver  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+as_json = "--json" in sys.argv
+n = int(args[0]) if args else 12
 seg = int(os.environ.get("OVERLAY_SEGMENT", "4"))      # ocean steps per coupling segment (run/control.in: segtim 5 d / dtts 1.25 d)
 oc = synthetic.make_ocean("c30", 102, 102, 19)
 shim = refdriver.RefOcean(oc, shim=True)
@@ -34,7 +36,8 @@ g = oc.grid
 units = g.imt * g.jmt * g.km * oc.cfg.nt
 med = sorted(ts)[len(ts) // 2]
 mean = sum(ts) / len(ts)
-print(f"overlay tracer call, {'resident' if os.environ.get('UVIC_RESIDENT') == '1' else 'upload/download every step'}, "
+if not as_json:
+  print(f"overlay tracer call, {'resident' if os.environ.get('UVIC_RESIDENT') == '1' else 'upload/download every step'}, "
       f"segments of {seg} steps: median {med * 1e3:.3f} ms, mean {mean * 1e3:.3f} ms per step = {units / mean / 1e9:.2f} G cell-updates/s "
       f"(PCIe included)")
 # the calls alone, back to back (the device never idles)
@@ -49,5 +52,10 @@ for k in range(n):
     shim.tracer()        # (no host rotation here: the harness rotates by copying 2 x 47 MB, the model by permuting indices)
     each.append(time.perf_counter() - t1)
 el = time.perf_counter() - t0
-print(f"back to back: {el / n * 1e3:.3f} ms per step; calls by position in the segment (ms): "
+if as_json:
+    import json
+    print(json.dumps({"call_ms": med * 1e3, "loop_ms": el / n * 1e3, "segment": seg, "steps": n,
+                      "loop_ms_by_position_in_segment": [sum(each[q::seg]) / len(each[q::seg]) * 1e3 for q in range(seg)]}))
+else:
+  print(f"back to back: {el / n * 1e3:.3f} ms per step; calls by position in the segment (ms): "
       + ", ".join(f"{sum(each[q::seg]) / len(each[q::seg]) * 1e3:.3f}" for q in range(seg)) + f"; slowest {max(each) * 1e3:.3f}")

@@ -686,57 +686,81 @@ __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m,
 // step stays on the device.  One thread per (row, level, tracer) adds along i in the reference's order (a running sum is
 // not associative: the same order gives the same bits).  tp = t(tau+1) BEFORE convection (diagt1 is called at tracer.F:1161).
 // acc: tbar, travar, dtabs, each (0:km, nt, jmt) as source/common/diag.h declares them.
+// Sixteen rows (k, j, n) per wave.  Row by row the 64 lanes fetch 64 consecutive columns at once (coalesced) and form the
+// three terms of each column in parallel, into an LDS tile; then lane r adds up row r of the tile column by column -- the
+// sequential sum of diagt1 (tracer.F:1516-1537), to the bit -- so a row costs one load instruction per 64 columns instead
+// of 64 scattered ones and the serial part runs sixteen rows abreast.
+#define TSI_ROWS 16
 __global__ void __launch_bounds__(64) k_tsi_rows(const uvic_ctx c, double *acc) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double t3[TSI_ROWS][65], t1[TSI_ROWS][65], t2[TSI_ROWS][65];
+  __shared__ double f_w[TSI_ROWS], f_x[TSI_ROWS];        // per row: dzt(k) and cst(j)*dyt(j); r2dt/dtxcel(k)
+  __shared__ long long base_t[TSI_ROWS], base_m[TSI_ROWS];   // per row: offset of the row in t (tracer n) and in tmask; -1: no row
+  const int lane = threadIdx.x;
   const int nrows = c.je - c.js + 1;
-  if (gid >= (long long)c.km * nrows * c.nt_local) return;
-  const int k = (int)(gid % c.km) + 1;
-  const int j = c.js + (int)((gid / c.km) % nrows);
-  const int n = c.n0 + (int)(gid / ((long long)c.km * nrows)) + 1;
+  const int total = c.km * nrows * c.nt_local, g0 = blockIdx.x * TSI_ROWS;
   const size_t N3 = (size_t)c.imt * c.km * c.jmt;
-  const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
-  const double *tt = c.t_tau + (size_t)(n - 1) * N3 + row, *tm = c.t_taum1 + (size_t)(n - 1) * N3 + row;
-  const double *tp = c.t_taup1 + (size_t)(n - 1) * N3 + row, *msk = c.tmask + row;
-  const double r2dt = 1.0 / c.c2dtts, cosdyt = c.cst[j - 1] * c.dyt[j - 1];
-  const double fx = r2dt / c.dtxcel[k - 1], dztk = c.dzt[k - 1];
+  int k = 0, j = 0, n = 0;
+  if (lane < TSI_ROWS) {
+    const int gid = g0 + lane;
+    long long bt = -1, bm = -1;
+    double fw = 0.0, fx = 0.0;
+    if (gid < total) {
+      k = gid % c.km + 1; j = c.js + (gid / c.km) % nrows; n = c.n0 + gid / (c.km * nrows) + 1;
+      bm = (long long)c.imt * ((long long)(k - 1) + (long long)c.km * (j - 1));
+      bt = (long long)(n - 1) * (long long)N3 + bm;
+      fw = c.dzt[k - 1]; fx = (1.0 / c.c2dtts) / c.dtxcel[k - 1];
+      f_x[lane] = fx;
+    }
+    base_t[lane] = bt; base_m[lane] = bm; f_w[lane] = fw;
+    t3[lane][64] = (gid < total) ? c.cst[j - 1] * c.dyt[j - 1] : 0.0;   // (the spare column of the tile: cosdyt of the row)
+  }
+  __syncthreads();
   double s_bar = 0.0, s_var = 0.0, s_abs = 0.0;
-  for (int i0 = 1; i0 < c.imt - 1; i0 += 8) {   // (i = 2..imt-1; eight columns per memory round trip)
-    double a[8], p[8], m[8], w[8];
-    _Pragma("unroll") for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u < c.imt - 1 ? i0 + u : c.imt - 2;
-      a[u] = tt[i]; p[u] = tp[i]; m[u] = tm[i];
-      w[u] = dztk * c.dxt[i] * cosdyt * msk[i];
-    }
-    _Pragma("unroll") for (int u = 0; u < 8; ++u)
-      if (i0 + u < c.imt - 1) {
-        const double temp3 = a[u] * w[u], temp1 = a[u] * a[u] * w[u], temp2 = dabs(p[u] - m[u]) * w[u] * fx;
-        s_bar = s_bar + temp3; s_var = s_var + temp1; s_abs = s_abs + temp2;
+  for (int i0 = 1; i0 < c.imt - 1; i0 += 64) {   // i = 2..imt-1
+    const int i = i0 + lane;
+    const bool in = i < c.imt - 1;
+    const double dx = in ? c.dxt[i] : 0.0;
+    for (int r = 0; r < TSI_ROWS; ++r) {
+      const long long bt = base_t[r];
+      double a3 = 0.0, a1 = 0.0, a2 = 0.0;
+      if (bt >= 0 && in) {
+        const double a = c.t_tau[bt + i], w = f_w[r] * dx * t3[r][64] * c.tmask[base_m[r] + i];
+        a3 = a * w; a1 = a * a * w; a2 = dabs(c.t_taup1[bt + i] - c.t_taum1[bt + i]) * w * f_x[r];
       }
-  }
-  const size_t q = (size_t)k + (size_t)(c.km + 1) * ((size_t)(n - 1) + (size_t)c.nt * (j - 1)), NA = (size_t)(c.km + 1) * c.nt * c.jmt;
-  acc[q] = s_bar; acc[NA + q] = s_var; acc[2 * NA + q] = s_abs;
-}
-// delta 14C of the final t(tau+1) weighted by the cell volume, one partial sum per row (k outer, i inner as tracer.F:1342-1353);
-// the caller adds the rows in order
-__global__ void __launch_bounds__(64) k_tsi_dc14(const uvic_ctx c, int ic14, int idic, double rc14std, double *rows) {
-  const int j = c.js + blockIdx.x * blockDim.x + threadIdx.x;
-  if (j > c.je) return;
-  const size_t N3 = (size_t)c.imt * c.km * c.jmt;
-  const double rrc14std = 1000. / rc14std, fy = c.cst[j - 1] * c.dyt[j - 1];
-  double sum = 0.0;
-  for (int k = 1; k <= c.km; ++k) {
-    const double fyz = fy * c.dzt[k - 1];
-    const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
-    const double *t14 = c.t_taup1 + (size_t)(ic14 - 1) * N3 + row, *tdic = c.t_taup1 + (size_t)(idic - 1) * N3 + row, *msk = c.tmask + row;
-    for (int i = 1; i < c.imt - 1; ++i) {
-      const double dc14 = (rrc14std * t14[i] / (tdic[i] + UV_EPSLN) - 1000.) * msk[i];
-      sum = sum + dc14 * c.dxt[i] * fyz * msk[i];
+      t3[r][lane] = a3; t1[r][lane] = a1; t2[r][lane] = a2;
     }
+    __syncthreads();
+    if (lane < TSI_ROWS) {
+      const int cnt = c.imt - 1 - i0 < 64 ? c.imt - 1 - i0 : 64;
+      for (int q = 0; q < cnt; ++q) { s_bar = s_bar + t3[lane][q]; s_var = s_var + t1[lane][q]; s_abs = s_abs + t2[lane][q]; }
+    }
+    __syncthreads();
   }
-  rows[j - 1] = sum;
+  if (lane < TSI_ROWS && g0 + lane < total) {
+    const size_t q = (size_t)k + (size_t)(c.km + 1) * ((size_t)(n - 1) + (size_t)c.nt * (j - 1)), NA = (size_t)(c.km + 1) * c.nt * c.jmt;
+    acc[q] = s_bar; acc[NA + q] = s_var; acc[2 * NA + q] = s_abs;
+  }
 }
-// global kinetic energy on the tau velocity, clinic.F:616-630: ektot(k, jrow) = sum over n = 1, 2 and i = 2..imt-1 of
-// u(i,k,j,n,tau)**2 * (rho0/2 csu dyu) dzt dxu, added in that order; one thread per (row, level); out (0:km, jmt)
+// delta 14C of t(tau+1) (tracer.F:1329-1353): the reference keeps one running sum over the whole grid; here one partial sum
+// per row (k, j) -- a wave per row, lanes over the columns, a fixed tree over the lanes -- which uvic_gpu_tsi_read adds up
+// in the order of the rows (agreement with the reference to rounding, run to run to the bit).
+__global__ void __launch_bounds__(256) k_tsi_dc14(const uvic_ctx c, int ic14, int idic, double rc14std, double *rows) {
+  const int gid = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x & 63;
+  const int nrows = c.je - c.js + 1;
+  if (gid >= c.km * nrows) return;
+  const int k = gid % c.km + 1, j = c.js + gid / c.km;
+  const size_t N3 = (size_t)c.imt * c.km * c.jmt;
+  const double rrc14std = 1000. / rc14std, fyz = c.cst[j - 1] * c.dyt[j - 1] * c.dzt[k - 1];
+  const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
+  const double *t14 = c.t_taup1 + (size_t)(ic14 - 1) * N3 + row, *tdic = c.t_taup1 + (size_t)(idic - 1) * N3 + row, *msk = c.tmask + row;
+  double sum = 0.0;
+  for (int i = 1 + lane; i < c.imt - 1; i += 64) {
+    const double dc14 = (rrc14std * t14[i] / (tdic[i] + UV_EPSLN) - 1000.) * msk[i];
+    sum = sum + dc14 * c.dxt[i] * fyz * msk[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_down(sum, off, 64);
+  if (lane == 0) rows[(size_t)(k - 1) + (size_t)c.km * (j - 1)] = sum;
+}
 __global__ void __launch_bounds__(64) k_tsi_ektot(const uvic_ctx c, const double *u1, const double *u2, double rho0, double *out) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int nrows = c.je - c.js + 1;
@@ -1039,7 +1063,10 @@ struct uvic_gpu {
   // time-step integrals (O_time_step_monitor) formed on the device on the steps the caller names (uvic_gpu_set_tsi)
   bool tsi_step;                // this step
   int tsi_ic14, tsi_idic;       // tracer numbers of 14C and DIC (0: no delta-14C sum)
-  double *tsi_acc;              // tbar, travar, dtabs, each (0:km, nt, jmt); then jmt row sums of delta 14C
+  double *tsi_acc;              // tbar, travar, dtabs, each (0:km, nt, jmt); then (km, jmt) row sums of delta 14C
+  double *tsi_host = nullptr;   // the same, page-locked: filled behind every time-step-monitor step
+  hipEvent_t ev_tsi = nullptr;
+  bool tsi_inflight = false;
   // what the look-ahead MOBI chain assumed about the step it computed for (checked when that step starts)
   double src_relyr, src_co2ccn, src_c2dtts;
   bool serial;        // uvic_gpu_profile: everything on the main stream, one kernel after the other
@@ -1389,6 +1416,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->sbc_tracer);
   (void)hipFree(h->sbc_acc);
   (void)hipFree(h->tsi_acc);
+  if (h->tsi_host) { (void)hipHostFree(h->tsi_host); (void)hipEventDestroy(h->ev_tsi); }
   (void)hipEventDestroy(h->ev_ts_host);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
@@ -1910,8 +1938,8 @@ static int launch_isopyc(uvic_gpu *h, bool may_defer = false) {
 // the time-step integrals of the tracers of `c` on stream `st`: after their pass B, before convection (diagt1, tracer.F:1161)
 static int launch_tsi_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid) {
   if (!h->tsi_step || c.nt_local <= 0) return 0;
-  const long long n = (long long)c.km * (c.je - c.js + 1) * c.nt_local;
-  hipLaunchKernelGGL(k_tsi_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c, h->tsi_acc);
+  const long long n = (long long)c.km * (c.je - c.js + 1) * c.nt_local;   // rows: sixteen to a wave
+  hipLaunchKernelGGL(k_tsi_rows, dim3((unsigned)((n + TSI_ROWS - 1) / TSI_ROWS)), dim3(64), 0, st, c, h->tsi_acc);
   mark_on(h, "tsi_rows", sid);
   HIPCHK(hipGetLastError());
   return 0;
@@ -2206,10 +2234,20 @@ static int launch_convect(uvic_gpu *h) {
   }
   if (h->tsi_step && h->tsi_ic14 > 0 && h->tsi_idic > 0) {   // delta 14C of the final t(tau+1), tracer.F:1329-1353
     const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt;
-    const int nrows = h->ctx.je - h->ctx.js + 1;
-    hipLaunchKernelGGL(k_tsi_dc14, dim3((unsigned)((nrows + 63) / 64)), dim3(64), 0, h->stream, h->ctx, h->tsi_ic14, h->tsi_idic, UV_RC14STD,
+    const int nrows = h->d.km * (h->ctx.je - h->ctx.js + 1);
+    hipLaunchKernelGGL(k_tsi_dc14, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, h->stream, h->ctx, h->tsi_ic14, h->tsi_idic, UV_RC14STD,
                        h->tsi_acc + 3 * NA);
     mark(h, "tsi_dc14");
+  }
+  if (h->tsi_step && h->tsi_host) {
+    // the integrals go to page-locked memory behind the step's last kernel (the T,S rows were summed on the T,S stream,
+    // which the main stream has waited for before it replayed the convective ranges): uvic_gpu_tsi_read waits for this copy
+    // alone, not for the look-ahead chains
+    const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt;
+    if (!h->ts_ahead) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_done, 0));
+    HIPCHK(hipMemcpyAsync(h->tsi_host, h->tsi_acc, (3 * NA + (size_t)h->d.km * h->d.jmt) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipEventRecord(h->ev_tsi, h->stream));
+    h->tsi_inflight = true;
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -3476,9 +3514,11 @@ extern "C" int uvic_gpu_set_tsi(uvic_gpu *h, int on, int ic14, int idic) {
   if (ic14 < 0 || ic14 > h->d.nt || idic < 0 || idic > h->d.nt) return fail_msg("uvic_gpu_set_tsi: tracer number outside 1..nt");
   HIPCHK(hipSetDevice(h->device));
   if (on && !h->tsi_acc) {
-    const size_t bytes = ((size_t)3 * (h->d.km + 1) * h->d.nt * h->d.jmt + h->d.jmt) * 8;
+    const size_t bytes = ((size_t)3 * (h->d.km + 1) * h->d.nt * h->d.jmt + (size_t)h->d.km * h->d.jmt) * 8;
     HIPCHK(hipMalloc((void **)&h->tsi_acc, bytes));
     HIPCHK(hipMemset(h->tsi_acc, 0, bytes));
+    HIPCHK(hipHostMalloc((void **)&h->tsi_host, bytes, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_tsi, hipEventDisableTiming));
   }
   h->tsi_step = on != 0;
   h->tsi_ic14 = ic14; h->tsi_idic = idic;
@@ -3491,16 +3531,22 @@ extern "C" int uvic_gpu_tsi_read(uvic_gpu *h, double *tbar, double *travar, doub
   if (!h || !tbar || !travar || !dtabs) return fail_msg("uvic_gpu_tsi_read: null argument");
   if (!h->tsi_acc) return fail_msg("uvic_gpu_tsi_read: no time-step-monitor step has run (uvic_gpu_set_tsi)");
   HIPCHK(hipSetDevice(h->device));
-  if (int rc = uvic_gpu_sync(h)) return rc;
-  const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt;
-  HIPCHK(hipMemcpy(tbar, h->tsi_acc, NA * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(travar, h->tsi_acc + NA, NA * 8, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(dtabs, h->tsi_acc + 2 * NA, NA * 8, hipMemcpyDeviceToHost));
+  const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt, NR = (size_t)h->d.km * h->d.jmt;
+  if (h->tsi_inflight) {   // the step's own copy (launch_convect)
+    HIPCHK(hipEventSynchronize(h->ev_tsi));
+    h->tsi_inflight = false;
+  } else {
+    if (int rc = uvic_gpu_sync(h)) return rc;
+    HIPCHK(hipMemcpy(h->tsi_host, h->tsi_acc, (3 * NA + NR) * 8, hipMemcpyDeviceToHost));
+  }
+  memcpy(tbar, h->tsi_host, NA * 8);
+  memcpy(travar, h->tsi_host + NA, NA * 8);
+  memcpy(dtabs, h->tsi_host + 2 * NA, NA * 8);
   if (dc14bar) {
-    std::vector<double> rows((size_t)h->d.jmt);
-    HIPCHK(hipMemcpy(rows.data(), h->tsi_acc + 3 * NA, rows.size() * 8, hipMemcpyDeviceToHost));
+    const double *rows = h->tsi_host + 3 * NA;
     double sum = 0.0;
-    for (int j = h->ctx.js; j <= h->ctx.je; ++j) sum = sum + rows[(size_t)j - 1];
+    for (int j = h->ctx.js; j <= h->ctx.je; ++j)
+      for (int k = 1; k <= h->d.km; ++k) sum = sum + rows[(size_t)(k - 1) + (size_t)h->d.km * (j - 1)];
     *dc14bar = sum;
   }
   return 0;
