@@ -9,12 +9,12 @@
 R=$PWD; O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
 BENCH="python3 $R/bench.py --steps 64 --warmup 4"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH --no-cpu-baseline --no-overlay > $O/stats.log 2>&1 || exit 1
 cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 # the momentum row (state + clinic, polar filter and sbc accumulation on): its own loop, same counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_clinic -- python3 $R/tools/clinic_loop.py 200 > $O/stats_clinic.log 2>&1 || exit 1
 cp $(ls $O/stats_clinic/*/*kernel_stats.csv | head -1) $O/clinic_kernel_stats.csv
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_$name.log 2>&1 || exit 1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlay > $O/pmc_$name.log 2>&1 || exit 1; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
 run fetch FETCH_SIZE
