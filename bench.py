@@ -322,14 +322,16 @@ def main():
         m.set_mobi(ocean)
     shard.apply(m)
     for kv in a.option:
-        m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        if not kv.startswith("iso2="):      # (iso2: a switch of the Python time loop, below)
+            m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if a.one_slab_of > 1 and world == 1:
         from uvic29_amd.parallel import slab_rows
         js, je = slab_rows(jmt, a.one_slab_of, a.one_slab_of // 2)
         m.set_shard(js=js, je=je)
 
     from uvic29_amd.tracer import TimeLoop
-    loop = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, shard=shard if world > 1 else None, segment=a.segment)
+    loop = TimeLoop(m, ocean.params.dtts, ocean.params.nmix, shard=shard if world > 1 else None, segment=a.segment,
+                    iso2=any(kv == "iso2=1" for kv in a.option))
 
     def one_step():
         loop.step()

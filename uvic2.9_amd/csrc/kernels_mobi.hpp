@@ -847,10 +847,21 @@ UVIC_DEV void mobi_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k, 
   double swr = P->tap * M.dnswr[ij] * 1e-3 * (1. + ai * (exp(-P->ki * (hi + hs)) - 1.));
   // attenuation by the phytoplankton above, the same running product as mobi.F:735-740
   double phin = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (device: the product of the exponentials as the exponential of the sum -- one exp instead of k per cell, within
+  // the rounding of the MOBI source tolerance; the host build keeps the running product and stays bit-identical)
+  double att = 0.0;
+  for (int m = 1; m <= k; ++m) {
+    att = att + P->kc * phin;
+    phin = TNC(m, MI::phyt) * P->dzt[m - 1] + TNC(m, MI::diaz) * P->dzt[m - 1];
+  }
+  swr = swr * exp(-att);
+#else
   for (int m = 1; m <= k; ++m) {
     swr = swr * exp(-P->kc * phin);
     phin = TNC(m, MI::phyt) * P->dzt[m - 1] + TNC(m, MI::diaz) * P->dzt[m - 1];
   }
+#endif
   const double gl = swr * exp(P->ztt[k - 1] * rctheta);
   // oxygen saturation -> apparent oxygen utilisation, tracer.F:456-476
   double aou_in;

@@ -613,13 +613,24 @@ UVIC_DEV void mobig_pre_cell(const uvic_ctx &c, const mobi_dev &M, int i, int k,
   double swr = P->tap * M.dnswr[ij] * 1e-3 * (1. + ai * (exp(-P->ki * (hi + hs)) - 1.));
   /* attenuation by what lies above: the running product of mobi_driver's level loop, mobi.F:799-816 */
   double phin = 0.0, caco3in = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double att = 0.0;   // (device: one exp of the summed exponents instead of k, as in mobi_pre_cell)
+#endif
   for (int m = 1; m <= k; ++m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (CACO3) att = att + (P->kc * phin + O->kc_c * caco3in);
+    else att = att + P->kc * phin;
+#else
     if (CACO3) swr = swr * exp(-P->kc * phin - O->kc_c * caco3in);
     else swr = swr * exp(-P->kc * phin);
+#endif
     phin = g_max(TN(m, X_phyt), UV_TRCMIN) * P->dzt[m - 1] + g_max(TN(m, X_diaz), UV_TRCMIN) * P->dzt[m - 1];
     if (SIL) phin = phin + g_max(TN(m, X_diat), UV_TRCMIN) * P->dzt[m - 1];
     if (CACO3) caco3in = caco3in + TNR(m, X_caco3) * P->dzt[m - 1];
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  swr = swr * exp(-att);
+#endif
   const double gl = swr * exp(P->ztt[k - 1] * rctheta);
   const double bct = UV_POWP(P->bbio, P->cbio * t_in);
   const double bctz = (0.5 * (tanh(o2_in - 8.) + 1)) * UV_POWP(P->bbio, P->cbio * t_in);
