@@ -142,6 +142,48 @@ def test_resident_overlay_over_several_steps(cfg, dims, exact, monkeypatch):
             assert np.abs(x - y).max() <= PROD_TOL * np.abs(y).max(), (slot, name, np.abs(x - y).max())
 
 
+def test_resident_overlay_back_to_back_on_the_full_grid(monkeypatch):
+    """The resident overlay on 102x102x19 with option set C, sixteen steps in segments of four with NOTHING between the calls
+    but the reference's own step -- long enough kernels and a busy enough device for the overlay's asynchronous schedule to
+    show if it were wrong: the step's inputs arrive by copies beside the main stream into device copies taken in turn, the
+    T,S chain of a step starts while the other tracers of the step before are still in their pass B, MOBI sources of a
+    segment's first step run beside pass A.  Production arithmetic: T and S of EVERY step bit-identical to the unmodified
+    reference, every tracer after the flush to the production tolerance."""
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    monkeypatch.setenv("UVIC_RESIDENT", "1")
+    cfg, dims = "c30", (102, 102, 19)
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    ref = refdriver.RefOcean(oc)
+    shim = refdriver.RefOcean(oc, shim=True)
+    jmt = dims[1]
+    rng = np.random.default_rng(11)
+    for r in (ref, shim):
+        r.set_step_kind(False)
+        r.ref.set("nmix", 0)
+    for it in range(1, 17):
+        stf = oc.stf * (1.0 + 0.02 * it) + 1e-9 * rng.standard_normal(oc.stf.shape) * (oc.topo.kmt > 0)[..., None]
+        # the inputs change from step to step; adv_vbt by continuity from adv_vet, adv_vnt, as adv_vel.F makes it
+        vet, vnt, vbt = synthetic.advective_velocities(oc.grid, oc.u * (1.0 + 0.03 * np.sin(0.9 * it)))
+        for r in (ref, shim):
+            _segment_switches(r, it, 4)
+            r.v["stf"][...] = stf
+            r.v["adv_vet"][...] = vet[:, :, 1:]
+            r.v["adv_vnt"][...] = vnt
+            r.v["adv_vbt"][...] = vbt[:, :, 1:]
+        want = ref.step().copy()
+        got = shim.step().copy()
+        assert np.array_equal(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2]), it
+        ref.rotate(); shim.rotate()
+    shim.flush()
+    a, b = shim.v["t"][..., 1], ref.v["t"][..., 1]
+    for n, name in enumerate(oc.cfg.tracers):
+        x, y = a[:, :, 1:jmt - 1, n], b[:, :, 1:jmt - 1, n]
+        assert np.abs(x - y).max() <= PROD_TOL * np.abs(y).max(), (name, np.abs(x - y).max())
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_resident_overlay_through_an_euler_backward_step(exact, monkeypatch):
     """An Euler backward mixing step (eb): both passes run on the host (euler1 with eots false, then euler2), after which

@@ -65,3 +65,22 @@ def test_inputs_in_one_call_equal_plain_uploads(cfg, grid, streams):
     got = _run(cfg, grid, True, streams)
     assert np.isfinite(ref).all()
     assert np.array_equal(got, ref)
+
+
+def test_inputs_without_velocities_need_velocities_formed_on_the_device():
+    """adv_vet/adv_vnt may be left out only after uvic_gpu_overlay_velocities has formed them on the device for the coming
+    step: otherwise the call is refused with a message, not computed through with whatever the buffers hold."""
+    from uvic29_amd import OPTION_SETS, synthetic
+    from uvic29_amd.tracer import TracerModel
+    cfg = OPTION_SETS["p2"]
+    ocean = synthetic.make_ocean(cfg, 14, 14, 6)
+    to, so, c = synthetic.load_eos(6)
+    m = TracerModel(14, 14, 6, cfg.nt, cfg.nsrc, cfg.ntnpzd, device=0)
+    m.load_ocean(ocean, to, so, c)
+    cbt = np.asfortranarray(ocean.diff_cbt_bg[:, :, 1:13])
+    p = [a.ctypes.data_as(ctypes.c_void_p) for a in (cbt, ocean.stf, ocean.btf)]
+    assert m.lib.uvic_gpu_overlay_inputs(m.h, 2, 13, None, None, None, p[0], p[1], p[2]) != 0
+    assert "uvic_gpu_overlay_velocities" in m.last_error()
+    vet = np.asfortranarray(ocean.adv_vet[:, :, 1:])
+    assert m.lib.uvic_gpu_overlay_inputs(m.h, 2, 13, vet.ctypes.data_as(ctypes.c_void_p), None, None, p[0], p[1], p[2]) != 0   # one of the pair
+    m.close()

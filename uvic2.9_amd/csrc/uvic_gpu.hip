@@ -3642,7 +3642,7 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
                                        const double *diff_cbt, const double *stf, const double *btf) {
   if (!h || !diff_cbt || !stf || !btf || (!adv_vet) != (!adv_vnt)) return fail_msg("uvic_gpu_overlay_inputs: null argument");
   if (!adv_vet && !(h->in.vel_pending && !h->in.used))
-    return fail_msg("uvic_gpu_overlay_inputs: no velocities given and none formed on the device for this step (uvic_gpu_overlay_momentum)");
+    return fail_msg("uvic_gpu_overlay_inputs: no velocities given and none formed on the device for this step (uvic_gpu_overlay_velocities)");
   const uvic_dims &d = h->d;
   if (jsmw < 1 || jsmw > 2 || jemw < jsmw || jemw > d.jmt) return fail_msg("uvic_gpu_overlay_inputs: window rows outside 1..jmt");
   h->idle_until_next = false;
