@@ -78,6 +78,28 @@ enum {
 // zero-filled when they are allocated and again when kmt changes (uvic_gpu.hip: iso_set_alloc, make_tmask), and nothing
 // reads the one unmasked slot (the vertical-diffusion coefficient) of a land cell: t(tau-1) is zero on both sides of
 // the face it belongs to.  The nineteen coefficients leave in ten 16-byte stores.
+// x / y with the reciprocal of y formed once for several quotients: the compiler's own fp64 division sequence
+// (v_rcp_f64, two Newton steps; quotient, residual, one correction) split in two -- the same bits as x / y for operands
+// away from the ends of the exponent range, which slopes and density differences are (kernels_colx.hpp uses the same
+// split).  The host build divides.
+UVIC_DEV double uv_rcp2(double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(y);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+#else
+  return 1.0 / y;
+#endif
+}
+UVIC_DEV double uv_div2(double x, double y, double r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q = x * r;
+  return __builtin_fma(__builtin_fma(-y, q, x), r, q);
+#else
+  (void)r;
+  return x / y;
+#endif
+}
 UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, int store_ai = 0) {
   UV_DIMS(c);
   const size_t q = X3(i, k, j);
@@ -138,10 +160,13 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, i
   }
   if (j >= 2 && k <= km - 1) {  // bottom face
     const double Ai0 = 0.5 * (c.fisop[XFIS(i, j, k + 1)] + c.fisop[XFIS(i, j, k)]) * c.ahisop;
+    // the eight slopes of the bottom face have two denominators between them: one reciprocal each
+    const double zb[2] = {drodzb(i, k, j, 0) + UV_EPSLN, drodzb(i, k, j, 1) + UV_EPSLN};
+    const double rzb[2] = {uv_rcp2(zb[0]), uv_rcp2(zb[1])};
     double sumx = 0.0;
     for (int ip = 0; ip <= 1; ++ip)
       for (int kr = 0; kr <= 1; ++kr) {
-        const double sl = drodxb(i, k, j, ip, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
+        const double sl = uv_div2(drodxb(i, k, j, ip, kr), zb[kr], rzb[kr]);
         const double sxb = dabs(sl);
         double a;
         if (sxb > sc) {
@@ -158,7 +183,7 @@ UVIC_DEV void ai_coef_cell(const uvic_ctx &c, double *cf, int i, int k, int j, i
     for (int jq = 0; jq <= 1; ++jq) {
       const double facty = c.csu[j - 1 + jq - 1] * c.dyu[j - 1 + jq - 1];
       for (int kr = 0; kr <= 1; ++kr) {
-        const double sl = drodyb(i, k, j, jq, kr) / (drodzb(i, k, j, kr) + UV_EPSLN);
+        const double sl = uv_div2(drodyb(i, k, j, jq, kr), zb[kr], rzb[kr]);
         const double syb = dabs(sl);
         double a;
         if (syb > sc) {
