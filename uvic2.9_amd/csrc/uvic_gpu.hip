@@ -686,11 +686,12 @@ __global__ void __launch_bounds__(64) k_mobi(const uvic_ctx c, const mobi_dev m,
 // step stays on the device.  One thread per (row, level, tracer) adds along i in the reference's order (a running sum is
 // not associative: the same order gives the same bits).  tp = t(tau+1) BEFORE convection (diagt1 is called at tracer.F:1161).
 // acc: tbar, travar, dtabs, each (0:km, nt, jmt) as source/common/diag.h declares them.
-// Sixteen rows (k, j, n) per wave.  Row by row the 64 lanes fetch 64 consecutive columns at once (coalesced) and form the
+// Eight rows (k, j, n) per wave.  Row by row the 64 lanes fetch 64 consecutive columns at once (coalesced) and form the
 // three terms of each column in parallel, into an LDS tile; then lane r adds up row r of the tile column by column -- the
 // sequential sum of diagt1 (tracer.F:1516-1537), to the bit -- so a row costs one load instruction per 64 columns instead
-// of 64 scattered ones and the serial part runs sixteen rows abreast.
-#define TSI_ROWS 16
+// of 64 scattered ones and the serial part runs eight rows abreast (eight, not sixteen or four: 12 KB of LDS per wave
+// leave enough waves per CU to cover the load latency; 120 / 85 / 68 us for 16 / 8 / 4 rows, but the T,S launch likes 8).
+#define TSI_ROWS 8
 __global__ void __launch_bounds__(64) k_tsi_rows(const uvic_ctx c, double *acc) {
   __shared__ double t3[TSI_ROWS][65], t1[TSI_ROWS][65], t2[TSI_ROWS][65];
   __shared__ double f_w[TSI_ROWS], f_x[TSI_ROWS];        // per row: dzt(k) and cst(j)*dyt(j); r2dt/dtxcel(k)
@@ -1938,7 +1939,7 @@ static int launch_isopyc(uvic_gpu *h, bool may_defer = false) {
 // the time-step integrals of the tracers of `c` on stream `st`: after their pass B, before convection (diagt1, tracer.F:1161)
 static int launch_tsi_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid) {
   if (!h->tsi_step || c.nt_local <= 0) return 0;
-  const long long n = (long long)c.km * (c.je - c.js + 1) * c.nt_local;   // rows: sixteen to a wave
+  const long long n = (long long)c.km * (c.je - c.js + 1) * c.nt_local;   // rows: TSI_ROWS to a wave
   hipLaunchKernelGGL(k_tsi_rows, dim3((unsigned)((n + TSI_ROWS - 1) / TSI_ROWS)), dim3(64), 0, st, c, h->tsi_acc);
   mark_on(h, "tsi_rows", sid);
   HIPCHK(hipGetLastError());
