@@ -762,22 +762,39 @@ __global__ void __launch_bounds__(256) k_tsi_dc14(const uvic_ctx c, int ic14, in
   for (int off = 32; off > 0; off >>= 1) sum = sum + __shfl_down(sum, off, 64);
   if (lane == 0) rows[(size_t)(k - 1) + (size_t)c.km * (j - 1)] = sum;
 }
+// Kinetic energy of the time-step monitor (clinic.F:616-630), one sum per row (k, j) over both components and the columns in
+// the reference's order; eight rows per wave through an LDS tile, as k_tsi_rows.
 __global__ void __launch_bounds__(64) k_tsi_ektot(const uvic_ctx c, const double *u1, const double *u2, double rho0, double *out) {
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nrows = c.je - c.js + 1;
-  if (gid >= c.km * nrows) return;
-  const int k = gid % c.km + 1, j = c.js + gid / c.km;
-  const size_t row = (size_t)c.imt * ((size_t)(k - 1) + (size_t)c.km * (j - 1));
-  const double fx = rho0 * 0.5 * c.csu[j - 1] * c.dyu[j - 1], fxz = fx * c.dzt[k - 1];
+  __shared__ double tile[TSI_ROWS][65];
+  const int lane = threadIdx.x;
+  const int nrows = c.je - c.js + 1, total = c.km * nrows, g0 = blockIdx.x * TSI_ROWS;
+  const int gid = g0 + (lane < TSI_ROWS ? lane : 0);
+  const int k = gid % c.km + 1, j = c.js + gid / c.km;    // (the row lane `lane` sums, if it is one)
   double sum = 0.0;
   for (int n = 0; n < 2; ++n) {
-    const double *u = (n ? u2 : u1) + row;
-    for (int i = 1; i < c.imt - 1; ++i) {
-      const double weight = fxz * c.dxu[i];
-      sum = sum + u[i] * u[i] * weight;
+    const double *u = n ? u2 : u1;
+    for (int i0 = 1; i0 < c.imt - 1; i0 += 64) {   // i = 2..imt-1
+      const int i = i0 + lane;
+      for (int r = 0; r < TSI_ROWS; ++r) {
+        const int g = g0 + r;
+        double v = 0.0;
+        if (g < total && i < c.imt - 1) {
+          const int kr = g % c.km + 1, jr = c.js + g / c.km;
+          const double fx = rho0 * 0.5 * c.csu[jr - 1] * c.dyu[jr - 1], fxz = fx * c.dzt[kr - 1];
+          const double x = u[(size_t)c.imt * ((size_t)(kr - 1) + (size_t)c.km * (jr - 1)) + i];
+          v = x * x * (fxz * c.dxu[i]);
+        }
+        tile[r][lane] = v;
+      }
+      __syncthreads();
+      if (lane < TSI_ROWS) {
+        const int cnt = c.imt - 1 - i0 < 64 ? c.imt - 1 - i0 : 64;
+        for (int q = 0; q < cnt; ++q) sum = sum + tile[lane][q];
+      }
+      __syncthreads();
     }
   }
-  out[(size_t)k + (size_t)(c.km + 1) * (j - 1)] = sum;
+  if (lane < TSI_ROWS && g0 + lane < total) out[(size_t)k + (size_t)(c.km + 1) * (j - 1)] = sum;
 }
 // Pass B runs over the ocean columns only; t(tau+1) is zero on land (the update is masked, tracer.F:1109-1130).  This
 // kernel clears the land columns of rows js..je of every local tracer (and the cyclic images of land columns 2 and
@@ -2747,7 +2764,7 @@ extern "C" int uvic_gpu_overlay_momentum(uvic_gpu *h, int fresh, int t_level, in
     if (!h->in.ektot_dev) HIPCHK(hipMalloc((void **)&h->in.ektot_dev, n * 8));
     HIPCHK(hipMemsetAsync(h->in.ektot_dev, 0, n * 8, st));
     const int work = d.km * (h->ctx.je - h->ctx.js + 1);
-    hipLaunchKernelGGL(k_tsi_ektot, dim3((unsigned)((work + 63) / 64)), dim3(64), 0, st, h->ctx, (const double *)h->buf[UVIC_F_U1],
+    hipLaunchKernelGGL(k_tsi_ektot, dim3((unsigned)((work + TSI_ROWS - 1) / TSI_ROWS)), dim3(64), 0, st, h->ctx, (const double *)h->buf[UVIC_F_U1],
                        (const double *)h->buf[UVIC_F_U2], rho0, h->in.ektot_dev);
     HIPCHK(hipMemcpyAsync(ektot_host, h->in.ektot_dev, n * 8, hipMemcpyDeviceToHost, st));
   }
@@ -3563,7 +3580,7 @@ extern "C" int uvic_gpu_tsi_ektot(uvic_gpu *h, double rho0, double *ektot) {
   HIPCHK(hipMalloc((void **)&dev, n * 8));
   HIPCHK(hipMemsetAsync(dev, 0, n * 8, h->stream));
   const int work = h->d.km * (h->ctx.je - h->ctx.js + 1);
-  hipLaunchKernelGGL(k_tsi_ektot, dim3((unsigned)((work + 63) / 64)), dim3(64), 0, h->stream, h->ctx, (const double *)h->buf[UVIC_F_U1],
+  hipLaunchKernelGGL(k_tsi_ektot, dim3((unsigned)((work + TSI_ROWS - 1) / TSI_ROWS)), dim3(64), 0, h->stream, h->ctx, (const double *)h->buf[UVIC_F_U1],
                      (const double *)h->buf[UVIC_F_U2], rho0, dev);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(ektot, dev, n * 8, hipMemcpyDeviceToHost, h->stream));
