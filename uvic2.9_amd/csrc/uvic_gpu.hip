@@ -243,6 +243,13 @@ __global__ void __launch_bounds__(256) k_pull4(const Pull4 p, int n) {
   const int q = blockIdx.y;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) p.dst[q][e] = p.src[q][e];
 }
+#if defined(UVIC_EXPERIMENTS)
+// stress test of the schedule (not in the shipped library): holds the stream it is launched on for `us` microseconds
+__global__ void k_stall(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+#endif
 // ---- baroclinic momentum step (kernels_clinic.hpp) -----------------------------------
 #define COL_DECODE(m)                                                 \
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;              \
@@ -1070,11 +1077,10 @@ struct uvic_gpu {
   // parity: the T,S passes of the NEXT step write that buffer (launch_transport)
   hipEvent_t ev_mobi_of[2];
   long long mobi_ev_step[2];
-  hipEvent_t ev_src_inline2[2];
+  hipEvent_t ev_src_inline2[2];   // sources of the current step computed on a MOBI side stream (launch_mobi), by step parity
   long long end_step_of[2];       // the step that recorded ev_step_end[q]
   bool close_step = false;        // uvic_gpu_set_option "close_step"
   bool prep_deferred;             // launch_isopyc left k_inputs_cell (and the wait for the inputs) to launch_transport
-  hipEvent_t ev_src_inline;       // sources of the current step computed on a MOBI side stream (launch_mobi)
   int sbc_count;                // tracers whose surface level is accumulated
   int *sbc_tracer;              // device: their 1-based tracer numbers
   double *sbc_acc;              // device (imt, jmt, sbc_count)
@@ -1314,7 +1320,6 @@ extern "C" int uvic_gpu_create(uvic_gpu **out, const uvic_dims *dims, int device
   h->idle_until_next = false;
   h->ts_waited_begin = -1;
   for (int q = 0; q < 2; ++q) HIPCHK(hipEventCreateWithFlags(&h->ev_src_next[q], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&h->ev_src_inline, hipEventDisableTiming));
   for (int q = 0; q < 2; ++q) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_src_inline2[q], hipEventDisableTiming));
     h->mobi_ev_step[q] = h->end_step_of[q] = -1; h->ev_mobi_of[q] = nullptr;
@@ -1447,7 +1452,6 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   if (h->src_alt) (void)hipFree(h->src_alt);
   (void)hipEventDestroy(h->ev_step_begin);
   for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(h->ev_src_next[q]); (void)hipEventDestroy(h->ev_step_end[q]); }
-  (void)hipEventDestroy(h->ev_src_inline);
   for (int q = 0; q < 2; ++q) (void)hipEventDestroy(h->ev_src_inline2[q]);
   for (void *q : h->pinned) (void)hipHostUnregister(q);
   h->pinned.clear();
@@ -2177,6 +2181,10 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_src_ready, 0));
       h->src_from_prefetch = false;
     }
+#if defined(UVIC_EXPERIMENTS)
+    if (const char *e = uv_env("UVIC_STALL_MAIN_US"))   // stress: the other tracers fall far behind T and S
+      hipLaunchKernelGGL(k_stall, dim3(1), dim3(1), 0, h->stream, (long long)atoi(e) * 100);
+#endif
     launch_b(cr, br, (const double *)(S + 2 * N3), h->stream);
     if (h->tsi_step) { mark(h, "colupd"); if (int rc = launch_tsi_rows(h, cr, h->stream, 0)) return rc; }
   } else {
