@@ -59,22 +59,20 @@ def pmc_traffic(kernel, workload_ok, split=False):
     (profiles/traffic.json, or $UVIC_TRAFFIC_JSON) and is null for any other workload."""
     path = os.environ.get("UVIC_TRAFFIC_JSON") or str(ROOT / "profiles" / "traffic.json")
     if not workload_ok or not os.path.exists(path):
-        return None, None
+        return None, None, None
     try:
         kernels = json.load(open(path))["kernels"]
         # the mark "colfct" / "colupd" is the pass, whichever form of the kernel the library launched for it
-        forms = {"colfct": ["k_colfct_sha_y", "k_colfct_sh_y", "k_colfct_sha", "k_colfct_sh", "k_colfct2", "k_colfct"],
-                 "colupd": ["k_colupd_y", "k_colupd_zg", "k_colupd"]}.get(kernel, ["k_" + kernel])
-        key = next((f for f in forms if any(k == f or k.startswith(f + "#") for k in kernels)), forms[-1])
+        key = "k_" + kernel
         if split:   # the summary lists a kernel per grid: plain name = all tracers in one launch (mixing steps, isolated
             # profile), "name#<grid>" the others; the main-stream launch of the other nt-2 tracers is the largest of those
             alt = [k for k in kernels if k.startswith(key + "#")]
             if alt:
                 key = max(alt, key=lambda k: int(k.split("#")[1]))
         ent = kernels.get(key)
-        return (ent or {}).get("total"), os.path.relpath(path, ROOT)
+        return (ent or {}).get("total"), os.path.relpath(path, ROOT), (ent or {}).get("valu_wave_insts")
     except (ValueError, KeyError, OSError):
-        return None, None
+        return None, None, None
 
 
 def hbm_probe(torch, mib=1024, nrep=20):
@@ -460,15 +458,16 @@ def main():
         prof = live
         names = [k for k in prof if kernel_alg_bytes(k, nt, nsrc)]
         dom = max(names, key=lambda k: prof[k])
-        # tracers of the dominant launch: when T and S take their passes first on the side stream (colfct_ts, colupd_ts:
+        # tracers of the dominant launch: when T and S take their passes first on the side stream (colx_fct_ts, colx_upd_conv_ts:
         # single rank and latitude slabs), the main-stream launch of colfct / colupd holds the other nt-2
-        nt_launch = shard.nt_local - 2 if "colfct_ts" in prof else shard.nt_local
+        ts_split = any(k in prof for k in ("colx_fct_ts", "colfct_ts", "fct_rows_ts"))   # T,S in kernels of their own
+        nt_launch = shard.nt_local - 2 if ts_split else shard.nt_local
         local_units = imt * jmt * km * nt_launch
         if decomp == "slab":
             local_units = imt * (shard.je - shard.js + 1 + 2) * km * nt_launch     # pass A also does one row beyond each side
         ach = kernel_alg_bytes(dom, nt_launch, nsrc) * local_units / (prof[dom] * 1e-3) / 1e9
         step_gbs = b_alg(nt, nsrc) * value / 1e9
-        traffic, traffic_src = pmc_traffic(dom, world == 1 and a.cfg == "c30" and a.grid == "102x102x19", split="colfct_ts" in prof)
+        traffic, traffic_src, valu_insts = pmc_traffic(dom, world == 1 and a.cfg == "c30" and a.grid == "102x102x19", split=ts_split)
         hbm_meas = max(hbm.get("copy_GBs", 0.0), hbm.get("triad_GBs", 0.0)) if hbm else 0.0
         out = {
             "metric": "tracer-cell updates/s (imt*jmt*km*nt)", "value": value, "unit": "cell-updates/s",
@@ -491,6 +490,11 @@ def main():
                                            "gloo through the host (rehearsal)" if rehearse else "RCCL")} if world > 1 else {})},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # what actually binds the kernel (fp64 VALU issue, not HBM): wave-level VALU instructions of the
+                         # launch (SQ_INSTS_VALU of the same PMC passes, scaled to all waves) x 4 cycles per wave64 fp64
+                         # instruction over 1024 SIMDs at 2.4 GHz x the launch's duration in the loop
+                         **({"valu_wave_insts": valu_insts,
+                             "valu_issue_frac": valu_insts * 4.0 / (1024 * 2.4e9 * prof[dom] * 1e-3)} if valu_insts else {}),
                          **({"peak_measured": hbm_meas, "frac_of_measured": ach / hbm_meas, "hbm_probe": hbm} if hbm_meas else {}),
                          "note": "dominant HBM-side (transport) kernel; kernel_ms are HIP-event means over a second, instrumented "
                                  "pass of the same K steps (ms_per_step_instrumented), where the look-ahead chains (MOBI, isopyc) "

@@ -53,6 +53,12 @@ except (KeyError, ZeroDivisionError) as e:
     print("calibration missing:", e)
 print("calibration (true bytes / counter bytes, 8 B per lane coalesced, 64 MiB): " + " ".join(f"{k}={v:.3f}" for k, v in cal.items()))
 fs, ws = load("fetch"), load("write")
+SQ = load("sq1")
+BIGGEST = {}
+for f in glob.glob(f"{base}/sq1/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].split("(")[0]
+        BIGGEST[n] = max(BIGGEST.get(n, 0), int(r["Grid_Size"]))
 traffic = {"unit": "bytes per launch", "calibration": cal, "kernels": {}}
 kf = cal.get("fetch_read8", 1.0)
 kw = cal.get("write_copy8", 1.0)
@@ -64,6 +70,12 @@ for k in sorted(set(fs) | set(ws)):
     ent = {"fetch_raw": fr, "write_raw": wr,
            "fetch": None if fr is None else fr * kf, "write": None if wr is None else wr * kw}
     ent["total"] = None if fr is None or wr is None else ent["fetch"] + ent["write"]
+    # wave-level VALU instructions per launch: the SQ counters see a share of the launch's waves (SQ_WAVES of grid/64)
+    sq = SQ.get(k)
+    if sq and "SQ_INSTS_VALU" in sq and "SQ_WAVES" in sq and mean(sq["SQ_WAVES"]) > 0:
+        grid = int(k.split("#")[1]) if "#" in k else BIGGEST.get(k.split("#")[0], 0)
+        if grid:
+            ent["valu_wave_insts"] = mean(sq["SQ_INSTS_VALU"]) * (grid / 64.0) / mean(sq["SQ_WAVES"])
     traffic["kernels"][k] = ent
     print(f"traffic {k:20s} fetch={ent['fetch'] and ent['fetch']/1e6:.2f} MB write={ent['write'] and ent['write']/1e6:.2f} MB per launch (corrected)")
 if len(sys.argv) > 2:
