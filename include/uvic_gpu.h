@@ -329,6 +329,17 @@ int uvic_gpu_sbc_transfer(uvic_gpu *h, double *host, int upload);
 int uvic_gpu_set_tsi(uvic_gpu *h, int on, int ic14, int idic);
 int uvic_gpu_tsi_read(uvic_gpu *h, double *tbar, double *travar, double *dtabs, double *dc14bar);
 int uvic_gpu_tsi_ektot(uvic_gpu *h, double rho0, double *ektot);
+/* Time-average steps (O_time_averages: timavgperts, one year in ten with the shipped run/control.in).  What `tracer`
+ * accumulates inside its own loops on such a step, with the options of run/mk.in: the convection diagnostics of convct2
+ * (O_save_convection; source/mom/convect.F:183-191, 279-283, 295-301: totalk, vdepth, pe -- u09/mom/tracer.F:1211-1222 adds
+ * them to ta_totalk, ta_vdepth, ta_pe) and the delta-14C field (O_carbon_14; tracer.F:1329-1340, :1355-1364 -> ta_dc14).
+ * uvic_gpu_set_tavg names the coming step as one (grav: pconst; zt (km): coord.h; ic14, idic 1-based or 0); the step then
+ * forms them on the device -- pe as the reference's one running sum over the column before and after convection, every
+ * interior column -- and uvic_gpu_tavg_read fetches totalk, vdepth, pe (imt,jmt each) and dc14 (imt,km,jmt; null if not
+ * wanted) after it.  Everything else a time-average step needs is outside `tracer` (diag -> avgvar reads t(tau), u(tau),
+ * adv_vbt from the memory window: a caller that keeps them on the device brings them down on such steps). */
+int uvic_gpu_set_tavg(uvic_gpu *h, int on, double grav, const double *zt, int ic14, int idic);
+int uvic_gpu_tavg_read(uvic_gpu *h, double *totalk, double *vdepth, double *pe, double *dc14);
 
 typedef struct uvic_overlay_step {
   double c2dtts, c2dtts_next, relyr_next, co2ccn_next;

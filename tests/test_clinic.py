@@ -256,12 +256,14 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=()):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
-    run, as in the model, on whatever the host arrays hold).  on_host: steps with a diagnostic switch set, which the
-    overlays hand to the reference routines.  segment: ocean steps per coupling segment (isbcu/asbcu sums of clinic)."""
+    run, as in the model, on whatever the host arrays hold).  on_host: steps with a diagnostic switch set (term balances),
+    which the overlays hand to the reference routines.  tavg: time-average steps (timavgperts), which stay on the device;
+    what `diag -> avgvar` reads of the memory window after them (t(tau), u(tau), adv_vbt) is appended to the returned list.
+    segment: ocean steps per coupling segment (isbcu/asbcu sums of clinic)."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -287,7 +289,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0)
         if segment:
             S("osegs", 1 if (n - 1) % segment == 0 else 0); S("osege", 1 if n % segment == 0 else 0)
         if on_host:
-            S("timavgperts", 1 if n in on_host else 0)
+            S("trmbts", 1 if n in on_host else 0)
+        if tavg:
+            S("timavgperts", 1 if n in tavg else 0)
         R.add_ext_mode(_psi(g, n), "tau")
         if n == 1:
             R.add_ext_mode(_psi(g, 0), "tau-1")
@@ -300,6 +304,10 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0)
         zus.append(zu)
         if segment and n % segment == 0:
             zus.append(np.array(v["sbc"][:, :, np_ - 10:np_ - 6], order="F"))     # the averages the atmosphere reads
+        if n in tavg:      # what avgvar (diag.F:138-147) reads next
+            zus.append(np.array(v["t"][:, :, 1:-1, :, 1], order="F"))
+            zus.append(np.array(v["u"][:, :, 1:-1, :, 1], order="F"))
+            zus.append(np.array(v["adv_vbt"][:, :, :-1], order="F"))
         R.rotate()
         u = v["u"]
         u[..., 0] = u[..., 1]
@@ -372,7 +380,8 @@ def test_fortran_overlays_keep_the_velocities_on_the_device(imt, jmt, km, nsteps
     (loadmw's add_ext_mode, state, adv_vel, setvbc) keep running on the host's stale copy as they would in the model.
     zu of every step, the isbcu/asbcu averages at the end of every segment, and T, S, u after the last step equal the
     reference's own loop bit for bit; one step in the middle carries a diagnostic switch and goes through the reference
-    routines (u comes down, adv_vel and setvbc are redone on the host, u(tau+1) goes back up)."""
+    routines (u comes down, adv_vel and setvbc are redone on the host, u(tau+1) goes back up); one is a time-average step,
+    which stays on the device and leaves t(tau), u(tau) and adv_vbt on the host for avgvar."""
     import refmodel
     if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
         pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
@@ -383,8 +392,9 @@ def test_fortran_overlays_keep_the_velocities_on_the_device(imt, jmt, km, nsteps
         monkeypatch.delenv("UVIC_EXACT", raising=False)
     oc, mom, _, _ = _setup(imt, jmt, km)
     on_host = (nsteps - 3,) if nsteps > 5 else ()
-    t_ref, u_ref, um_ref, zus = _reference_loop(oc, mom, nsteps, True, on_host=on_host, segment=3)
-    out = _reference_loop(oc, mom, nsteps, True, shim=True, on_host=on_host, segment=3)
+    tavg = (nsteps - 1,) if nsteps > 5 else (3,)
+    t_ref, u_ref, um_ref, zus = _reference_loop(oc, mom, nsteps, True, on_host=on_host, segment=3, tavg=tavg)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, on_host=on_host, segment=3, tavg=tavg)
     if len(out) != 5:
         pytest.skip("oracle/_ref shim predates the resident velocities")
     t, u, um, got, stale = out

@@ -357,3 +357,64 @@ def test_time_step_monitor_steps_stay_on_the_device(resident, exact, monkeypatch
         assert np.array_equal(got_u[:, :, 1:-1], want_u[:, :, 1:-1])
         assert np.abs(ref.v["ektot"]).max() > 0 and np.array_equal(shim.v["ektot"], ref.v["ektot"]), it
         ref.rotate(); shim.rotate()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("resident", [False, True])
+def test_time_average_steps_stay_on_the_device(resident, exact, monkeypatch):
+    """With the shipped run/control.in (timavgint = 3650 d, timavgper = 365 d) timavgperts is true on one year in ten, and
+    run/mk.in defines O_time_averages and O_save_convection: on such a step `tracer` also adds the convection diagnostics of
+    convct2 (totalk, vdepth, pe; convect.F:183-301, tracer.F:1211-1222) and the delta-14C field (tracer.F:1329-1364) to its
+    time averages, and `diag -> avgvar` afterwards reads t(tau) of EVERY tracer from the memory window.  The overlay keeps
+    such steps on the device (a step through the reference routine costs a thousand device steps): five steps of option set C,
+    three of them time-average steps and all of them time-step-monitor steps, against the unmodified reference -- the
+    accumulated ta_totalk, ta_vdepth, ta_pe, nta_conv bit for bit (they depend on T and S alone), ta_dc14 and the host's
+    t(tau) on those steps to the production tolerance."""
+    _arith(monkeypatch, exact)
+    if resident:
+        monkeypatch.setenv("UVIC_RESIDENT", "1")
+    else:
+        monkeypatch.delenv("UVIC_RESIDENT", raising=False)
+    cfg, dims = "t30", (14, 14, 6)
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    ref = refdriver.RefOcean(oc)
+    shim = refdriver.RefOcean(oc, shim=True)
+    if not hasattr(shim.ref.lib, "tracer_gpu_tavg_"):
+        pytest.skip("oracle/_ref shim predates the time-average steps on the device")
+    jmt = dims[1]
+    names = ("ta_totalk", "ta_vdepth", "ta_pe", "ta_dc14")
+    for R in (ref, shim):
+        R.set_step_kind(False)
+        R.ref.set("nmix", 0); R.ref.set("tsiperts", 1); R.ref.set("nta_conv", 0)
+        for n in names:
+            R.v[n][...] = 0.0
+        # a few columns with dense water on top, so that the convective walk has something to do on every step
+        t = R.v["t"]
+        for slot in (0, 1):
+            t[3:9, 0, 3:9, 0, slot] -= 6.0
+            t[3:9, 0, 3:9, 0, slot] *= oc.topo.tmask[3:9, 0, 3:9]
+    for it in range(1, 6):
+        tavg = it in (2, 3, 4)
+        for R in (ref, shim):
+            _segment_switches(R, it, 4)
+            R.ref.set("timavgperts", 1 if tavg else 0)
+            for n in ("tbar", "travar", "dtabs"):
+                R.v[n][...] = 0.0
+            R.ref.set("dc14bar", 0.0)
+        want = ref.step().copy()
+        got = shim.step().copy()
+        assert _same(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2], exact), it
+        if tavg:    # what avgvar reads next: t(tau) of every tracer, on the host
+            a, b = shim.v["t"][:, :, 1:jmt - 1, :, 1], ref.v["t"][:, :, 1:jmt - 1, :, 1]
+            for n, name in enumerate(oc.cfg.tracers):
+                assert np.abs(a[..., n] - b[..., n]).max() <= PROD_TOL * max(np.abs(b[..., n]).max(), 1e-300), (it, name)
+        ref.rotate(); shim.rotate()
+    assert int(shim.ref.get("nta_conv")) == int(ref.ref.get("nta_conv")) == 3
+    assert ref.v["ta_totalk"].max() >= 2.0 and np.abs(ref.v["ta_pe"]).max() > 0.0 and ref.v["ta_vdepth"].max() > 0.0
+    for n in ("ta_totalk", "ta_vdepth", "ta_pe"):
+        assert np.array_equal(shim.v[n], ref.v[n]), n
+    a, b = shim.v["ta_dc14"], ref.v["ta_dc14"]
+    assert np.abs(b).max() > 0 and np.abs(a - b).max() <= PROD_TOL * np.abs(b).max()

@@ -4,7 +4,7 @@ calls them -- on the 102x102x19 grid (oracle/_ref shim "m2": T and S only; or "t
 and ocean segments of four steps), PCIe included, with the velocities shipped on
 every call (UVIC_RESIDENT=1) or resident on the device (UVIC_RESIDENT=2: psi and the wind stress up, zu down).  The host
 routines of the loop (loadmw's add_ext_mode, state, adv_vel, isopyc, setvbc) are run but not timed.
-usage: UVIC_RESIDENT=1|2 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--json]"""
+usage: UVIC_RESIDENT=1|2 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--tavg] [--json]"""
 import os
 import sys
 import time
@@ -22,6 +22,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 24
 cfg = args[1] if len(args) > 1 else "m2"       # "t30": option set C built as run/mk.in builds it, tsiperts on every step
 as_json, seg = "--json" in sys.argv, 4
+tavg = "--tavg" in sys.argv                    # every step a time-average step as well (timavgperts: one year in ten of the shipped run)
 dims = (102, 102, 19)
 oc = synthetic.make_ocean(cfg, *dims)
 mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
@@ -37,6 +38,7 @@ R.set_step_kind(False)
 v["u"][..., 2] = 0.0
 if cfg == "t30":
     S("nmix", 0); S("ntspos", seg); S("prelyr", float(v["relyr"][0])); S("tsiperts", 1)
+    S("timavgperts", 1 if tavg else 0)
 tt, tc = [], []
 for it in range(1, n + 1):
     S("itt", it)
@@ -61,7 +63,7 @@ for it in range(1, n + 1):
 med = lambda x: sorted(x[4:])[len(x[4:]) // 2] * 1e3
 if as_json:
     import json
-    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "steps": n, "cfg": cfg,
+    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "steps": n, "cfg": cfg, "time_average_steps": tavg,
                       "resident": os.environ.get("UVIC_RESIDENT", "")}))
     sys.exit(0)
 print(f"UVIC_RESIDENT={os.environ.get('UVIC_RESIDENT', '')}: tracer call {med(tt):.3f} ms, clinic call {med(tc):.3f} ms (medians over {n - 4} steps, PCIe included)")

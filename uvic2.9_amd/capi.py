@@ -51,7 +51,7 @@ EXPORTS = [
     "uvic_gpu_set_clinic_params", "uvic_gpu_state", "uvic_gpu_clinic", "uvic_gpu_set_filter_u",
     "uvic_gpu_state_async", "uvic_gpu_clinic_async",
     "uvic_gpu_tmm_create", "uvic_gpu_tmm_set_mobi", "uvic_gpu_tmm_sources", "uvic_gpu_rotate_u", "uvic_gpu_add_ext_mode", "uvic_gpu_adv_vel_async",
-    "uvic_gpu_momentum_async", "uvic_gpu_momentum_wait", "uvic_gpu_unpin_host", "uvic_gpu_set_option", "uvic_gpu_set_tsi", "uvic_gpu_tsi_read", "uvic_gpu_tsi_ektot",
+    "uvic_gpu_momentum_async", "uvic_gpu_momentum_wait", "uvic_gpu_unpin_host", "uvic_gpu_set_option", "uvic_gpu_set_tsi", "uvic_gpu_tsi_read", "uvic_gpu_tsi_ektot", "uvic_gpu_set_tavg", "uvic_gpu_tavg_read",
 ]
 
 
@@ -163,6 +163,8 @@ def load():
     lib.uvic_gpu_halo_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     lib.uvic_gpu_overlay_inputs.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 6
+    lib.uvic_gpu_set_tavg.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.uvic_gpu_tavg_read.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
     lib.uvic_gpu_overlay_velocities.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.uvic_gpu_overlay_momentum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double] + [ctypes.c_void_p] * 4
     lib.uvic_gpu_push_setup.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]

@@ -250,6 +250,46 @@ __global__ void k_stall(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 #endif
+// ---- time-average steps (O_time_averages + O_save_convection, timavgperts): what `tracer` accumulates inside its own loops
+// The convection diagnostics of convct2 (source/mom/convect.F:183-191, 279-283, 295-301): pe(i,j) is ONE running sum -- the
+// potential energy of the column before convection added level by level, then the same after convection subtracted level by
+// level, then divided by c2dtts -- so the two halves run before and after the walk on the same plane, every interior
+// column (land included: the reference's residue of rounding is reproduced, not assumed zero); totalk and vdepth come
+// from the segments the walk recorded.  diag: (imt, jmt, 3) = totalk, vdepth, pe.
+__global__ void __launch_bounds__(64) k_conv_pe(const uvic_ctx c, const double *zt, double grav, double *diag, int phase) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ni = c.imt - 2, nrows = c.je - c.js + 1;
+  if (gid >= ni * nrows) return;
+  const int i = gid % ni + 2, j = c.js + gid / ni;
+  UV_DIMS(c);
+  const size_t ij = X2(i, j), N2 = (size_t)imt * jmt;
+  const double *ts = c.t_taup1;
+  double pe = phase == 0 ? 0.0 : diag[2 * N2 + ij];
+  for (int k = 1; k <= km; ++k) {
+    const double ru = eos_dens(c.c, km, ts[X3(i, k, j)] - c.to[k - 1], ts[X3(i, k, j) + N3] - c.so[k - 1], k);
+    const double term = grav * zt[k - 1] * ru * c.dztxcl[k - 1];
+    pe = phase == 0 ? pe + term : pe - term;
+  }
+  if (phase == 0) { diag[2 * N2 + ij] = pe; return; }
+  diag[2 * N2 + ij] = pe / c.c2dtts;
+  double totalk = 0.0, vdepth = 0.0;
+  const int nseg = c.cv_nseg[ij];
+  for (int s = 1; s <= nseg; ++s) {
+    const int kt = c.cv_kt[X3(i, s, j)], kb = c.cv_kb[X3(i, s, j)];
+    totalk = totalk + (double)(kb - kt + 1);
+    if (kt == 1) vdepth = c.zw[kb - 1];
+  }
+  diag[ij] = totalk;
+  diag[N2 + ij] = vdepth;
+}
+// delta 14C of the final t(tau+1) as a field (tracer.F:1329-1340): what ta_dc14 accumulates
+__global__ void __launch_bounds__(256) k_dc14_field(const uvic_ctx c, int ic14, int idic, double rc14std, double *out) {
+  CELL_DECODE(c);
+  if (j > c.jmt) return;
+  const size_t N3 = (size_t)c.imt * c.km * c.jmt, q = (size_t)gid;
+  const double rrc14std = 1000. / rc14std;
+  out[q] = (rrc14std * c.t_taup1[(size_t)(ic14 - 1) * N3 + q] / (c.t_taup1[(size_t)(idic - 1) * N3 + q] + UV_EPSLN) - 1000.) * c.tmask[q];
+}
 // ---- baroclinic momentum step (kernels_clinic.hpp) -----------------------------------
 #define COL_DECODE(m)                                                 \
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;              \
@@ -1088,6 +1128,11 @@ struct uvic_gpu {
   bool tsi_step;                // this step
   int tsi_ic14, tsi_idic;       // tracer numbers of 14C and DIC (0: no delta-14C sum)
   double *tsi_acc;              // tbar, travar, dtabs, each (0:km, nt, jmt); then (km, jmt) row sums of delta 14C
+  // time-average steps (uvic_gpu_set_tavg): convection diagnostics (imt, jmt, 3), the delta-14C field, depths of the T points
+  bool tavg_step = false;
+  double tavg_grav = 0.0;
+  double *tavg_zt = nullptr, *tavg_diag = nullptr, *tavg_dc14 = nullptr;
+  int tavg_ic14 = 0, tavg_idic = 0;
   double *tsi_host = nullptr;   // the same, page-locked: filled behind every time-step-monitor step
   hipEvent_t ev_tsi = nullptr;
   bool tsi_inflight = false;
@@ -1150,7 +1195,7 @@ static int64_t field_elems(const uvic_dims &d, int f) { return plane(d, FIELDS[f
 static size_t elem_size(int f) { return FIELDS[f].is_int ? 4 : 8; }
 
 extern "C" const char *uvic_gpu_last_error(void) { return g_err.c_str(); }
-extern "C" int uvic_gpu_abi_version(void) { return 11; }   // 11: uvic_gpu_overlay_inputs, uvic_gpu_overlay_velocities, uvic_gpu_overlay_momentum, uvic_gpu_push_*; 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
+extern "C" int uvic_gpu_abi_version(void) { return 11; }   // 11: uvic_gpu_set_tavg/_tavg_read, uvic_gpu_overlay_inputs, uvic_gpu_overlay_velocities, uvic_gpu_overlay_momentum, uvic_gpu_push_*; 10: uvic_gpu_set_option, set_exact modes 2 and 3 (T and S bit-exact by default); 9: uvic_gpu_unpin_host; 8: uvic_gpu_momentum_async/_wait; 7: uvic_gpu_rotate_u, uvic_gpu_add_ext_mode; 6: uvic_gpu_tmm_*; 5: uvic_gpu_state, uvic_gpu_clinic
 
 static void bind_ctx(uvic_gpu *h) {
   uvic_ctx &c = h->ctx;
@@ -1440,6 +1485,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipFree(h->sbc_acc);
   (void)hipFree(h->tsi_acc);
   if (h->tsi_host) { (void)hipHostFree(h->tsi_host); (void)hipEventDestroy(h->ev_tsi); }
+  (void)hipFree(h->tavg_zt); (void)hipFree(h->tavg_diag); (void)hipFree(h->tavg_dc14);
   (void)hipEventDestroy(h->ev_ts_host);
   if (h->mobi_st.params) {
     (void)hipFree(h->mobi_st.params);
@@ -1891,6 +1937,7 @@ static unsigned col_blocks(const uvic_gpu *h, int bs) {
 
 // the T,S-derived fields of a step (mixing tensor, GM velocities, folded coefficients): ctx `c` says what is read
 // (t_taum1) and where the products go; `sid` 0 = main stream, 2 = the isopyc side stream
+static int launch_conv_pe(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int phase);
 static int inputs_next_copy(uvic_gpu *h);
 static int inputs_first(uvic_gpu *h, bool vbt_follows = false);
 static int inputs_rest(uvic_gpu *h);
@@ -2141,7 +2188,8 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     mark_on(h, "begin", 3);
     const WetCols w = wet_range(h, c.js, c.je);
     // (a time-step-monitor step wants t(tau+1) of T and S before convection: pass B, the sums, then the walk on its own)
-    const bool walk_fused = w.count > 0 && !h->tsi_step && !(h->ts_exact && h->ts_rows);
+    // (and so does a time-average step: the convection diagnostics sum over the column before and after the walk)
+    const bool walk_fused = w.count > 0 && !h->tsi_step && !h->tavg_step && !(h->ts_exact && h->ts_rows);
     if (h->ts_exact && h->ts_rows) {   // cross-check: the row kernels of kernels_fct.hpp
       if (int rc = launch_rows(h, cts, h->side_ts, 3, nullptr, "fct_rows_ts", "update_rows_ts")) return rc;
     } else if (h->ts_exact) {
@@ -2153,10 +2201,12 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     }
     if (!walk_fused) {
       if (int rc = launch_tsi_rows(h, cts, h->side_ts, 3)) return rc;
+      if (int rc = launch_conv_pe(h, cts, h->side_ts, 0)) return rc;
       HIPCHK(hipMemsetAsync(h->cv_list, 0, 4, h->side_ts));
       if (w.count > 0)
         hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), ((size_t)2 * h->d.km * 64 + (size_t)12 * h->d.km) * 8, h->side_ts, cts, w, h->cv_list);
       mark_on(h, "convect_ts", 3);
+      if (int rc = launch_conv_pe(h, cts, h->side_ts, 1)) return rc;
     }
     HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
     if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
@@ -2224,11 +2274,21 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+// the two halves of the convection diagnostics of a time-average step, around the T,S walk on stream `st`
+static int launch_conv_pe(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int phase) {
+  if (!h->tavg_step) return 0;
+  const int n = (c.imt - 2) * (c.je - c.js + 1);
+  hipLaunchKernelGGL(k_conv_pe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c, (const double *)h->tavg_zt, h->tavg_grav, h->tavg_diag, phase);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int launch_convect(uvic_gpu *h) {
   mark(h, "begin");
   if (h->exact_convect) {
+    if (int rc = launch_conv_pe(h, h->ctx, h->stream, 0)) return rc;
     hipLaunchKernelGGL(k_convect, dim3(col_blocks(h, 128)), dim3(128), 0, h->stream, h->ctx);
     mark(h, "convect");
+    if (int rc = launch_conv_pe(h, h->ctx, h->stream, 1)) return rc;
   } else {
     const WetCols w = wet_range(h, h->ctx.js, h->ctx.je);
     const bool fused = h->ts_ahead;   // the T,S walk has run on the side stream (launch_transport): its mixed ranges are replayed here
@@ -2240,9 +2300,11 @@ static int launch_convect(uvic_gpu *h) {
       mark(h, "convect_apply");
     }
     if (!fused) {
+      if (int rc = launch_conv_pe(h, h->ctx, h->stream, 0)) return rc;
       if (w.count > 0)
         hipLaunchKernelGGL(k_convect_ts, dim3((unsigned)((w.count + 63) / 64)), dim3(64), (size_t)2 * h->d.km * 64 * 8 + (size_t)12 * h->d.km * 8, h->stream, h->ctx, w, (int *)nullptr);
       mark(h, "convect_ts");
+      if (int rc = launch_conv_pe(h, h->ctx, h->stream, 1)) return rc;
     }
     if (h->d.nt > 2 && !fused) {
       const long long n = (long long)w.count * (h->d.nt - 2);
@@ -2257,6 +2319,10 @@ static int launch_convect(uvic_gpu *h) {
                        (size_t)(2 * h->flt_threads + 4) * 8, h->stream, cf, (const FilterItem *)h->flt_items,
                        (const double *)h->flt_mats, h->flt_nitems);
     mark(h, "filt");
+  }
+  if (h->tavg_step && h->tavg_ic14 > 0 && h->tavg_idic > 0) {   // the delta-14C field of the final t(tau+1), tracer.F:1329-1340
+    hipLaunchKernelGGL(k_dc14_field, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx, h->tavg_ic14, h->tavg_idic, UV_RC14STD, h->tavg_dc14);
+    mark(h, "dc14_field");
   }
   if (h->tsi_step && h->tsi_ic14 > 0 && h->tsi_idic > 0) {   // delta 14C of the final t(tau+1), tracer.F:1329-1353
     const size_t NA = (size_t)(h->d.km + 1) * h->d.nt * h->d.jmt;
@@ -3260,6 +3326,7 @@ extern "C" int uvic_gpu_rotate(uvic_gpu *h) {
     h->ev_src_ready = h->ev_src_pending;
   }
   h->tsi_step = false;
+  h->tavg_step = false;
   if (h->cv_lists[0]) {   // the convective walk's arrays of the step that starts now
     const int odd = (int)((h->step_no + 1) & 1);
     h->cv_list = h->cv_lists[odd];
@@ -3553,6 +3620,49 @@ extern "C" int uvic_gpu_set_tsi(uvic_gpu *h, int on, int ic14, int idic) {
 // ... and fetch them once the step is complete (waits for it): tbar, travar, dtabs as source/common/diag.h declares them,
 // (0:km, nt, jmt) each (rows and levels the step did not compute are zero, as diagi leaves them); dc14bar = the sum of the
 // rows' sums, rows ascending.  Call before the uvic_gpu_rotate that ends the step, or right after uvic_gpu_overlay_step.
+// -- time-average steps (O_time_averages, timavgperts; u09/mom/tracer.F:1211-1222, 1355-1364 with O_save_convection and
+// O_carbon_14): the step named by uvic_gpu_set_tavg also forms the convection diagnostics totalk, vdepth, pe of convct2
+// (source/mom/convect.F:183-301) and the delta-14C field; uvic_gpu_tavg_read fetches them after the step (before the
+// rotation that ends it, or right after uvic_gpu_overlay_step).  grav, zt(km): pconst / coord.h.  ic14/idic = 0: no 14C.
+extern "C" int uvic_gpu_set_tavg(uvic_gpu *h, int on, double grav, const double *zt, int ic14, int idic) {
+  if (!h) return fail_msg("uvic_gpu_set_tavg: null handle");
+  if (ic14 < 0 || ic14 > h->d.nt || idic < 0 || idic > h->d.nt) return fail_msg("uvic_gpu_set_tavg: tracer number outside 1..nt");
+  HIPCHK(hipSetDevice(h->device));
+  if (on) {
+    if (!zt) return fail_msg("uvic_gpu_set_tavg: zt missing");
+    const size_t N2 = (size_t)h->d.imt * h->d.jmt, N3 = N2 * h->d.km;
+    if (!h->tavg_zt) {
+      HIPCHK(hipMalloc((void **)&h->tavg_zt, (size_t)h->d.km * 8));
+      HIPCHK(hipMalloc((void **)&h->tavg_diag, 3 * N2 * 8));
+      HIPCHK(hipMemset(h->tavg_diag, 0, 3 * N2 * 8));
+    }
+    if (ic14 > 0 && idic > 0 && !h->tavg_dc14) {
+      HIPCHK(hipMalloc((void **)&h->tavg_dc14, N3 * 8));
+      HIPCHK(hipMemset(h->tavg_dc14, 0, N3 * 8));
+    }
+    HIPCHK(hipMemcpyAsync(h->tavg_zt, zt, (size_t)h->d.km * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->tavg_grav = grav;
+  }
+  h->tavg_step = on != 0;
+  h->tavg_ic14 = ic14; h->tavg_idic = idic;
+  return 0;
+}
+extern "C" int uvic_gpu_tavg_read(uvic_gpu *h, double *totalk, double *vdepth, double *pe, double *dc14) {
+  if (!h || !totalk || !vdepth || !pe) return fail_msg("uvic_gpu_tavg_read: null argument");
+  if (!h->tavg_diag) return fail_msg("uvic_gpu_tavg_read: no time-average step has run (uvic_gpu_set_tavg)");
+  HIPCHK(hipSetDevice(h->device));
+  if (int rc = uvic_gpu_sync(h)) return rc;
+  const size_t N2 = (size_t)h->d.imt * h->d.jmt, N3 = N2 * h->d.km;
+  HIPCHK(hipMemcpy(totalk, h->tavg_diag, N2 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(vdepth, h->tavg_diag + N2, N2 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(pe, h->tavg_diag + 2 * N2, N2 * 8, hipMemcpyDeviceToHost));
+  if (dc14) {
+    if (!h->tavg_dc14) return fail_msg("uvic_gpu_tavg_read: no delta-14C field (uvic_gpu_set_tavg without ic14, idic)");
+    HIPCHK(hipMemcpy(dc14, h->tavg_dc14, N3 * 8, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
 extern "C" int uvic_gpu_tsi_read(uvic_gpu *h, double *tbar, double *travar, double *dtabs, double *dc14bar) {
   if (!h || !tbar || !travar || !dtabs) return fail_msg("uvic_gpu_tsi_read: null argument");
   if (!h->tsi_acc) return fail_msg("uvic_gpu_tsi_read: no time-step-monitor step has run (uvic_gpu_set_tsi)");

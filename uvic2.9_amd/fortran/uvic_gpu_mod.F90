@@ -46,6 +46,8 @@
       integer(c_int), parameter :: F_DIFF_CBT=58
 !     adv_vel on the device (uvic_gpu_overlay_velocities)
       integer(c_int), parameter :: F_DXT2R=61, F_DYT2R=62
+!     depth of the T-cell bottoms: vdepth of the convection diagnostics (uvic_gpu_set_tavg)
+      integer(c_int), parameter :: F_ZW=63
 !     baroclinic momentum step (clinic_gpu.F)
       integer(c_int), parameter :: F_U1=59, F_U2=60, F_RHO=69
       integer(c_int), parameter :: F_UM1=70, F_UM2=71, F_UP1=72, F_UP2=73
@@ -258,6 +260,21 @@
           type(c_ptr), value :: h
           integer(c_int), value :: jsmw, jemw
           real(c_double) :: adv_vet(*), adv_vnt(*), adv_vbt(*), diff_cbt(*), stf(*), btf(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_tavg(h, on, grav, zt, ic14, idic) bind(C,name='uvic_gpu_set_tavg') result(rc)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: on, ic14, idic
+          real(c_double), value :: grav
+          real(c_double) :: zt(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_tavg_read(h, totalk, vdepth, pe, dc14) bind(C,name='uvic_gpu_tavg_read') result(rc)
+          import
+          type(c_ptr), value :: h
+          real(c_double) :: totalk(*), vdepth(*), pe(*)
+          type(c_ptr), value :: dc14
           integer(c_int) :: rc
         end function
         function uvic_gpu_overlay_velocities(h, ext_taum1, psi) bind(C,name='uvic_gpu_overlay_velocities') result(rc)
