@@ -1,8 +1,10 @@
 // kernels_prep.hpp -- producers of the tracer step's shared inputs:
 //   adv_vel   /root/reference/source/mom/adv_vel.F:63-131        (T-cell part, rigid lid)
 //   vmixc     /root/reference/updates/09/source/mom/vmixc.F:62-190 (O_constvmix O_tidal_kv O_isopycmix)
-// Same expressions and evaluation order as the reference (bit-identical apart from `exp` of the
-// device math library in the tidal term); one memory window, joff = 0.
+// Same expressions and evaluation order as the reference; one memory window, joff = 0.  vmixc's exponentials depend on
+// the level pair only: the library tabulates them on the host with the C library's exp -- the one the compiled
+// reference calls -- so diff_cbt comes out bit-identical (uvic_ctx.vmix_e/vmix_d; without the tables the kernel calls
+// exp itself and differs by its rounding).
 #ifndef UVIC_KERNELS_PREP_HPP
 #define UVIC_KERNELS_PREP_HPP
 
@@ -52,8 +54,10 @@ UVIC_DEV void vmixc_cell(const uvic_ctx &c, int i, int k, int j) {
     double edr = 0.;
     for (int k1 = k + 1; k1 <= kz; ++k1) {
       const double hab = c.zw[k - 1] - c.zw[k1 - 1];
+      const double e = c.vmix_e ? c.vmix_e[(k - 1) * km + k1 - 1] : exp(hab * c.zetar);
+      const double dn = c.vmix_d ? c.vmix_d[k1 - 1] : 1 - exp(-c.zetar * c.zw[k1 - 1]);
       edr = edr + (q2 * (c.edrm2[X3(i, k1, j)] + c.edrs2[X3(i, k1, j)]) + qk1 * c.edrk1[X3(i, k1, j)] + qo1 * c.edro1[X3(i, k1, j)]) *
-                      exp(hab * c.zetar) / (1 - exp(-c.zetar * c.zw[k1 - 1]));
+                      e / dn;
     }
     const double zkappa = c.ogamma * edr / zn2;
     d = dmax(c.kappa_h, dmin(100., zkappa + c.kappa_h));

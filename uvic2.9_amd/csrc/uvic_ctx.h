@@ -67,6 +67,9 @@ typedef struct uvic_ctx {
   const double *tlat;                                             /* (imt,jmt) */
   const double *edrm2, *edrs2, *edrk1, *edro1;                    /* (imt,km,jmt) */
   double kappa_h, zetar, ogamma, gravrho0r;
+  /* vmixc's two exponentials, tabulated on the host with the C library's exp (the one the reference calls):
+   * vmix_e[(k-1)*km + k1-1] = exp((zw(k)-zw(k1))*zetar), vmix_d[k1-1] = 1 - exp(-zetar*zw(k1)); null: exp in the kernel */
+  const double *vmix_e, *vmix_d;
   int no_landskip;   /* measurement: 1 = segments without ocean are marched like the others (UVIC_NO_LANDSKIP) */
   int prio;          /* bit 0: MOBI team waves at normal issue priority (UVIC_TEAM_PRIO0); bit 1: this launch at raised priority (the T,S passes) */
 } uvic_ctx;

@@ -1041,6 +1041,8 @@ struct uvic_gpu {
   int mobi_key;   // n15 | c13<<1 | caco3<<2 | silicon<<3 of the set bound by uvic_gpu_set_mobi_opt
   bool have_mobi;
   bool have_vmix;   // uvic_gpu_set_vmix_params was called
+  double *vmix_tab = nullptr;   // (km*km + km): uvic_ctx.vmix_e, vmix_d
+  bool vmix_tab_ready = false;
   std::vector<void *> pinned;   // host ranges page-locked through uvic_gpu_pin_host
   hipStream_t side_mom;     // uvic_gpu_momentum_async: state + clinic beside the tracer step
   hipEvent_t ev_mom_in, ev_mom_done;
@@ -1483,6 +1485,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   for (int q = 0; q < 2; ++q) (void)hipFree(h->cv_lists[q]);
   (void)hipFree(h->sbc_tracer);
   (void)hipFree(h->sbc_acc);
+  (void)hipFree(h->vmix_tab);
   (void)hipFree(h->tsi_acc);
   if (h->tsi_host) { (void)hipHostFree(h->tsi_host); (void)hipEventDestroy(h->ev_tsi); }
   (void)hipFree(h->tavg_zt); (void)hipFree(h->tavg_diag); (void)hipFree(h->tavg_dc14);
@@ -1712,6 +1715,7 @@ static int state_from_host(uvic_gpu *h, int field) {
 }
 // the host wrote into a time level of t: its land columns are the host's business again (land_clean)
 static void velocity_touched(uvic_gpu *h, int field) {
+  if (field == UVIC_F_ZW) h->vmix_tab_ready = false;
   if (field != UVIC_F_ADV_VET && field != UVIC_F_ADV_VNT && field != UVIC_F_ADV_VBT) return;
   for (int q = 0; q < 3; ++q)
     if (h->iso_set[q].for_step >= 0) h->iso_set[q].vel_stale = true;
@@ -2476,9 +2480,32 @@ static int launch_adv_vel(uvic_gpu *h) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+// the exponentials of vmixc.F:103-105 for every level pair, by the host's exp (synchronises the main stream once)
+static int vmix_tables(uvic_gpu *h) {
+  if (h->vmix_tab_ready) return 0;
+  const int km = h->d.km;
+  std::vector<double> zw(km), tab((size_t)km * km + km, 0.0);
+  HIPCHK(hipMemcpyAsync(zw.data(), h->buf[UVIC_F_ZW], (size_t)km * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const double zetar = h->ctx.zetar;
+  for (int k = 1; k <= km; ++k)
+    for (int k1 = k + 1; k1 <= km; ++k1) {
+      const double hab = zw[k - 1] - zw[k1 - 1];
+      tab[(size_t)(k - 1) * km + k1 - 1] = exp(hab * zetar);
+    }
+  for (int k1 = 1; k1 <= km; ++k1) tab[(size_t)km * km + k1 - 1] = 1 - exp(-zetar * zw[k1 - 1]);
+  if (!h->vmix_tab) HIPCHK(hipMalloc((void **)&h->vmix_tab, tab.size() * 8));
+  HIPCHK(hipMemcpyAsync(h->vmix_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->ctx.vmix_e = h->vmix_tab;
+  h->ctx.vmix_d = h->vmix_tab + (size_t)km * km;
+  h->vmix_tab_ready = true;
+  return 0;
+}
 static int launch_vmixc(uvic_gpu *h) {
   if (!h->have_vmix) return fail_msg("uvic_gpu_vmixc: call uvic_gpu_set_vmix_params first");
   if (!h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_vmixc: set uvic_params.diff_cbt_has_k33 = 1 (isopyc must leave diff_cbt to vmixc)");
+  if (int rc = vmix_tables(h)) return rc;
   mark(h, "begin");
   hipLaunchKernelGGL(k_vmixc, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
   mark(h, "vmixc");
@@ -2541,6 +2568,7 @@ extern "C" int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p) 
   if (!h || !p) return fail_msg("uvic_gpu_set_vmix_params: null argument");
   h->ctx.kappa_h = p->kappa_h; h->ctx.zetar = p->zetar; h->ctx.ogamma = p->ogamma; h->ctx.gravrho0r = p->gravrho0r;
   h->have_vmix = true;
+  h->vmix_tab_ready = false;
   return 0;
 }
 extern "C" int uvic_gpu_vmixc(uvic_gpu *h) {
