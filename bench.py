@@ -226,13 +226,17 @@ def ocean_overlay_baseline(imt, jmt, km, steps=32):
     """Both Fortran overlays in the reference's own order (`tracer` then `clinic`, source/mom/mom.F:389-395) on option set C
     built as run/mk.in builds it (oracle/_ref shim "t30": + O_stream_function, O_anisotropic_viscosity, O_ice_evp,
     O_time_step_monitor) with the switches the shipped run/control.in gives: tsiperts on every step (the time-step
-    integrals are formed on the device), ocean segments of four steps; tracers and velocities resident (UVIC_RESIDENT=2).
-    The host routines of the loop run between the calls and are not timed.  Medians, ms per call (tools/ocean_overlay_time.py)."""
+    integrals are formed on the device), ocean segments of four steps; tracers and velocities resident and `isopyc` and
+    `vmixc` left to the device (UVIC_RESIDENT=3, mixing_gpu.F: their two calls return at once -- isopyc_vmixc_calls_ms --
+    where the reference's own routines take host_isopyc_vmixc_ms, measured the same way with UVIC_RESIDENT=2).
+    The other host routines of the loop run between the calls and are not timed.  Medians, ms per call (tools/ocean_overlay_time.py)."""
     import refmodel
     if (imt, jmt, km) != (102, 102, 19) or not refmodel.available("t30", imt, jmt, km, shim=True):
         return None
-    out = _tool_json("ocean_overlay_time.py", [str(steps), "t30"], {"UVIC_RESIDENT": "2"})
-    out["switches"] = "tsiperts every step (run/control.in: tsiint = tsiper), segments of 4 steps, UVIC_RESIDENT=2"
+    out = _tool_json("ocean_overlay_time.py", [str(steps), "t30"], {"UVIC_RESIDENT": "3"})
+    host = _tool_json("ocean_overlay_time.py", ["12", "t30"], {"UVIC_RESIDENT": "2"})
+    out["host_isopyc_vmixc_ms"] = host["isopyc_vmixc_calls_ms"]
+    out["switches"] = "tsiperts every step (run/control.in: tsiint = tsiper), segments of 4 steps, UVIC_RESIDENT=3"
     return out
 
 

@@ -352,7 +352,12 @@ int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, double *ts_ho
  * diff_cbt (imt,km,jsmw:jemw), stf and btf (imt,jmt,nt) -- page-locked (uvic_gpu_pin_host) and left alone until the
  * step's uvic_gpu_overlay_step returns.  The copies run beside the main stream into the device copy the previous step
  * does not read, what T and S need first; the step waits for each group where it reads it.  adv_vbt may be null: it is
- * then formed on the device from adv_vet and adv_vnt as source/mom/adv_vel.F:98-127 does (rigid lid, zero at the surface). */
+ * then formed on the device from adv_vet and adv_vnt as source/mom/adv_vel.F:98-127 does (rigid lid, zero at the surface).
+ * diff_cbt may be null (after uvic_gpu_set_vmix_params, with uvic_params.diff_cbt_has_k33 = 1): the step then forms it on
+ * the device as updates/09/source/mom/vmixc.F:62-190 does -- tidal mixing above the bottom level from the stratification
+ * of the step's isopyc fields and UVIC_F_EDR*, the previous value below, plus K33 -- bit-identically (the scheme's two
+ * exponentials depend on the level pair only and are tabulated on the host with the C library's exp); a caller that
+ * does so need not run the host's `isopyc` and `vmixc` on that step at all (uvic2.9_amd/fortran/mixing_gpu.F). */
 int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
                             const double *diff_cbt, const double *stf, const double *btf);
 /* (adv_vet and adv_vnt may both be null after uvic_gpu_overlay_velocities, which has formed the step's velocities on the device.)
@@ -405,7 +410,9 @@ int uvic_gpu_set_vmix_params(uvic_gpu *h, const uvic_vmix_params *p);
 /* replaces the tracer part of `call vmixc (joff, js, je, is, ie)` (mom.F:347; u09/mom/vmixc.F:62-190 with
  * O_constvmix O_tidal_kv O_isopycmix): UVIC_F_DIFF_CBT = max(kappa_h, min(100, tidal + kappa_h)) above the
  * bottom level, the previous value elsewhere, plus K33.  Call after uvic_gpu_isopyc of the same step with
- * uvic_params.diff_cbt_has_k33 = 1 (isopyc then leaves diff_cbt to this call). */
+ * uvic_params.diff_cbt_has_k33 = 1 (isopyc then leaves diff_cbt to this call).  Bit-identical with the reference: exp
+ * of the level-pair terms comes from a host-made table (built at the first call after uvic_gpu_set_vmix_params from
+ * UVIC_F_ZW, which must have been uploaded). */
 int uvic_gpu_vmixc(uvic_gpu *h);
 
 /* ---- the reference's second, coarser boundary: the O_TMM column-batch source operator --------

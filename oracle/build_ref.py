@@ -166,7 +166,8 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
     if shim:
         # the drop-in test: the package's Fortran overlay (uvic2.9_amd/fortran) provides `tracer`;
         # it is preprocessed like any model source (it #includes the reference's headers)
-        shim_files = ["tracer_gpu.F"] + (["clinic_gpu.F"] if any(x.endswith("/clinic.F") for x in EXTRA_SOURCES.get(cfg, [])) else [])
+        # (mixing_gpu.F: `isopyc` and `vmixc` as calls the device makes unnecessary under UVIC_RESIDENT=3)
+        shim_files = ["tracer_gpu.F", "mixing_gpu.F"] + (["clinic_gpu.F"] if any(x.endswith("/clinic.F") for x in EXTRA_SOURCES.get(cfg, [])) else [])
         for f in shim_files:
             r = run(["cpp", "-traditional", "-P", *incs, *defs, str(SHIM_DIR / f)])
             (work / (Path(f).stem + ".f")).write_text(patch(r.stdout), encoding="latin-1")
@@ -194,8 +195,8 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
         if verbose:
             print("  compiled", f.name)
         objs.append(str(o))
-        if shim and f.name in ("tracer.f", "clinic.f"):
-            # keep the reference routine reachable as `tracer_cpu` / `clinic_cpu` (diagnostic time steps)
+        if shim and f.name in ("tracer.f", "clinic.f", "isopyc.f", "vmixc.f"):
+            # keep the reference routine reachable as `tracer_cpu` / `clinic_cpu` / ... (diagnostic time steps)
             nm = f.stem
             rr = run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--redefine-sym", f"{nm}_={nm}_cpu_", str(o)])
             if rr.returncode != 0:
@@ -245,7 +246,7 @@ def build_default(force: bool = False, verbose: bool = False, jobs: int = 4):
     if (GPU_LIB_DIR / "libuvic_gpu.so").exists():
         for cfg, imt, jmt, km in SHIM_BUILDS:
             t = shim_lib_name(cfg, imt, jmt, km)
-            srcs = [SHIM_DIR / "tracer_gpu.F", SHIM_DIR / "clinic_gpu.F", SHIM_DIR / "uvic_gpu_mod.F90"]
+            srcs = [SHIM_DIR / "tracer_gpu.F", SHIM_DIR / "clinic_gpu.F", SHIM_DIR / "mixing_gpu.F", SHIM_DIR / "uvic_gpu_mod.F90"]
             built.append(t)
             if t.exists() and not force and all(t.stat().st_mtime >= s_.stat().st_mtime for s_ in srcs):
                 continue

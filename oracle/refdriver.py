@@ -318,11 +318,27 @@ class RefOcean:
         gp = np.zeros((g.imt, g.km, g.jmt, 2), order="F"); gp[:, :, 1:g.jmt - 1] = v["grad_p"]
         return np.array(v["u"][..., 2], order="F"), np.array(v["zu"], order="F"), gp
 
+    def set_tidal(self, tidal):
+        """COMMON /tdr/ (updates/09/source/mom/tidal_kv.h) and the diffusivity vmixc finds below the bottom level on
+        the first step: from here on `step` calls the reference's own vmixc (tidal mixing + K33) after isopyc."""
+        g = self.ocean.grid
+        for n in ("edrm2", "edrs2", "edrk1", "edro1"):
+            self.v[n][...] = getattr(tidal, n)
+        for n in ("zetar", "ogamma", "gravrho0r", "kappa_h"):
+            self.ref.set(n, getattr(tidal, n))
+        self.v["diff_cbt"][...] = self.diff_cbt_bg[:, :, 1:g.jmt - 1]
+        self.v["k33"][...] = 0.0
+        self.tidal = tidal
+
     def step(self, c2dtts=None):
         if c2dtts is not None:
             self.ref.set("c2dtts", c2dtts)
         self.isopyc()
-        self.add_k33()
+        if getattr(self, "tidal", None) is not None:
+            g = self.ocean.grid
+            self.ref.call("vmixc", 0, 1, g.jmt, 2, g.imt - 1)       # mom.F:347
+        else:
+            self.add_k33()
         self.tracer()
         return self.v["t"][..., 2]
 

@@ -256,14 +256,16 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=()):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
     run, as in the model, on whatever the host arrays hold).  on_host: steps with a diagnostic switch set (term balances),
     which the overlays hand to the reference routines.  tavg: time-average steps (timavgperts), which stay on the device;
     what `diag -> avgvar` reads of the memory window after them (t(tau), u(tau), adv_vbt) is appended to the returned list.
-    segment: ocean steps per coupling segment (isbcu/asbcu sums of clinic)."""
+    segment: ocean steps per coupling segment (isbcu/asbcu sums of clinic).  tidal: the tidal dissipation fields -- the
+    reference's own `vmixc` (tidal mixing + K33) then follows `isopyc` instead of the "+K33" done here; the host's K33
+    after the last step is appended to what a shim run returns (stale where the overlays left isopyc to the device)."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -283,6 +285,13 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         v["sbc"][:, :, np_ - 10:np_ - 6] = np.random.default_rng(3).standard_normal((g.imt, g.jmt, 4))
     R.set_step_kind(False)          # leapfrog steps throughout (switch.h)
     v["u"][..., 2] = 0.0            # (the COMMON blocks outlive a model instance in this process)
+    if tidal is not None:           # COMMON /tdr/ (tidal_kv.h) and what vmixc finds below the bottom level on the first step
+        for name in ("edrm2", "edrs2", "edrk1", "edro1"):
+            v[name][...] = getattr(tidal, name)
+        for name in ("zetar", "ogamma", "gravrho0r", "kappa_h"):
+            S(name, getattr(tidal, name))
+        v["diff_cbt"][...] = oc.diff_cbt_bg[:, :, 1:g.jmt - 1]
+        v["k33"][...] = 0.0
     zus = []
     for n in range(1, nsteps + 1):
         S("itt", n)
@@ -297,7 +306,11 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             R.add_ext_mode(_psi(g, 0), "tau-1")
         R.state()
         R.ref.call("adv_vel", 0, 1, g.jmt, 2, g.imt - 1)
-        R.isopyc(); R.add_k33()
+        R.isopyc()
+        if tidal is not None:
+            R.ref.call("vmixc", 0, 1, g.jmt, 2, g.imt - 1)
+        else:
+            R.add_k33()
         R.setvbc()
         R.tracer()
         _, zu, _ = R.clinic()
@@ -320,7 +333,12 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         R.ref.call("clinic_gpu_flush")      # u(tau+1), u(tau), u(tau-1) of the last step
         u = v["u"]
         last_tau, last_taup1 = np.array(u[..., 1], order="F"), np.array(u[..., 2], order="F")
+        if tidal is not None:
+            return np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale, np.array(v["k33"], order="F")
         return np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale
+    if tidal is not None:
+        return (np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus,
+                np.array(v["k33"], order="F"))
     return np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus
 
 
@@ -404,6 +422,42 @@ def test_fortran_overlays_keep_the_velocities_on_the_device(imt, jmt, km, nsteps
     assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
     assert not np.array_equal(stale[:, :, 1:-1], u_ref[:, :, 1:-1])     # resident for real: the host's copy was stale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False])
+@pytest.mark.parametrize("imt,jmt,km,nsteps", [(14, 14, 6, 9), (102, 102, 19, 5)])
+def test_fortran_overlays_leave_isopyc_and_vmixc_to_the_device(imt, jmt, km, nsteps, exact, monkeypatch):
+    """UVIC_RESIDENT=3 (tracer_gpu.F + clinic_gpu.F + mixing_gpu.F): the host's `isopyc` and `vmixc` -- most of what the
+    host still does per step once `tracer` and `clinic` are served by the device -- are left out on the steps the `tracer`
+    overlay takes; no diff_cbt goes up, the device forms it as vmixc.F does (tidal mixing from the stratification + K33).
+    Against the reference's own loop with its own isopyc and vmixc: zu of every step, the segment averages, T, S and u
+    bit for bit; one step carries a diagnostic switch (both host routines run again, `tracer_cpu` takes their products),
+    one is a time-average step (they run for isopyc's own averages, the step stays on the device)."""
+    import refmodel
+    from uvic29_amd import synthetic
+    if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
+    monkeypatch.setenv("UVIC_RESIDENT", "3")
+    if exact:
+        monkeypatch.setenv("UVIC_EXACT", "1")
+    else:
+        monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc, mom, _, _ = _setup(imt, jmt, km)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    on_host = (nsteps - 4,) if nsteps > 5 else ()
+    tavg = (nsteps - 2,) if nsteps > 5 else (3,)
+    t_ref, u_ref, um_ref, zus, k33_ref = _reference_loop(oc, mom, nsteps, True, on_host=on_host, segment=3, tavg=tavg, tidal=tid)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, on_host=on_host, segment=3, tavg=tavg, tidal=tid)
+    if len(out) != 6:
+        pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+    t, u, um, got, stale, k33_host = out
+    assert len(got) == len(zus)
+    for n, (a, b) in enumerate(zip(got, zus)):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
+    assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
+    assert not np.array_equal(k33_host, k33_ref)        # left out for real: the host's K33 is not the last step's
 
 
 @pytest.mark.gpu

@@ -89,17 +89,20 @@ def _segment_switches(r, it, nseg):
 
 
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("s37", (14, 14, 6))])
-def test_resident_overlay_over_several_steps(cfg, dims, exact, monkeypatch):
+@pytest.mark.parametrize("cfg,dims,level", [("p2", (14, 14, 6), "1"), ("c30", (14, 14, 6), "1"), ("s37", (14, 14, 6), "1"),
+                                            ("p2", (14, 14, 6), "3"), ("c30", (14, 14, 6), "3")])
+def test_resident_overlay_over_several_steps(cfg, dims, level, exact, monkeypatch):
     """UVIC_RESIDENT=1: t stays on the device and rotates there (what loadmw/putmw and the
     ramdrive do on the host); per step only T and S come back, the call returns as soon as they have, the sources and
     the isopycnal tensor of the next step are started ahead inside an ocean segment, and the surface sums of set_sbc
     stay on the device until the segment's last step.  Six steps of the reference's own call sequence in two segments
     of three -- leapfrog, a forward (mixing) step the overlay did not foresee (its look-ahead must be dropped), and one
     step on which the overlay hands the work to the reference routine (every tracer goes down, t(tau+1) comes up) --
-    against the unmodified reference."""
+    against the unmodified reference.  level 3 (UVIC_RESIDENT=3, mixing_gpu.F): with the reference's vmixc (tidal mixing) in
+    the loop, and its isopyc and vmixc left out by the overlay's side on the steps the device takes -- the forward step
+    forms the tensor and diff_cbt inside the step, the handed-over step runs the host's two routines again."""
     _arith(monkeypatch, exact)
-    monkeypatch.setenv("UVIC_RESIDENT", "1")
+    monkeypatch.setenv("UVIC_RESIDENT", level)
     if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
         pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
     import refdriver
@@ -108,6 +111,11 @@ def test_resident_overlay_over_several_steps(cfg, dims, exact, monkeypatch):
     shim = refdriver.RefOcean(oc, shim=True)
     if not hasattr(shim.ref.lib, "tracer_gpu_flush_"):
         pytest.skip("oracle/_ref shim predates the resident mode")
+    if level == "3":
+        if not hasattr(shim.ref.lib, "uvic_mix_on_host_"):
+            pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+        tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+        ref.set_tidal(tid); shim.set_tidal(tid)
     jmt = dims[1]
     # surface boundary conditions: T, S and (with MOBI) three more tracers feed sbc slots (csbc.h: trsbcindex)
     slots = {0: 3, 1: 4}

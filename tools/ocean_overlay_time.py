@@ -2,9 +2,12 @@
 """Wall time per time step of the two Fortran overlays together -- `tracer` then `clinic`, as source/mom/mom.F:389-395
 calls them -- on the 102x102x19 grid (oracle/_ref shim "m2": T and S only; or "t30": option set C built as run/mk.in builds it, with tsiperts on every step
 and ocean segments of four steps), PCIe included, with the velocities shipped on
-every call (UVIC_RESIDENT=1) or resident on the device (UVIC_RESIDENT=2: psi and the wind stress up, zu down).  The host
-routines of the loop (loadmw's add_ext_mode, state, adv_vel, isopyc, setvbc) are run but not timed.
-usage: UVIC_RESIDENT=1|2 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--tavg] [--json]"""
+every call (UVIC_RESIDENT=1) or resident on the device (UVIC_RESIDENT=2: psi and the wind stress up, zu down).  The calls
+of `isopyc` and `vmixc` (mom.F:340-347, with the tidal mixing of run/mk.in) are timed beside them: the reference's own
+routines on one host core, or -- UVIC_RESIDENT=3, mixing_gpu.F -- two calls that return at once because the device forms
+the tensor and diff_cbt itself.  The other host routines of the loop (loadmw's add_ext_mode, state, adv_vel, setvbc) are
+run but not timed.
+usage: UVIC_RESIDENT=1|2|3 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--tavg] [--json]"""
 import os
 import sys
 import time
@@ -39,7 +42,13 @@ v["u"][..., 2] = 0.0
 if cfg == "t30":
     S("nmix", 0); S("ntspos", seg); S("prelyr", float(v["relyr"][0])); S("tsiperts", 1)
     S("timavgperts", 1 if tavg else 0)
-tt, tc = [], []
+tid = synthetic.make_tidal(g, oc.topo, oc.params.kappa_h)
+for nm in ("edrm2", "edrs2", "edrk1", "edro1"):
+    v[nm][...] = getattr(tid, nm)
+for nm in ("zetar", "ogamma", "gravrho0r", "kappa_h"):
+    S(nm, getattr(tid, nm))
+v["diff_cbt"][...] = oc.diff_cbt_bg[:, :, 1:g.jmt - 1]
+tt, tc, tm = [], [], []
 for it in range(1, n + 1):
     S("itt", it)
     if cfg == "t30":
@@ -51,7 +60,11 @@ for it in range(1, n + 1):
         R.add_ext_mode(_psi(g, 0), "tau-1")
     R.state()
     R.ref.call("adv_vel", 0, 1, g.jmt, 2, g.imt - 1)
-    R.isopyc(); R.add_k33(); R.setvbc()
+    tm0 = time.perf_counter()
+    R.isopyc()
+    R.ref.call("vmixc", 0, 1, g.jmt, 2, g.imt - 1)
+    tm.append(time.perf_counter() - tm0)
+    R.setvbc()
     t0 = time.perf_counter()
     R.ref.call("tracer", 0, 2, g.jmt - 1, 2, g.imt - 1)
     t1 = time.perf_counter()
@@ -63,7 +76,7 @@ for it in range(1, n + 1):
 med = lambda x: sorted(x[4:])[len(x[4:]) // 2] * 1e3
 if as_json:
     import json
-    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "steps": n, "cfg": cfg, "time_average_steps": tavg,
+    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "isopyc_vmixc_calls_ms": med(tm), "steps": n, "cfg": cfg, "time_average_steps": tavg,
                       "resident": os.environ.get("UVIC_RESIDENT", "")}))
     sys.exit(0)
-print(f"UVIC_RESIDENT={os.environ.get('UVIC_RESIDENT', '')}: tracer call {med(tt):.3f} ms, clinic call {med(tc):.3f} ms (medians over {n - 4} steps, PCIe included)")
+print(f"UVIC_RESIDENT={os.environ.get('UVIC_RESIDENT', '')}: tracer call {med(tt):.3f} ms, clinic call {med(tc):.3f} ms, isopyc + vmixc calls {med(tm):.3f} ms (medians over {n - 4} steps, PCIe included)")

@@ -42,7 +42,7 @@ UVIC_DEV void adv_vel_vert_column(const uvic_ctx &c, int i, int j) {
 
 // diff_cbt: tidal mixing above the bottom level (an O(km) sum per cell), previous value elsewhere,
 // plus K33; one thread per cell, rows 2..jmt-1, i = 2..imt-1
-UVIC_DEV void vmixc_cell(const uvic_ctx &c, int i, int k, int j) {
+UVIC_DEV double vmixc_cell(const uvic_ctx &c, int i, int k, int j) {
   UV_DIMS(c);
   const int kz = c.kmt[X2(i, j)];
   double d = c.diff_cbt[X3(i, k, j)];
@@ -62,7 +62,9 @@ UVIC_DEV void vmixc_cell(const uvic_ctx &c, int i, int k, int j) {
     const double zkappa = c.ogamma * edr / zn2;
     d = dmax(c.kappa_h, dmin(100., zkappa + c.kappa_h));
   }
-  c.diff_cbt[X3(i, k, j)] = d + c.K33[X3(i, k, j)];
+  d = d + c.K33[X3(i, k, j)];
+  c.diff_cbt[X3(i, k, j)] = d;
+  return d;
 }
 
 }  // namespace uvic

@@ -70,6 +70,7 @@ typedef struct uvic_ctx {
   /* vmixc's two exponentials, tabulated on the host with the C library's exp (the one the reference calls):
    * vmix_e[(k-1)*km + k1-1] = exp((zw(k)-zw(k1))*zetar), vmix_d[k1-1] = 1 - exp(-zetar*zw(k1)); null: exp in the kernel */
   const double *vmix_e, *vmix_d;
+  int vmix_dev;      /* 1: this step's diff_cbt is formed on the device (vmixc_cell) where its inputs are prepared */
   int no_landskip;   /* measurement: 1 = segments without ocean are marched like the others (UVIC_NO_LANDSKIP) */
   int prio;          /* bit 0: MOBI team waves at normal issue priority (UVIC_TEAM_PRIO0); bit 1: this launch at raised priority (the T,S passes) */
 } uvic_ctx;

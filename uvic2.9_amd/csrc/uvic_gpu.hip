@@ -233,8 +233,10 @@ __global__ void __launch_bounds__(256) k_inputs_cell(const uvic_ctx c, double *c
   cf[CF_IDX(CF_VN, q, N3)] = n;
   cf[CF_IDX(CF_VB, q, N3)] = (k < km) ? acc + c.adv_vbtiso[fq] : acc;
   cf[CF_IDX(CF_VS, q, N3)] = (j >= 2) ? c.adv_vnt[q - rowstride] + c.adv_vntiso[q - rowstride] : 0.0;
-  if (j >= 2 && j <= jmt - 1 && i >= 2 && i <= imt - 1 && !SLAB_OUT(c, j) && k <= km - 1)
-    cf[CF_IDX(CF_BV, q, N3)] = c.diff_cbt[q] * c.dzwr[k] * (1.0 - c.aidif);
+  if (j >= 2 && j <= jmt - 1 && i >= 2 && i <= imt - 1 && !SLAB_OUT(c, j)) {
+    const double dcb = c.vmix_dev ? vmixc_cell(c, i, k, j) : c.diff_cbt[q];   // (vmixc on the device: uvic_gpu_overlay_inputs)
+    if (k <= km - 1) cf[CF_IDX(CF_BV, q, N3)] = dcb * c.dzwr[k] * (1.0 - c.aidif);
+  }
 }
 // MOBI's four forcing planes of an ocean segment (light, ice cover, ice and snow thickness) straight out of the caller's
 // page-locked arrays: 4 x imt*jmt doubles at the head of the chain that needs them -- no copy engine, no event between streams
@@ -1716,6 +1718,7 @@ static int state_from_host(uvic_gpu *h, int field) {
 // the host wrote into a time level of t: its land columns are the host's business again (land_clean)
 static void velocity_touched(uvic_gpu *h, int field) {
   if (field == UVIC_F_ZW) h->vmix_tab_ready = false;
+  if (field == UVIC_F_DIFF_CBT) h->ctx.vmix_dev = 0;   // the caller brought this step's diff_cbt itself
   if (field != UVIC_F_ADV_VET && field != UVIC_F_ADV_VNT && field != UVIC_F_ADV_VBT) return;
   for (int q = 0; q < 3; ++q)
     if (h->iso_set[q].for_step >= 0) h->iso_set[q].vel_stale = true;
@@ -1998,6 +2001,11 @@ static int launch_isopyc(uvic_gpu *h, bool may_defer = false) {
       h->iso_set[set].vel_stale = false;
       h->iso_waited = false;   // the T,S stream reads them too: it must not start before this
     }
+    if (h->ctx.vmix_dev) {   // ... the step's own diff_cbt is formed here, from the fields the chain left
+      hipLaunchKernelGGL(k_vmixc, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
+      mark(h, "vmixc");
+      h->iso_waited = false;
+    }
     if (h->ctx.diff_cbt_given && !h->exact) {   // ... and so did the step's own diff_cbt
       hipLaunchKernelGGL(k_coef_bv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
       mark(h, "coef_bv");
@@ -2006,7 +2014,17 @@ static int launch_isopyc(uvic_gpu *h, bool may_defer = false) {
     HIPCHK(hipGetLastError());
     return 0;
   }
-  return launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0);
+  if (int rc = launch_isopyc_on(h, h->ctx, h->coef, h->stream, 0)) return rc;
+  if (h->ctx.vmix_dev) {   // vmixc follows isopyc (mom.F:340-347): diff_cbt, then the coefficient folded from it
+    hipLaunchKernelGGL(k_vmixc, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx);
+    mark(h, "vmixc");
+    if (!h->exact) {
+      hipLaunchKernelGGL(k_coef_bv, dim3(cell_blocks(h, 256)), dim3(256), 0, h->stream, h->ctx, h->coef);
+      mark(h, "coef_bv");
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
 }
 // the time-step integrals of the tracers of `c` on stream `st`: after their pass B, before convection (diagt1, tracer.F:1161)
 static int launch_tsi_rows(uvic_gpu *h, const uvic_ctx &c, hipStream_t st, int sid) {
@@ -3804,7 +3822,13 @@ static int inputs_next_copy(uvic_gpu *h) {
 // formed on the device from adv_vet and adv_vnt, as adv_vel.F:98-127 does on the host (rigid lid: zero at the surface).
 extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const double *adv_vet, const double *adv_vnt, const double *adv_vbt,
                                        const double *diff_cbt, const double *stf, const double *btf) {
-  if (!h || !diff_cbt || !stf || !btf || (!adv_vet) != (!adv_vnt)) return fail_msg("uvic_gpu_overlay_inputs: null argument");
+  if (!h || !stf || !btf || (!adv_vet) != (!adv_vnt)) return fail_msg("uvic_gpu_overlay_inputs: null argument");
+  if (!diff_cbt) {   // vmixc on the device
+    if (!h->have_vmix) return fail_msg("uvic_gpu_overlay_inputs: no diff_cbt given and no uvic_gpu_set_vmix_params for the device to form it");
+    if (!h->ctx.diff_cbt_given) return fail_msg("uvic_gpu_overlay_inputs: no diff_cbt given: set uvic_params.diff_cbt_has_k33 = 1 (vmixc forms all of it)");
+    if (int rc = vmix_tables(h)) return rc;
+  }
+  h->ctx.vmix_dev = diff_cbt ? 0 : 1;
   if (!adv_vet && !(h->in.vel_pending && !h->in.used))
     return fail_msg("uvic_gpu_overlay_inputs: no velocities given and none formed on the device for this step (uvic_gpu_overlay_velocities)");
   const uvic_dims &d = h->d;
@@ -3826,7 +3850,7 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
     HIPCHK(up(sb, dev[1], adv_vnt, (size_t)d.jmt * row));
     I.vel_pending = false;
   }
-  HIPCHK(up(sa, (char *)h->buf[UVIC_F_DIFF_CBT] + (size_t)(jsmw - 1) * row, diff_cbt, (size_t)(jemw - jsmw + 1) * row));
+  if (diff_cbt) HIPCHK(up(sa, (char *)h->buf[UVIC_F_DIFF_CBT] + (size_t)(jsmw - 1) * row, diff_cbt, (size_t)(jemw - jsmw + 1) * row));
   HIPCHK(up(sb, dev[3], stf, 2 * N2 * 8));
   HIPCHK(up(sb, dev[4], btf, 2 * N2 * 8));
   if (adv_vbt && adv_vet) HIPCHK(up(sb, (char *)dev[2] + (size_t)(jsmw - 1) * rowf, adv_vbt, (size_t)(d.jmt - jsmw + 1) * rowf));

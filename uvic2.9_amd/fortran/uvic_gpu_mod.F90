@@ -48,6 +48,9 @@
       integer(c_int), parameter :: F_DXT2R=61, F_DYT2R=62
 !     depth of the T-cell bottoms: vdepth of the convection diagnostics (uvic_gpu_set_tavg)
       integer(c_int), parameter :: F_ZW=63
+!     vmixc on the device (UVIC_RESIDENT=3: mixing_gpu.F): latitudes and tidal energy dissipation rates (tidal_kv.h)
+      integer(c_int), parameter :: F_TLAT=64, F_EDRM2=65, F_EDRS2=66
+      integer(c_int), parameter :: F_EDRK1=67, F_EDRO1=68
 !     baroclinic momentum step (clinic_gpu.F)
       integer(c_int), parameter :: F_U1=59, F_U2=60, F_RHO=69
       integer(c_int), parameter :: F_UM1=70, F_UM2=71, F_UP1=72, F_UP2=73
@@ -62,6 +65,11 @@
       integer(c_int), parameter :: F_SBC_GU=96, F_SBC_GV=97, F_SBC_SU=98
       integer(c_int), parameter :: F_SBC_SV=99, F_SPSIN=100, F_SPCOS=101
       integer(c_int), parameter :: F_PHI=102, F_PSI=103
+
+!     scalars of vmixc (include/uvic_gpu.h: uvic_vmix_params)
+      type, bind(C) :: uvic_vmix_params
+        real(c_double) :: kappa_h, zetar, ogamma, gravrho0r
+      end type uvic_vmix_params
 
 !     scalars of clinic (include/uvic_gpu.h: uvic_clinic_params)
       type, bind(C) :: uvic_clinic_params
@@ -253,6 +261,22 @@
           real(c_double) :: diff_cbt(*), stf(*), btf(*)
           integer(c_int) :: rc
         end function
+        function uvic_gpu_overlay_inputs_p(h, jsmw, jemw, p1, p2, p3, pcbt, stf, btf)                        &
+     &      bind(C,name='uvic_gpu_overlay_inputs') result(rc)
+!         the same entry point by addresses: pcbt = c_null_ptr has the device form diff_cbt itself (vmixc there)
+          import
+          type(c_ptr), value :: h
+          integer(c_int), value :: jsmw, jemw
+          type(c_ptr), value :: p1, p2, p3, pcbt
+          real(c_double) :: stf(*), btf(*)
+          integer(c_int) :: rc
+        end function
+        function uvic_gpu_set_vmix_params(h, p) bind(C,name='uvic_gpu_set_vmix_params') result(rc)
+          import
+          type(c_ptr), value :: h
+          type(uvic_vmix_params) :: p
+          integer(c_int) :: rc
+        end function
         function uvic_gpu_overlay_inputs_vbt(h, jsmw, jemw, adv_vet, adv_vnt, adv_vbt, diff_cbt, stf, btf)   &
      &      bind(C,name='uvic_gpu_overlay_inputs') result(rc)
 !         the same entry point with adv_vbt sent as well (free surface: not zero at the top)
@@ -377,6 +401,10 @@
 !     first overlay called in a step), uvic_u_host_itt the step for which the host's u(tau), u(tau-1) are what the
 !     device holds; uvic_vel_dev_itt the step whose adv_v?t were formed on the device
       logical, save :: uvic_resident_u = .false.
+!     ... and so do isopyc and vmixc (UVIC_RESIDENT=3: uvic_resident_mix; mixing_gpu.F): uvic_mix_skip_itt is the step
+!     on which the host's two routines were left out, so that `tracer` sends no diff_cbt and the device forms its own
+      logical, save :: uvic_resident_mix = .false.
+      integer, save :: uvic_mix_skip_itt = -1
       logical, save :: uvic_u_dev = .false.
       integer, save :: uvic_u_itt = -1, uvic_u_rot_itt = -1, uvic_u_host_itt = -1, uvic_vel_dev_itt = -1
 !     the step after which the device holds the running sums of isbcu/asbcu (clinic.F:729-895)
