@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -265,7 +265,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     what `diag -> avgvar` reads of the memory window after them (t(tau), u(tau), adv_vbt) is appended to the returned list.
     segment: ocean steps per coupling segment (isbcu/asbcu sums of clinic).  tidal: the tidal dissipation fields -- the
     reference's own `vmixc` (tidal mixing + K33) then follows `isopyc` instead of the "+K33" done here; the host's K33
-    after the last step is appended to what a shim run returns (stale where the overlays left isopyc to the device)."""
+    after the last step is appended to what a shim run returns (stale where the overlays left isopyc to the device).
+    tsi: every step a time-step-monitor step (tsiperts, as with the shipped run/control.in); the integrals of every step
+    (tbar, travar, dtabs, ektot) are returned under "tsi" beside the host's K33."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -292,6 +294,11 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             S(name, getattr(tidal, name))
         v["diff_cbt"][...] = oc.diff_cbt_bg[:, :, 1:g.jmt - 1]
         v["k33"][...] = 0.0
+    tsis = []
+    if tsi:
+        S("tsiperts", 1)
+        if "relyr" in v:            # MOBI: the overlay predicts the next step's light from these (switch.F:217-223, tmngr.F:330-367)
+            S("nmix", 0); S("prelyr", float(v["relyr"][0]))
     zus = []
     for n in range(1, nsteps + 1):
         S("itt", n)
@@ -301,6 +308,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             S("trmbts", 1 if n in on_host else 0)
         if tavg:
             S("timavgperts", 1 if n in tavg else 0)
+        if tsi:                     # diagi zeroes them at the start of every step (source/mom/diagi.F:193-205)
+            for name in ("tbar", "travar", "dtabs", "ektot"):
+                v[name][...] = 0.0
         R.add_ext_mode(_psi(g, n), "tau")
         if n == 1:
             R.add_ext_mode(_psi(g, 0), "tau-1")
@@ -315,6 +325,8 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         R.tracer()
         _, zu, _ = R.clinic()
         zus.append(zu)
+        if tsi:
+            tsis.append({name: np.array(v[name], order="F") for name in ("tbar", "travar", "dtabs", "ektot")})
         if segment and n % segment == 0:
             zus.append(np.array(v["sbc"][:, :, np_ - 10:np_ - 6], order="F"))     # the averages the atmosphere reads
         if n in tavg:      # what avgvar (diag.F:138-147) reads next
@@ -335,11 +347,11 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         last_tau, last_taup1 = np.array(u[..., 1], order="F"), np.array(u[..., 2], order="F")
         if tidal is not None:
             return (np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale,
-                    {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F")})
+                    {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis})
         return np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale
     if tidal is not None:
         return (np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus,
-                {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F")})
+                {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis})
     return np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus
 
 
@@ -460,6 +472,52 @@ def test_fortran_overlays_leave_isopyc_and_vmixc_to_the_device(imt, jmt, km, nst
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
     # left out for real: the host's K33 and adv_vnt are not the last step's
     assert not np.array_equal(host["k33"], host_ref["k33"]) and not np.array_equal(host["adv_vnt"], host_ref["adv_vnt"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [True, False])
+def test_fortran_overlays_with_the_shipped_options_and_switches(exact, monkeypatch):
+    """The nearest thing to the shipped run this tree can drive: option set C built as run/mk.in builds it (oracle/_ref "t30":
+    MOBI nt=30 + O_stream_function, O_anisotropic_viscosity, O_ice_evp, O_time_step_monitor, tidal mixing), the switches of
+    run/control.in (tsiperts on every step, ocean segments), both polar filters on, everything resident and isopyc, vmixc,
+    adv_vel left to the device (UVIC_RESIDENT=3) -- mom.F's loop through the three overlays against the reference's own
+    loop: zu, u and the segment averages of every step, T and S, the kinetic-energy integral bit for bit; the MOBI tracers
+    and their integrals to the production tolerance (their sources go through the device's exp/log)."""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 14, 14, 6, 7
+    if not (refmodel.available("t30", imt, jmt, km) and refmodel.available("t30", imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build t30 (reference and shim) did not travel with the tree")
+    monkeypatch.setenv("UVIC_RESIDENT", "3")
+    if exact:
+        monkeypatch.setenv("UVIC_EXACT", "1")
+    else:
+        monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc = synthetic.make_ocean("t30", imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    t_ref, u_ref, um_ref, zus, host_ref = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, tsi=True)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, tsi=True)
+    if len(out) != 6:
+        pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+    t, u, um, got, stale, host = out
+    tol = 1e-11
+    assert len(got) == len(zus)
+    for n, (a, b) in enumerate(zip(got, zus)):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
+    for n, name in enumerate(oc.cfg.tracers):
+        a, b = t[:, :, 1:-1, n], t_ref[:, :, 1:-1, n]
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (name, np.abs(a - b).max())
+    assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
+    for step, (a, b) in enumerate(zip(host["tsi"], host_ref["tsi"])):
+        assert np.abs(b["ektot"]).max() > 0 and np.array_equal(a["ektot"], b["ektot"]), step
+        for name in ("tbar", "travar", "dtabs"):
+            assert np.abs(b[name]).max() > 0
+            assert np.array_equal(a[name][:, :2], b[name][:, :2]), (step, name)          # T and S
+            scale = np.abs(b[name]).max(axis=(0, 2), keepdims=True)
+            assert (np.abs(a[name] - b[name]) <= tol * np.maximum(scale, 1e-300)).all(), (step, name)
+    assert not np.array_equal(host["k33"], host_ref["k33"])
 
 
 @pytest.mark.gpu
