@@ -1160,6 +1160,8 @@ struct uvic_gpu {
   long long step_no;        // counts uvic_gpu_rotate
   hipEvent_t ev_ts_final;   // T and S of this step's t(tau+1) are final (after convection and the polar filter)
   bool ts_final_valid;
+  hipEvent_t ev_ts_filt = nullptr;   // ... filtered on the T,S stream, behind their walk
+  bool ts_filtered = false;          // launch_convect's filter then leaves T and S out
   hipEvent_t ev_step_begin, ev_src_next[2];
   hipEvent_t ev_begin_cur;      // the event that stands for this step's begin: ev_step_begin, or the previous step's end event
   bool idle_until_next;         // the caller has promised that nothing follows the step on the main stream before the next one
@@ -1513,6 +1515,7 @@ extern "C" int uvic_gpu_destroy(uvic_gpu *h) {
   (void)hipStreamDestroy(h->side2);
   (void)hipEventDestroy(h->ev_fct_done);
   (void)hipEventDestroy(h->ev_ts_done);
+  if (h->ev_ts_filt) (void)hipEventDestroy(h->ev_ts_filt);
   for (int q = 0; q < 3; ++q) (void)hipEventDestroy(h->iso_set[q].ev);
   (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1767,6 +1770,24 @@ extern "C" int uvic_gpu_download(uvic_gpu *h, int field, void *host, int64_t off
 }
 
 static double g_xfer_ms = 0.0;   // UVIC_OVL_TIMING: host time spent inside the transfer entry points since the last report
+#if defined(UVIC_EXPERIMENTS)
+// ... and where the host is, in wall time since the first overlay entry point of the step, when it submits the parts of a call
+static std::vector<std::pair<const char *, std::chrono::steady_clock::time_point>> g_stamps;
+static void ovl_stamp(const char *what) {
+  static const bool on = uv_env("UVIC_OVL_TIMING") != nullptr;
+  if (on) g_stamps.emplace_back(what, std::chrono::steady_clock::now());
+}
+static void ovl_stamps_print() {
+  if (g_stamps.empty()) return;
+  fprintf(stderr, "overlay host stamps (us):");
+  for (auto &q : g_stamps) fprintf(stderr, " %s %.0f", q.first, std::chrono::duration<double, std::micro>(q.second - g_stamps[0].second).count());
+  fprintf(stderr, "\n");
+  g_stamps.clear();
+}
+#else
+static inline void ovl_stamp(const char *) {}
+static inline void ovl_stamps_print() {}
+#endif
 struct XferTimer {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   ~XferTimer() { g_xfer_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
@@ -2139,6 +2160,7 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
     mark_on(h, "begin", sid);
     hipLaunchKernelGGL(k_inputs_cell, dim3(cell_blocks(h, 256)), dim3(256), 0, st, cp, h->coef);
     mark_on(h, "inputs_cell", sid);
+    ovl_stamp("inputs_cell");
     if (st != h->stream) {
       HIPCHK(hipEventRecord(h->ev_fct_done, st));
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fct_done, 0));
@@ -2231,13 +2253,27 @@ static int launch_transport(uvic_gpu *h, bool convect_follows) {
       if (int rc = launch_conv_pe(h, cts, h->side_ts, 1)) return rc;
     }
     HIPCHK(hipEventRecord(h->ev_ts_done, h->side_ts));
-    if (h->ts_host && h->flt_nitems == 0) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
+    if (h->flt_nitems > 0) {
+      // the polar filter of T and S (tracer.F:1245, after convection) here, behind their walk: they are final -- and on
+      // their way to a host that waits for them -- while the other tracers are still in their passes
+      uvic_ctx cf = cts;
+      cf.prio = c.prio;
+      hipLaunchKernelGGL(k_filt, dim3((unsigned)h->flt_nitems * 2u), dim3(h->flt_threads), (size_t)(2 * h->flt_threads + 4) * 8, h->side_ts, cf,
+                         (const FilterItem *)h->flt_items, (const double *)h->flt_mats, h->flt_nitems);
+      mark_on(h, "filt_ts", 3);
+      if (!h->ev_ts_filt) HIPCHK(hipEventCreateWithFlags(&h->ev_ts_filt, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(h->ev_ts_filt, h->side_ts));
+      h->ts_filtered = true;
+    }
+    if (h->ts_host) {   // the resident overlay wants T,S of t(tau+1) as soon as they are final
       HIPCHK(hipMemcpyAsync(h->ts_host, c.t_taup1, (size_t)2 * c.imt * c.km * c.jmt * 8, hipMemcpyDeviceToHost, h->side_ts));
       HIPCHK(hipEventRecord(h->ev_ts_host, h->side_ts));
       h->ts_host_queued = true;
+      ovl_stamp("ts_d2h");
     }
     h->ts_ahead = true;
-    if (h->flt_nitems == 0) { h->ev_ts_final = h->ev_ts_done; h->ts_final_valid = true; }
+    h->ev_ts_final = h->ts_filtered ? h->ev_ts_filt : h->ev_ts_done;
+    h->ts_final_valid = true;
     // the other tracers on the main stream: work arrays are indexed from the group's first tracer
     uvic_ctx cr = c;
     cr.n0 = 2; cr.nt_local = c.nt - 2;
@@ -2337,7 +2373,13 @@ static int launch_convect(uvic_gpu *h) {
   if (h->flt_nitems > 0) {   // filt follows convection inside `tracer` (tracer.F:1245); like convection it
     uvic_ctx cf = h->ctx;    // runs on every tracer (under tracer sharding: replicated, after the exchange)
     cf.n0 = 0; cf.nt_local = h->d.nt;
-    hipLaunchKernelGGL(k_filt, dim3((unsigned)h->flt_nitems * (unsigned)h->d.nt), dim3(h->flt_threads),
+    if (h->ts_filtered) {    // T and S had theirs on the T,S stream (launch_transport); the step ends behind it
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ts_filt, 0));
+      cf.n0 = 2; cf.nt_local = h->d.nt - 2;
+      h->ts_filtered = false;
+    }
+    if (cf.nt_local > 0)
+    hipLaunchKernelGGL(k_filt, dim3((unsigned)h->flt_nitems * (unsigned)cf.nt_local), dim3(h->flt_threads),
                        (size_t)(2 * h->flt_threads + 4) * 8, h->stream, cf, (const FilterItem *)h->flt_items,
                        (const double *)h->flt_mats, h->flt_nitems);
     mark(h, "filt");
@@ -2831,6 +2873,7 @@ extern "C" int uvic_gpu_momentum_async(uvic_gpu *h, int sbc_flags, double rts, d
 // copy of the step's inputs the tracer step will read: the uvic_gpu_overlay_inputs that follows leaves adv_vet, adv_vnt out.
 extern "C" int uvic_gpu_overlay_velocities(uvic_gpu *h, int ext_taum1, const double *psi) {
   if (!h || !psi) return fail_msg("uvic_gpu_overlay_velocities: null argument");
+  ovl_stamp("vel_in");
   HIPCHK(hipSetDevice(h->device));
   if (int rc = momentum_stream(h)) return rc;
   if (int rc = mom_host_join(h)) return rc;
@@ -3829,6 +3872,7 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
     if (int rc = vmix_tables(h)) return rc;
   }
   h->ctx.vmix_dev = diff_cbt ? 0 : 1;
+  ovl_stamp("inputs_in");
   if (!adv_vet && !(h->in.vel_pending && !h->in.used))
     return fail_msg("uvic_gpu_overlay_inputs: no velocities given and none formed on the device for this step (uvic_gpu_overlay_velocities)");
   const uvic_dims &d = h->d;
@@ -3866,6 +3910,7 @@ extern "C" int uvic_gpu_overlay_inputs(uvic_gpu *h, int jsmw, int jemw, const do
   I.rest_inflight = true;
   I.derive_vbt = adv_vbt == nullptr || adv_vet == nullptr;
   velocity_touched(h, UVIC_F_ADV_VET);
+  ovl_stamp("inputs_out");
   return 0;
 }
 // the main stream waits for the inputs a step is about to read (every other stream of the step starts behind the main one)
@@ -3893,12 +3938,14 @@ extern "C" int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, do
   HIPCHK(hipSetDevice(h->device));
   static const bool timing = uv_env("UVIC_OVL_TIMING") != nullptr;   // diagnosis: host wall time of the call's parts
   const auto tq0 = std::chrono::steady_clock::now();
+  ovl_stamp("step_in");
   h->ts_host = ts_host;
   h->ts_host_queued = false;
   if (int rc = uvic_gpu_step_lookahead_at(h, s->c2dtts, s->mixing, s->mobi_ahead, s->c2dtts_next, s->relyr_next, s->co2ccn_next, s->iso_ahead))
     return rc;
   h->ts_host = nullptr;
   const auto tq1 = std::chrono::steady_clock::now();
+  ovl_stamp("queued");
   if (h->sbc_count > 0 && (s->sbc_accumulate || s->sbc_zero)) {
     const long long n = (long long)h->d.imt * h->d.jmt * h->sbc_count;
     hipLaunchKernelGGL(k_sbc_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->ctx, (const int *)h->sbc_tracer,
@@ -3918,6 +3965,8 @@ extern "C" int uvic_gpu_overlay_step(uvic_gpu *h, const uvic_overlay_step *s, do
   if (h->in.rest_inflight) { HIPCHK(hipEventSynchronize(h->in.ev_rest)); h->in.rest_inflight = false; }
   if (h->in.forcing_inflight) { HIPCHK(hipEventSynchronize(h->in.ev_forcing)); h->in.forcing_inflight = false; }
   if (timing) {
+    ovl_stamp("returned");
+    ovl_stamps_print();
     const auto tq2 = std::chrono::steady_clock::now();
     fprintf(stderr, "overlay_step: queueing %.3f ms, wait for T,S %.3f ms; row transfers before it %.3f ms\n",
             std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(tq2 - tq1).count(), g_xfer_ms);
