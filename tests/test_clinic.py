@@ -521,6 +521,38 @@ def test_fortran_overlays_with_the_shipped_options_and_switches(exact, monkeypat
 
 
 @pytest.mark.gpu
+def test_full_grid_with_mixing_on_the_device_equals_mixing_on_the_host(monkeypatch):
+    """102x102x19, option set C as run/mk.in builds it, shipped switches, production arithmetic, twelve steps through the three
+    overlays: with isopyc, vmixc and adv_vel left to the device (UVIC_RESIDENT=3) EVERY tracer, u and zu come out bit for bit
+    as with the host's own routines feeding the overlays (UVIC_RESIDENT=2) -- the device's diff_cbt and velocities are the
+    host's, bit for bit, so nothing downstream may differ.  (Level 2 against the reference itself: the tests above.)"""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 102, 102, 19, 12
+    if not refmodel.available("t30", imt, jmt, km, shim=True):
+        pytest.skip("oracle/_ref shim t30 102x102x19 did not travel with the tree")
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc = synthetic.make_ocean("t30", imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    runs = {}
+    for level in ("2", "3"):
+        monkeypatch.setenv("UVIC_RESIDENT", level)
+        out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=4, tidal=tid, tsi=True)
+        if len(out) != 6:
+            pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+        runs[level] = out
+    (t2, u2, um2, zu2, _, h2), (t3, u3, um3, zu3, _, h3) = runs["2"], runs["3"]
+    assert np.isfinite(t3).all() and np.abs(u3).max() > 0.1
+    assert np.array_equal(t2, t3)
+    assert np.array_equal(u2, u3) and np.array_equal(um2, um3)
+    assert all(np.array_equal(a, b) for a, b in zip(zu2, zu3))
+    for a, b in zip(h2["tsi"], h3["tsi"]):
+        assert all(np.array_equal(a[n], b[n]) for n in a)
+    assert not np.array_equal(h2["k33"], h3["k33"])      # (the host's K33: current with level 2, stale with level 3)
+
+
+@pytest.mark.gpu
 def test_gpu_momentum_entry_points_fail_loudly():
     """Misuse is refused with a message, not computed through (the error convention of the C ABI: non-zero status and
     uvic_gpu_last_error)."""
