@@ -149,7 +149,7 @@ def _gpu_model(oc, mom, eos):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("imt,jmt,km", GRIDS)
+@pytest.mark.parametrize("imt,jmt,km", GRIDS + [(23, 17, 6), (38, 101, 19)])       # (the last two: not square, odd)
 def test_gpu_state_and_clinic_equal_oracle(imt, jmt, km):
     oc, mom, eos, flt = _setup(imt, jmt, km)
     rho, M, up, zu = _oracle_step(oc, mom, eos)

@@ -115,7 +115,7 @@ def test_reference_tracer_with_filter_equals_oracle_transport_then_filter():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("exact", [True, False])
-@pytest.mark.parametrize("cfg,imt,jmt,km", GRIDS)
+@pytest.mark.parametrize("cfg,imt,jmt,km", GRIDS + [("p2", 23, 17, 6), ("p2", 38, 101, 19)])     # (not square, odd)
 def test_gpu_tracer_with_filter(cfg, imt, jmt, km, exact):
     import oracle_c
     from uvic29_amd import synthetic

@@ -28,7 +28,9 @@ def _rand_src(oc, seed=2029, scale=1e-9):
 
 
 @pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("c30", (102, 102, 19)),
-                                      ("p2", (202, 202, 32)), ("c30", (202, 202, 32)), ("perf15", (102, 102, 19))])
+                                      ("p2", (202, 202, 32)), ("c30", (202, 202, 32)), ("perf15", (102, 102, 19)),
+                                      # grids that are not square, not multiples of the wave or of anything else
+                                      ("c30", (23, 17, 6)), ("c30", (17, 39, 19)), ("p2", (71, 14, 6)), ("c30", (38, 101, 19))])
 @pytest.mark.parametrize("mode", [False, "columns"])
 def test_one_step_vs_oracle(cfg, dims, mode):
     """mode False: production (T, S through the bit-exact kernels, the others through the column kernels); "columns":

@@ -37,7 +37,8 @@ ISO = ("alphai", "betai", "ddxt", "ddyt", "ddzt", "Ai_ez", "Ai_nz", "Ai_bx", "Ai
        "adv_vetiso", "adv_vbtiso")
 
 
-@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("p2", (102, 102, 19))])
+@pytest.mark.parametrize("cfg,dims", [("p2", (14, 14, 6)), ("c30", (14, 14, 6)), ("p2", (102, 102, 19)),
+                                      ("c30", (23, 17, 6)), ("p2", (17, 39, 19)), ("c30", (71, 14, 6))])   # (odd, non-square grids)
 def test_isopyc_transport_convect_bit_exact_vs_oracle(cfg, dims):
     oc = synthetic.make_ocean(cfg, *dims)
     to, so, c = synthetic.load_eos(dims[2])

@@ -110,7 +110,7 @@ MOBI_RTOL = 1e-11  # per source slot, relative to the slot max; measured on MI35
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims", [(14, 14, 6), (102, 102, 19)])
+@pytest.mark.parametrize("dims", [(14, 14, 6), (102, 102, 19), (23, 17, 6), (38, 101, 19)])   # (the last two: not square, odd)
 def test_gpu_mobi_sources_vs_oracle(dims):
     from uvic29_amd.tracer import TracerModel
     oc = synthetic.make_ocean("c30", *dims)

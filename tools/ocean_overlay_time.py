@@ -7,7 +7,7 @@ of `isopyc` and `vmixc` (mom.F:340-347, with the tidal mixing of run/mk.in) are 
 routines on one host core, or -- UVIC_RESIDENT=3, mixing_gpu.F -- two calls that return at once because the device forms
 the tensor and diff_cbt itself.  The other host routines of the loop (loadmw's add_ext_mode, state, adv_vel, setvbc) are
 run but not timed.
-usage: UVIC_RESIDENT=1|2|3 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--tavg] [--json]"""
+usage: UVIC_RESIDENT=1|2|3 python tools/ocean_overlay_time.py [nsteps [m2|t30]] [--tavg] [--notsi] [--json]"""
 import os
 import sys
 import time
@@ -25,6 +25,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n = int(args[0]) if args else 24
 cfg = args[1] if len(args) > 1 else "m2"       # "t30": option set C built as run/mk.in builds it, tsiperts on every step
 as_json, seg = "--json" in sys.argv, 4
+notsi = "--notsi" in sys.argv                  # t30 without the time-step monitor (tsiint > one step): the call returns with T and S
 tavg = "--tavg" in sys.argv                    # every step a time-average step as well (timavgperts: one year in ten of the shipped run)
 dims = (102, 102, 19)
 oc = synthetic.make_ocean(cfg, *dims)
@@ -40,7 +41,7 @@ v["sbc"][:, :, np_ - 4] = oc.stf[:, :, 0]; v["sbc"][:, :, np_ - 3] = oc.stf[:, :
 R.set_step_kind(False)
 v["u"][..., 2] = 0.0
 if cfg == "t30":
-    S("nmix", 0); S("ntspos", seg); S("prelyr", float(v["relyr"][0])); S("tsiperts", 1)
+    S("nmix", 0); S("ntspos", seg); S("prelyr", float(v["relyr"][0])); S("tsiperts", 0 if notsi else 1)
     S("timavgperts", 1 if tavg else 0)
 tid = synthetic.make_tidal(g, oc.topo, oc.params.kappa_h)
 for nm in ("edrm2", "edrs2", "edrk1", "edro1"):
