@@ -237,6 +237,7 @@ def ocean_overlay_baseline(imt, jmt, km, steps=32):
     host = _tool_json("ocean_overlay_time.py", ["12", "t30"], {"UVIC_RESIDENT": "2"})
     out["host_isopyc_vmixc_ms"] = host["isopyc_vmixc_calls_ms"]
     out["host_adv_vel_ms"] = host["adv_vel_call_ms"]
+    out["host_state_ms"] = host["state_call_ms"]
     out["switches"] = "tsiperts every step (run/control.in: tsiint = tsiper), segments of 4 steps, UVIC_RESIDENT=3"
     return out
 

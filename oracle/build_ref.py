@@ -195,7 +195,7 @@ def build(cfg: str, imt: int, jmt: int, km: int, keep: bool = False, verbose: bo
         if verbose:
             print("  compiled", f.name)
         objs.append(str(o))
-        if shim and f.name in ("tracer.f", "clinic.f", "isopyc.f", "vmixc.f", "adv_vel.f"):
+        if shim and f.name in ("tracer.f", "clinic.f", "isopyc.f", "vmixc.f", "adv_vel.f", "state.f"):
             # keep the reference routine reachable as `tracer_cpu` / `clinic_cpu` / ... (diagnostic time steps)
             nm = f.stem
             rr = run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--redefine-sym", f"{nm}_={nm}_cpu_", str(o)])

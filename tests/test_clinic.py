@@ -347,11 +347,13 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         last_tau, last_taup1 = np.array(u[..., 1], order="F"), np.array(u[..., 2], order="F")
         if tidal is not None:
             return (np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale,
-                    {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis})
+                    {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis,
+                     "rho": np.array(v["rho"], order="F")})
         return np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale
     if tidal is not None:
         return (np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus,
-                {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis})
+                {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis,
+                 "rho": np.array(v["rho"], order="F")})
     return np.array(v["t"][..., 1], order="F"), np.array(v["u"][..., 1], order="F"), np.array(v["u"][..., 0], order="F"), zus
 
 
@@ -442,8 +444,8 @@ def test_fortran_overlays_keep_the_velocities_on_the_device(imt, jmt, km, nsteps
 @pytest.mark.parametrize("imt,jmt,km,nsteps", [(14, 14, 6, 9), (102, 102, 19, 5)])
 def test_fortran_overlays_leave_isopyc_and_vmixc_to_the_device(imt, jmt, km, nsteps, exact, monkeypatch):
     """UVIC_RESIDENT=3 (tracer_gpu.F + clinic_gpu.F + mixing_gpu.F): the host's `isopyc` and `vmixc` -- most of what the
-    host still does per step once `tracer` and `clinic` are served by the device -- and `adv_vel` are left out on the steps
-    the `tracer` overlay takes; no diff_cbt goes up, the device forms it as vmixc.F does (tidal mixing from the stratification + K33).
+    host still does per step once `tracer` and `clinic` are served by the device -- `adv_vel` and loadmw's `state` are left
+    out on the steps the `tracer` overlay takes; no diff_cbt goes up, the device forms it as vmixc.F does (tidal mixing from the stratification + K33).
     Against the reference's own loop with its own isopyc and vmixc: zu of every step, the segment averages, T, S and u
     bit for bit; one step carries a diagnostic switch (both host routines run again, `tracer_cpu` takes their products),
     one is a time-average step (they run for isopyc's own averages, the step stays on the device)."""
@@ -470,8 +472,9 @@ def test_fortran_overlays_leave_isopyc_and_vmixc_to_the_device(imt, jmt, km, nst
         assert np.array_equal(a, b), n
     assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
-    # left out for real: the host's K33 and adv_vnt are not the last step's
+    # left out for real: the host's K33, adv_vnt and rho are not the last step's
     assert not np.array_equal(host["k33"], host_ref["k33"]) and not np.array_equal(host["adv_vnt"], host_ref["adv_vnt"])
+    assert not np.array_equal(host["rho"], host_ref["rho"])
 
 
 @pytest.mark.gpu

@@ -49,7 +49,7 @@ for nm in ("edrm2", "edrs2", "edrk1", "edro1"):
 for nm in ("zetar", "ogamma", "gravrho0r", "kappa_h"):
     S(nm, getattr(tid, nm))
 v["diff_cbt"][...] = oc.diff_cbt_bg[:, :, 1:g.jmt - 1]
-tt, tc, tm, ta = [], [], [], []
+tt, tc, tm, ta, tst = [], [], [], [], []
 for it in range(1, n + 1):
     S("itt", it)
     if cfg == "t30":
@@ -59,7 +59,9 @@ for it in range(1, n + 1):
     R.add_ext_mode(_psi(g, it), "tau")
     if it == 1:
         R.add_ext_mode(_psi(g, 0), "tau-1")
+    ts0 = time.perf_counter()
     R.state()
+    tst.append(time.perf_counter() - ts0)
     ta0 = time.perf_counter()
     R.ref.call("adv_vel", 0, 1, g.jmt, 2, g.imt - 1)
     ta.append(time.perf_counter() - ta0)
@@ -79,7 +81,7 @@ for it in range(1, n + 1):
 med = lambda x: sorted(x[4:])[len(x[4:]) // 2] * 1e3
 if as_json:
     import json
-    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "isopyc_vmixc_calls_ms": med(tm), "adv_vel_call_ms": med(ta), "steps": n, "cfg": cfg, "time_average_steps": tavg,
+    print(json.dumps({"tracer_call_ms": med(tt), "clinic_call_ms": med(tc), "isopyc_vmixc_calls_ms": med(tm), "adv_vel_call_ms": med(ta), "state_call_ms": med(tst), "steps": n, "cfg": cfg, "time_average_steps": tavg,
                       "resident": os.environ.get("UVIC_RESIDENT", "")}))
     sys.exit(0)
-print(f"UVIC_RESIDENT={os.environ.get('UVIC_RESIDENT', '')}: tracer call {med(tt):.3f} ms, clinic call {med(tc):.3f} ms, isopyc + vmixc calls {med(tm):.3f} ms, adv_vel call {med(ta):.3f} ms (medians over {n - 4} steps, PCIe included)")
+print(f"UVIC_RESIDENT={os.environ.get('UVIC_RESIDENT', '')}: tracer call {med(tt):.3f} ms, clinic call {med(tc):.3f} ms, isopyc + vmixc calls {med(tm):.3f} ms, adv_vel call {med(ta):.3f} ms, state call {med(tst):.3f} ms (medians over {n - 4} steps, PCIe included)")

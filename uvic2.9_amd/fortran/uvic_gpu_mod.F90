@@ -405,6 +405,11 @@
 !     on which the host's two routines were left out, so that `tracer` sends no diff_cbt and the device forms its own
       logical, save :: uvic_resident_mix = .false.
       integer, save :: uvic_mix_skip_itt = -1
+!     ... and loadmw's `state` (rho of t(tau) for clinic, loadmw.F:154): left out on the step uvic_state_skip_itt; whoever
+!     turns out to need the host's rho after all (clinic_gpu.F on the steps it hands to clinic_cpu or takes from the host's
+!     arrays) calls uvic_host_rho first, which has the reference's routine run then (mixing_gpu.F: uvic_state_replay)
+      integer, save :: uvic_state_skip_itt = -1
+      procedure(), pointer, save :: uvic_state_replay_p => null()
       logical, save :: uvic_u_dev = .false.
       integer, save :: uvic_u_itt = -1, uvic_u_rot_itt = -1, uvic_u_host_itt = -1, uvic_vel_dev_itt = -1
 !     the step after which the device holds the running sums of isbcu/asbcu (clinic.F:729-895)
@@ -416,6 +421,15 @@
       real(c_double), allocatable, save :: uvic_sbc_plane(:,:,:)
 
       contains
+
+      subroutine uvic_host_rho(itt)
+!       the host's rho is about to be read: form it now if loadmw's `state` was left out on this step
+        integer, intent(in) :: itt
+        if (uvic_state_skip_itt .eq. itt .and. associated(uvic_state_replay_p)) then
+          call uvic_state_replay_p()
+        endif
+        uvic_state_skip_itt = -1
+      end subroutine
 
       function uvic_addr(a) result(p)
 !       the address of a COMMON array (which has no TARGET attribute of its own) for an optional argument of the C ABI
