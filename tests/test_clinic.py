@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=()):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -267,7 +267,10 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     reference's own `vmixc` (tidal mixing + K33) then follows `isopyc` instead of the "+K33" done here; the host's K33
     after the last step is appended to what a shim run returns (stale where the overlays left isopyc to the device).
     tsi: every step a time-step-monitor step (tsiperts, as with the shipped run/control.in); the integrals of every step
-    (tbar, travar, dtabs, ektot) are returned under "tsi" beside the host's K33."""
+    (tbar, travar, dtabs, ektot) are returned under "tsi" beside the host's K33.  gyre: steps with gyrets set, which only the
+    `tracer` overlay hands to the reference routine (`clinic` stays on the device -- or, on step 1, finds no device instance
+    yet and goes to the reference routine as well).  glen: steps with glents set, which only the `clinic` overlay hands to
+    the reference routine."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -308,6 +311,10 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             S("trmbts", 1 if n in on_host else 0)
         if tavg:
             S("timavgperts", 1 if n in tavg else 0)
+        if gyre:
+            S("gyrets", 1 if n in gyre else 0)
+        if glen:
+            S("glents", 1 if n in glen else 0)
         if tsi:                     # diagi zeroes them at the start of every step (source/mom/diagi.F:193-205)
             for name in ("tbar", "travar", "dtabs", "ektot"):
                 v[name][...] = 0.0
@@ -475,6 +482,36 @@ def test_fortran_overlays_leave_isopyc_and_vmixc_to_the_device(imt, jmt, km, nst
     # left out for real: the host's K33, adv_vnt and rho are not the last step's
     assert not np.array_equal(host["k33"], host_ref["k33"]) and not np.array_equal(host["adv_vnt"], host_ref["adv_vnt"])
     assert not np.array_equal(host["rho"], host_ref["rho"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["2", "3"])
+def test_fortran_overlays_when_the_run_opens_on_the_host(level, monkeypatch):
+    """A run whose FIRST step the `tracer` overlay hands to the reference routine (here: gyrets; an Euler backward start or
+    tavgts do the same): no device instance exists when `clinic` is called, which then takes the reference routine too
+    instead of stopping; the device comes in at step 2.  Another such step in mid-run: `tracer_cpu` with the tracers brought
+    down, `clinic` on the device (which then takes the advective velocities from the host: nobody formed them on the
+    device).  And the converse, a step only `clinic` hands over (glents): `tracer` on the device, u brought down for
+    `clinic_cpu`, u(tau+1) back up.  With UVIC_RESIDENT=3 the host's isopyc, vmixc, adv_vel, state run on exactly the steps
+    that need them.  Everything bit for bit against the reference's own loop."""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 14, 14, 6, 8
+    if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
+    monkeypatch.setenv("UVIC_RESIDENT", level)
+    monkeypatch.setenv("UVIC_EXACT", "1")
+    oc, mom, _, _ = _setup(imt, jmt, km)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
+    if len(out) != 6:
+        pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+    t, u, um, got, _, _ = out
+    for n, (a, b) in enumerate(zip(got, zus)):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1], t_ref[:, :, 1:-1])
+    assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
 
 
 @pytest.mark.gpu
