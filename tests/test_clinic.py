@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=()):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=()):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -270,7 +270,8 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     (tbar, travar, dtabs, ektot) are returned under "tsi" beside the host's K33.  gyre: steps with gyrets set, which only the
     `tracer` overlay hands to the reference routine (`clinic` stays on the device -- or, on step 1, finds no device instance
     yet and goes to the reference routine as well).  glen: steps with glents set, which only the `clinic` overlay hands to
-    the reference routine."""
+    the reference routine.  forward: forward ("mixing") steps -- c2dt = dt and, as loadmw does for the wide-open window
+    (loadmw.F:99-102), the index taum1 aliased to tau for the step."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -315,6 +316,11 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             S("gyrets", 1 if n in gyre else 0)
         if glen:
             S("glents", 1 if n in glen else 0)
+        if forward:
+            fwd = n in forward
+            R.set_step_kind(fwd)
+            S("c2dtuv", mom.dtuv if fwd else 2.0 * mom.dtuv)
+            S("taum1", 0 if fwd else -1)          # (mw.h: the time levels are indexed -1:1)
         if tsi:                     # diagi zeroes them at the start of every step (source/mom/diagi.F:193-205)
             for name in ("tbar", "travar", "dtabs", "ektot"):
                 v[name][...] = 0.0
@@ -336,6 +342,8 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             tsis.append({name: np.array(v[name], order="F") for name in ("tbar", "travar", "dtabs", "ektot")})
         if segment and n % segment == 0:
             zus.append(np.array(v["sbc"][:, :, np_ - 10:np_ - 6], order="F"))     # the averages the atmosphere reads
+        if forward and n in forward:
+            S("taum1", -1)
         if n in tavg:      # what avgvar (diag.F:138-147) reads next
             zus.append(np.array(v["t"][:, :, 1:-1, :, 1], order="F"))
             zus.append(np.array(v["u"][:, :, 1:-1, :, 1], order="F"))
@@ -505,6 +513,33 @@ def test_fortran_overlays_when_the_run_opens_on_the_host(level, monkeypatch):
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
     t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
     out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
+    if len(out) != 6:
+        pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+    t, u, um, got, _, _ = out
+    for n, (a, b) in enumerate(zip(got, zus)):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1], t_ref[:, :, 1:-1])
+    assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", ["2", "3"])
+def test_fortran_overlays_through_forward_steps(level, monkeypatch):
+    """Forward ("mixing") steps in mid-run -- every nmix-th step of the shipped run -- with everything resident: the `tracer`
+    overlay has the device read t(tau) as t(tau-1) and brings u down (the host's adv_vel runs again on it), `clinic` takes
+    the step from the host's arrays and u(tau+1) stays on the device for the leapfrog steps that follow.  Against the
+    reference's own loop, bit for bit."""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 14, 14, 6, 9
+    if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
+    monkeypatch.setenv("UVIC_RESIDENT", level)
+    monkeypatch.setenv("UVIC_EXACT", "1")
+    oc, mom, _, _ = _setup(imt, jmt, km)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, forward=(4, 7))
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, forward=(4, 7))
     if len(out) != 6:
         pytest.skip("oracle/_ref shim predates mixing_gpu.F")
     t, u, um, got, _, _ = out
