@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=()):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -271,7 +271,8 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     `tracer` overlay hands to the reference routine (`clinic` stays on the device -- or, on step 1, finds no device instance
     yet and goes to the reference routine as well).  glen: steps with glents set, which only the `clinic` overlay hands to
     the reference routine.  forward: forward ("mixing") steps -- c2dt = dt and, as loadmw does for the wide-open window
-    (loadmw.F:99-102), the index taum1 aliased to tau for the step."""
+    (loadmw.F:99-102), the index taum1 aliased to tau for the step; nmix: what the overlay predicts the next step's kind
+    from (switch.F:217-223: a mixing step when mod(itt, nmix) = 1)."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -303,6 +304,8 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         S("tsiperts", 1)
         if "relyr" in v:            # MOBI: the overlay predicts the next step's light from these (switch.F:217-223, tmngr.F:330-367)
             S("nmix", 0); S("prelyr", float(v["relyr"][0]))
+    if nmix is not None:
+        S("nmix", nmix)
     zus = []
     for n in range(1, nsteps + 1):
         S("itt", n)
@@ -494,7 +497,8 @@ def test_fortran_overlays_leave_isopyc_and_vmixc_to_the_device(imt, jmt, km, nst
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("level", ["2", "3"])
-def test_fortran_overlays_when_the_run_opens_on_the_host(level, monkeypatch):
+@pytest.mark.parametrize("exact", [False, True])
+def test_fortran_overlays_when_the_run_opens_on_the_host(exact, level, monkeypatch):
     """A run whose FIRST step the `tracer` overlay hands to the reference routine (here: gyrets; an Euler backward start or
     tavgts do the same): no device instance exists when `clinic` is called, which then takes the reference routine too
     instead of stopping; the device comes in at step 2.  Another such step in mid-run: `tracer_cpu` with the tracers brought
@@ -508,7 +512,10 @@ def test_fortran_overlays_when_the_run_opens_on_the_host(level, monkeypatch):
     if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
         pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
     monkeypatch.setenv("UVIC_RESIDENT", level)
-    monkeypatch.setenv("UVIC_EXACT", "1")
+    if exact:
+        monkeypatch.setenv("UVIC_EXACT", "1")
+    else:
+        monkeypatch.delenv("UVIC_EXACT", raising=False)
     oc, mom, _, _ = _setup(imt, jmt, km)
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
     t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
@@ -523,29 +530,41 @@ def test_fortran_overlays_when_the_run_opens_on_the_host(level, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg,nmix", [("m2", 0), ("m2", 3), ("t30", 0), ("t30", 3)])
 @pytest.mark.parametrize("level", ["2", "3"])
-def test_fortran_overlays_through_forward_steps(level, monkeypatch):
+@pytest.mark.parametrize("exact", [False, True])
+def test_fortran_overlays_through_forward_steps(exact, level, cfg, nmix, monkeypatch):
     """Forward ("mixing") steps in mid-run -- every nmix-th step of the shipped run -- with everything resident: the `tracer`
     overlay has the device read t(tau) as t(tau-1) and brings u down (the host's adv_vel runs again on it), `clinic` takes
-    the step from the host's arrays and u(tau+1) stays on the device for the leapfrog steps that follow.  Against the
-    reference's own loop, bit for bit."""
+    the step from the host's arrays and u(tau+1) stays on the device for the leapfrog steps that follow.  nmix = 3: the
+    overlay sees them coming (no look-ahead into them); nmix = 0: it does not, and drops what it computed ahead.  T and S
+    only (m2) and option set C with the time-step monitor on every step (t30).  Against the reference's own loop: T, S, u,
+    zu bit for bit, the other tracers to the production tolerance."""
     import refmodel
     from uvic29_amd import synthetic
     imt, jmt, km, nsteps = 14, 14, 6, 9
-    if not (refmodel.available("m2", imt, jmt, km) and refmodel.available("m2", imt, jmt, km, shim=True)):
-        pytest.skip("oracle/_ref build m2 (reference and shim) did not travel with the tree")
+    if not (refmodel.available(cfg, imt, jmt, km) and refmodel.available(cfg, imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build %s (reference and shim) did not travel with the tree" % cfg)
     monkeypatch.setenv("UVIC_RESIDENT", level)
-    monkeypatch.setenv("UVIC_EXACT", "1")
-    oc, mom, _, _ = _setup(imt, jmt, km)
+    if exact:
+        monkeypatch.setenv("UVIC_EXACT", "1")
+    else:       # the production schedule: T,S on their own stream, look-ahead chains, relaxed ordering
+        monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
-    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, forward=(4, 7))
-    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, forward=(4, 7))
+    kw = dict(segment=3, tidal=tid, forward=(4, 7), nmix=nmix, tsi=(cfg == "t30"))
+    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, **kw)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, **kw)
     if len(out) != 6:
         pytest.skip("oracle/_ref shim predates mixing_gpu.F")
     t, u, um, got, _, _ = out
     for n, (a, b) in enumerate(zip(got, zus)):
         assert np.array_equal(a, b), n
-    assert np.array_equal(t[:, :, 1:-1], t_ref[:, :, 1:-1])
+    assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
+    for n, name in enumerate(oc.cfg.tracers):
+        a, b = t[:, :, 1:-1, n], t_ref[:, :, 1:-1, n]
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (name, np.abs(a - b).max())
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
 
 
