@@ -150,6 +150,64 @@ def test_resident_overlay_over_several_steps(cfg, dims, level, exact, monkeypatc
             assert np.abs(x - y).max() <= PROD_TOL * np.abs(y).max(), (slot, name, np.abs(x - y).max())
 
 
+@pytest.mark.parametrize("level", ["1", "3"])
+@pytest.mark.parametrize("cfg,dims", [("c30", (14, 14, 6)), ("s37", (14, 14, 6)), ("c30", (102, 102, 19))])
+def test_resident_overlay_takes_new_forcing_at_every_segment(cfg, dims, level, monkeypatch):
+    """Between two ocean segments the atmosphere and the ice model change what MOBI reads of them -- the short-wave
+    radiation, ice cover, ice and snow thickness (light under ice, tracer.F:355-420) and the atmospheric CO2 -- and the
+    first step of the new segment computes its sources in line from the new fields (the overlay fetches them from the
+    caller's arrays: k_pull4).  Three segments of three steps, every one with its own forcing, against the unmodified
+    reference with the same changes; production arithmetic."""
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    monkeypatch.setenv("UVIC_RESIDENT", level)
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    ref = refdriver.RefOcean(oc)
+    shim = refdriver.RefOcean(oc, shim=True)
+    if not hasattr(shim.ref.lib, "tracer_gpu_flush_"):
+        pytest.skip("oracle/_ref shim predates the resident mode")
+    if level == "3":
+        if not hasattr(shim.ref.lib, "uvic_mix_on_host_"):
+            pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+        tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+        ref.set_tidal(tid); shim.set_tidal(tid)
+    imt, jmt = dims[0], dims[1]
+    f = oc.forcing
+    ii, jj = np.meshgrid(np.arange(imt), np.arange(jmt), indexing="ij")
+    for it in range(1, 10):
+        seg = (it - 1) // 3
+        for r in (ref, shim):
+            r.set_step_kind(False)
+            _segment_switches(r, it, 3)
+            if (it - 1) % 3 == 0:      # what the coupler does between segments (the same for both)
+                r.v["dnswr"][...] = f.dnswr * (1.0 + 0.25 * seg) * (1.0 + 0.1 * np.sin(0.3 * ii + seg))
+                r.v["aice"][:, :, 1] = np.clip(f.aice + 0.3 * seg * (np.cos(0.2 * jj) > 0.5), 0.0, 1.0)
+                r.v["hice"][:, :, 1] = f.hice + 20.0 * seg * (r.v["aice"][:, :, 1] > 0)
+                r.v["hsno"][:, :, 1] = f.hsno + 5.0 * seg * (r.v["aice"][:, :, 1] > 0)
+                r.ref.set("co2ccn", f.co2ccn + 40.0 * seg)
+        want = ref.step().copy()
+        got = shim.step().copy()
+        assert np.array_equal(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2]), it
+        ref.rotate(); shim.rotate()
+    shim.flush()
+    a, b = np.array(shim.v["t"][..., 1]), np.array(ref.v["t"][..., 1])     # (copies: one library = one set of COMMON blocks)
+    for n, name in enumerate(oc.cfg.tracers):
+        x, y = a[:, :, 1:jmt - 1, n], b[:, :, 1:jmt - 1, n]
+        assert np.abs(x - y).max() <= PROD_TOL * np.abs(y).max(), (name, np.abs(x - y).max())
+    # the forcing mattered: the same run with the first segment's forcing throughout ends elsewhere
+    ref2 = refdriver.RefOcean(oc)
+    if level == "3":
+        ref2.set_tidal(tid)
+    for it in range(1, 10):
+        ref2.set_step_kind(False)
+        _segment_switches(ref2, it, 3)
+        ref2.step()
+        ref2.rotate()
+    assert not np.allclose(ref2.v["t"][:, 0, 1:jmt - 1, 2:, 1], b[:, 0, 1:jmt - 1, 2:], rtol=1e-6, atol=0.0)
+
+
 def test_resident_overlay_back_to_back_on_the_full_grid(monkeypatch):
     """The resident overlay on 102x102x19 with option set C, sixteen steps in segments of four with NOTHING between the calls
     but the reference's own step -- long enough kernels and a busy enough device for the overlay's asynchronous schedule to
