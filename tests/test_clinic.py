@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None, vary=False):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -272,7 +272,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     yet and goes to the reference routine as well).  glen: steps with glents set, which only the `clinic` overlay hands to
     the reference routine.  forward: forward ("mixing") steps -- c2dt = dt and, as loadmw does for the wide-open window
     (loadmw.F:99-102), the index taum1 aliased to tau for the step; nmix: what the overlay predicts the next step's kind
-    from (switch.F:217-223: a mixing step when mod(itt, nmix) = 1)."""
+    from (switch.F:217-223: a mixing step when mod(itt, nmix) = 1).  vary: the surface heat and salt fluxes and the wind
+    stress (sbc planes, which setvbc turns into stf and smf) differ from step to step -- the device copies of the step's
+    inputs are taken in turn, a stale one would show."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -324,6 +326,12 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             R.set_step_kind(fwd)
             S("c2dtuv", mom.dtuv if fwd else 2.0 * mom.dtuv)
             S("taum1", 0 if fwd else -1)          # (mw.h: the time levels are indexed -1:1)
+        if vary:
+            w = 1.0 + 0.2 * np.sin(1.7 * n)
+            v["sbc"][:, :, np_ - 4] = oc.stf[:, :, 0] * w
+            v["sbc"][:, :, np_ - 3] = oc.stf[:, :, 1] * (2.0 - w)
+            v["sbc"][:, :, int(R.ref.get("itaux")) - 1] = mom.smf[..., 0] * (2.0 - w)
+            v["sbc"][:, :, int(R.ref.get("itauy")) - 1] = mom.smf[..., 1] * w
         if tsi:                     # diagi zeroes them at the start of every step (source/mom/diagi.F:193-205)
             for name in ("tbar", "travar", "dtabs", "ektot"):
                 v[name][...] = 0.0
@@ -518,8 +526,8 @@ def test_fortran_overlays_when_the_run_opens_on_the_host(exact, level, monkeypat
         monkeypatch.delenv("UVIC_EXACT", raising=False)
     oc, mom, _, _ = _setup(imt, jmt, km)
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
-    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
-    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,))
+    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,), vary=True)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, gyre=(1, 4), glen=(6,), vary=True)
     if len(out) != 6:
         pytest.skip("oracle/_ref shim predates mixing_gpu.F")
     t, u, um, got, _, _ = out
@@ -553,7 +561,7 @@ def test_fortran_overlays_through_forward_steps(exact, level, cfg, nmix, monkeyp
     oc = synthetic.make_ocean(cfg, imt, jmt, km)
     mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
-    kw = dict(segment=3, tidal=tid, forward=(4, 7), nmix=nmix, tsi=(cfg == "t30"))
+    kw = dict(segment=3, tidal=tid, forward=(4, 7), nmix=nmix, tsi=(cfg == "t30"), vary=True)
     t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, **kw)
     out = _reference_loop(oc, mom, nsteps, True, shim=True, **kw)
     if len(out) != 6:
@@ -590,8 +598,8 @@ def test_fortran_overlays_with_the_shipped_options_and_switches(exact, monkeypat
     oc = synthetic.make_ocean("t30", imt, jmt, km)
     mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
-    t_ref, u_ref, um_ref, zus, host_ref = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, tsi=True)
-    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, tsi=True)
+    t_ref, u_ref, um_ref, zus, host_ref = _reference_loop(oc, mom, nsteps, True, segment=3, tidal=tid, tsi=True, vary=True)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=3, tidal=tid, tsi=True, vary=True)
     if len(out) != 6:
         pytest.skip("oracle/_ref shim predates mixing_gpu.F")
     t, u, um, got, stale, host = out
@@ -632,7 +640,7 @@ def test_full_grid_with_mixing_on_the_device_equals_mixing_on_the_host(monkeypat
     runs = {}
     for level in ("2", "3"):
         monkeypatch.setenv("UVIC_RESIDENT", level)
-        out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=4, tidal=tid, tsi=True)
+        out = _reference_loop(oc, mom, nsteps, True, shim=True, segment=4, tidal=tid, tsi=True, vary=True)
         if len(out) != 6:
             pytest.skip("oracle/_ref shim predates mixing_gpu.F")
         runs[level] = out
