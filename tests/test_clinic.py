@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None, vary=False):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None, vary=False, perturb=()):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -274,7 +274,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     (loadmw.F:99-102), the index taum1 aliased to tau for the step; nmix: what the overlay predicts the next step's kind
     from (switch.F:217-223: a mixing step when mod(itt, nmix) = 1).  vary: the surface heat and salt fluxes and the wind
     stress (sbc planes, which setvbc turns into stf and smf) differ from step to step -- the device copies of the step's
-    inputs are taken in turn, a stale one would show."""
+    inputs are taken in turn, a stale one would show.  perturb: after these steps the HOST changes t and u (as a restart
+    read or a nudging term would); a shim run brings its copies up to date first (clinic_gpu_flush, tracer_gpu_flush) and
+    says so afterwards (tracer_gpu_invalidate)."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -359,10 +361,23 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             zus.append(np.array(v["t"][:, :, 1:-1, :, 1], order="F"))
             zus.append(np.array(v["u"][:, :, 1:-1, :, 1], order="F"))
             zus.append(np.array(v["adv_vbt"][:, :, :-1], order="F"))
+        resident = shim and hasattr(R.ref.lib, "tracer_gpu_invalidate_")
+        if n in perturb and resident:
+            R.ref.call("clinic_gpu_flush")          # u(tau+1), u(tau), u(tau-1) of this step into their slots
         R.rotate()
         u = v["u"]
         u[..., 0] = u[..., 1]
         u[..., 1] = u[..., 2]
+        if n in perturb:
+            if resident:
+                R.ref.call("tracer_gpu_flush")      # t(tau-1), t(tau) of the coming step
+            b1 = 1.0 + 1e-3 * np.sin(np.arange(g.imt))
+            b1[0], b1[-1] = b1[-2], b1[1]           # (the cyclic image columns stay images)
+            bump = b1[:, None, None, None]
+            v["t"][..., 1] *= bump
+            v["u"][..., 1] *= bump
+            if resident:
+                R.ref.call("tracer_gpu_invalidate")
     if shim and hasattr(R.ref.lib, "clinic_gpu_flush_"):
         # resident overlays: what the device holds for the coming step, into the host's (already rotated) slots
         stale = np.array(v["u"][..., 1], order="F")
@@ -535,6 +550,42 @@ def test_fortran_overlays_when_the_run_opens_on_the_host(exact, level, monkeypat
         assert np.array_equal(a, b), n
     assert np.array_equal(t[:, :, 1:-1], t_ref[:, :, 1:-1])
     assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["m2", "t30"])
+@pytest.mark.parametrize("level", ["1", "2", "3"])
+def test_fortran_overlays_when_the_host_changes_the_state(level, cfg, monkeypatch):
+    """In mid-run the host changes t and u between two steps (a restart read, nudging, assimilation).  With the state
+    resident the caller brings the host copies up to date first (clinic_gpu_flush, tracer_gpu_flush), makes its change and
+    says so (tracer_gpu_invalidate): the next step takes its time levels from the host's arrays and drops what the device
+    had computed ahead from its own.  Against the reference's loop with the same change; production arithmetic."""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 14, 14, 6, 8
+    if not (refmodel.available(cfg, imt, jmt, km) and refmodel.available(cfg, imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build %s (reference and shim) did not travel with the tree" % cfg)
+    monkeypatch.setenv("UVIC_RESIDENT", level)
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    kw = dict(segment=3, tidal=tid, tsi=(cfg == "t30"), vary=True, perturb=(3, 5))
+    t_ref, u_ref, um_ref, zus, _ = _reference_loop(oc, mom, nsteps, True, **kw)
+    out = _reference_loop(oc, mom, nsteps, True, shim=True, **kw)
+    if len(out) != 6 or not hasattr(__import__("refdriver").RefOcean(oc, shim=True).ref.lib, "tracer_gpu_invalidate_"):
+        pytest.skip("oracle/_ref shim predates tracer_gpu_invalidate")
+    t, u, um, got, _, _ = out
+    for n, (a, b) in enumerate(zip(got, zus)):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
+    for n, name in enumerate(oc.cfg.tracers):
+        a, b = t[:, :, 1:-1, n], t_ref[:, :, 1:-1, n]
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (name, np.abs(a - b).max())
+    if level == "1":    # (u is the host's own all along: its tau slot after the last rotation is the reference's)
+        assert np.array_equal(um[:, :, 1:-1], u_ref[:, :, 1:-1])
+    else:
+        assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
 
 
 @pytest.mark.gpu
