@@ -107,3 +107,45 @@ def test_hundred_steps_against_the_reference():
         for name, dmax, p999 in rows:
             assert p999 <= P999_TOL, (how + " vs exact", name, p999)
             assert dmax <= MAX_TOL[how], (how + " vs exact", name, dmax)
+
+
+def test_hundred_steps_through_the_fortran_overlay(monkeypatch):
+    """The same 100 steps where the north star puts them: behind the reference's own `tracer` call, through the Fortran
+    overlay (tracer_gpu.F -> ISO_C_BINDING -> the library), tracers resident, production arithmetic, ocean segments of four
+    steps, the forward step every 16th seen coming by the overlay (switch.F:217-223) -- against the committed golden of the
+    compiled reference's run: integrals to 1e-12, the sample columns to 1e-12 of max|t| for every tracer."""
+    import refmodel
+    from uvic29_amd import synthetic
+    import make_golden_run100 as mg
+    if not refmodel.available("c30", 102, 102, 19, shim=True):
+        pytest.skip("oracle/_ref shim c30 102x102x19 did not travel with the tree")
+    import refdriver
+    monkeypatch.setenv("UVIC_RESIDENT", "1")
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    oc = synthetic.make_ocean("c30")
+    gold = np.load(GOLD / "run_c30_102x102x19_n100.npz")
+    ro = refdriver.RefOcean(oc, shim=True)
+    if not hasattr(ro.ref.lib, "tracer_gpu_flush_"):
+        pytest.skip("oracle/_ref shim predates the resident mode")
+    nmix, seg = oc.params.nmix, 4
+    S = ro.ref.set
+    S("nmix", nmix); S("ntspos", seg); S("prelyr", float(ro.v["relyr"][0]))
+    for it in range(1, 101):
+        ro.set_step_kind((it % nmix) == 0)          # the golden run's forward steps: 16, 32, ...
+        S("itt", it + 1)                            # ... which switch.F puts at mod(itt, nmix) = 1
+        S("osegs", 1 if (it - 1) % seg == 0 else 0); S("osege", 1 if it % seg == 0 else 0)
+        ro.step()
+        ro.rotate()
+    ro.flush()
+    got = np.array(ro.v["t"][..., 1], order="F")
+    assert np.isfinite(got).all()
+    tb, tv = mg.integrals(oc, got)
+    rb = np.abs(tb - gold["tbar"]) / np.abs(gold["tbar"])
+    rv = np.abs(tv - gold["travar"]) / np.abs(gold["travar"])
+    print(f"overlay: integrals tbar {rb.max():.2e} travar {rv.max():.2e}")
+    assert rb.max() <= INTEGRAL_TOL and rv.max() <= INTEGRAL_TOL, (rb.max(), rv.max())
+    cols = np.stack([got[i - 1, :, j - 1, :] for i, j in zip(gold["cols_i"], gold["cols_j"])])
+    dc = np.abs(cols - gold["cols"]).max(axis=(0, 1)) / gold["tmax"]
+    print(f"overlay: sample columns max {dc.max():.2e} ({oc.cfg.tracers[int(dc.argmax())]})")
+    assert dc.max() <= MAX_TOL["production"], dc
+    assert np.array_equal(cols[..., :2], gold["cols"][..., :2])      # T and S: the reference's bits after 100 steps
