@@ -649,7 +649,7 @@ def test_fortran_overlays_with_the_shipped_options_and_switches(exact, monkeypat
     oc = synthetic.make_ocean("t30", imt, jmt, km)
     mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
     tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
-    kw = dict(segment=3, tidal=tid, tsi=True, vary=True, tavg=(5,), forward=(4,), nmix=3)
+    kw = dict(segment=3, tidal=tid, tsi=True, vary=True, tavg=(4, 5), forward=(4,), nmix=3)      # (step 4: forward AND time-average)
     t_ref, u_ref, um_ref, zus, host_ref = _reference_loop(oc, mom, nsteps, True, **kw)
     out = _reference_loop(oc, mom, nsteps, True, shim=True, **kw)
     if len(out) != 6:
