@@ -385,7 +385,10 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         v["u"][..., 2] = 0.0
         R.ref.call("clinic_gpu_flush")      # u(tau+1), u(tau), u(tau-1) of the last step
         u = v["u"]
-        last_tau, last_taup1 = np.array(u[..., 1], order="F"), np.array(u[..., 2], order="F")
+        if np.any(u[..., 2] != 0.0):
+            last_tau, last_taup1 = np.array(u[..., 1], order="F"), np.array(u[..., 2], order="F")
+        else:      # the last step left u with the host (a forward step, a step of the reference routines): nothing to bring down
+            last_tau, last_taup1 = np.array(u[..., 0], order="F"), np.array(u[..., 1], order="F")
         if tidal is not None:
             return (np.array(v["t"][..., 1], order="F"), last_taup1, last_tau, zus, stale,
                     {"k33": np.array(v["k33"], order="F"), "adv_vnt": np.array(v["adv_vnt"], order="F"), "tsi": tsis,
@@ -586,6 +589,65 @@ def test_fortran_overlays_when_the_host_changes_the_state(level, cfg, monkeypatc
         assert np.array_equal(um[:, :, 1:-1], u_ref[:, :, 1:-1])
     else:
         assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]) and np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1])
+
+
+def _compare_runs(oc, ref_out, shim_out, level, tol=1e-11):
+    """zu, segment averages and what a time-average step leaves on the host: bit for bit (t of the tracers other than T, S
+    to `tol` of its maximum); t, u after the last step likewise."""
+    t_ref, u_ref, um_ref, zus, _ = ref_out
+    t, u, um, got, _, _ = shim_out
+    assert len(got) == len(zus)
+    for n, (a, b) in enumerate(zip(got, zus)):
+        if a.ndim == 4 and a.shape[-1] == oc.cfg.nt and oc.cfg.nt > 2:
+            assert np.array_equal(a[..., :2], b[..., :2]), n
+            scale = np.abs(b).max(axis=(0, 1, 2), keepdims=True)
+            assert (np.abs(a - b) <= tol * scale).all(), n
+        else:
+            assert np.array_equal(a, b), n
+    assert np.array_equal(t[:, :, 1:-1, :2], t_ref[:, :, 1:-1, :2])
+    for n, name in enumerate(oc.cfg.tracers):
+        a, b = t[:, :, 1:-1, n], t_ref[:, :, 1:-1, n]
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (name, np.abs(a - b).max())
+    if level == "1" and not np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]):      # (u is the host's own all along)
+        assert np.array_equal(um[:, :, 1:-1], u_ref[:, :, 1:-1])
+    else:
+        assert np.array_equal(u[:, :, 1:-1], u_ref[:, :, 1:-1]), "u(tau+1) of the last step"
+        assert np.array_equal(um[:, :, 1:-1], um_ref[:, :, 1:-1]), "u(tau) of the last step"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 1 + int(__import__("os").environ.get("UVIC_TEST_SCHEDULES", "8"))))
+@pytest.mark.parametrize("cfg", ["m2", "t30"])
+@pytest.mark.parametrize("level", ["1", "2", "3"])
+def test_fortran_overlays_random_schedules(level, cfg, seed, monkeypatch):
+    """Twelve steps whose kinds are drawn at random (fixed seeds): forward steps, time-average steps, steps both overlays
+    hand to the reference routines (trmbts), steps only `tracer` (gyrets) or only `clinic` (glents) hands over, and changes of
+    t and u by the host in between -- in whatever combination the draw gives, from the first step on.  Production arithmetic,
+    surface fluxes and wind changing every step, segments of three steps; against the reference's own loop."""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 14, 14, 6, 12
+    if not (refmodel.available(cfg, imt, jmt, km) and refmodel.available(cfg, imt, jmt, km, shim=True)):
+        pytest.skip("oracle/_ref build %s (reference and shim) did not travel with the tree" % cfg)
+    monkeypatch.setenv("UVIC_RESIDENT", level)
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    rng = np.random.default_rng(1000 * seed + 7)
+    steps = np.arange(1, nsteps + 1)
+    draw = lambda p: tuple(int(n) for n in steps[rng.random(nsteps) < p])
+    kw = dict(segment=3, tsi=(cfg == "t30"), vary=True, nmix=int(rng.integers(0, 5)),
+              forward=draw(0.2), tavg=draw(0.25), on_host=draw(0.12), gyre=draw(0.12), glen=draw(0.12),
+              perturb=tuple(n for n in draw(0.15) if n < nsteps))
+    oc = synthetic.make_ocean(cfg, imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
+    kw["tidal"] = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    ref_out = _reference_loop(oc, mom, nsteps, True, **kw)
+    shim_out = _reference_loop(oc, mom, nsteps, True, shim=True, **kw)
+    if len(shim_out) != 6:
+        pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+    try:
+        _compare_runs(oc, ref_out, shim_out, level)
+    except AssertionError as e:
+        raise AssertionError("schedule %r: %s" % ({k: v for k, v in kw.items() if k != "tidal"}, e))
 
 
 @pytest.mark.gpu
