@@ -208,6 +208,60 @@ def test_resident_overlay_takes_new_forcing_at_every_segment(cfg, dims, level, m
     assert not np.allclose(ref2.v["t"][:, 0, 1:jmt - 1, 2:, 1], b[:, 0, 1:jmt - 1, 2:], rtol=1e-6, atol=0.0)
 
 
+@pytest.mark.parametrize("seed", range(1, 1 + int(__import__("os").environ.get("UVIC_TEST_SCHEDULES", "6"))))
+@pytest.mark.parametrize("cfg", ["c30", "s37"])
+@pytest.mark.parametrize("level", ["1", "3"])
+def test_resident_overlay_random_schedules(level, cfg, seed, monkeypatch):
+    """`tracer` alone, sixteen steps whose kinds are drawn at random (fixed seeds): forward steps seen coming or not (nmix),
+    steps handed to the reference routine, time-average steps, segments of random length each with its own atmosphere and
+    ice fields.  T and S of every step bit for bit, every tracer after the last step to the production tolerance."""
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    monkeypatch.setenv("UVIC_RESIDENT", level)
+    dims = (14, 14, 6)
+    if not (refmodel.available(cfg, *dims) and refmodel.available(cfg, *dims, shim=True)):
+        pytest.skip("oracle/_ref reference/shim libraries did not travel with the tree")
+    import refdriver
+    oc = synthetic.make_ocean(cfg, *dims)
+    ref = refdriver.RefOcean(oc)
+    shim = refdriver.RefOcean(oc, shim=True)
+    if not hasattr(shim.ref.lib, "uvic_mix_on_host_"):
+        pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+    tid = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    ref.set_tidal(tid); shim.set_tidal(tid)
+    rng = np.random.default_rng(77 * seed + 5)
+    nsteps, seg, nmix = 16, int(rng.integers(2, 6)), int(rng.integers(0, 5))
+    forward = rng.random(nsteps + 1) < 0.2
+    on_host = rng.random(nsteps + 1) < 0.15
+    tavg = rng.random(nsteps + 1) < 0.2
+    imt, jmt = dims[0], dims[1]
+    f = oc.forcing
+    ii, jj = np.meshgrid(np.arange(imt), np.arange(jmt), indexing="ij")
+    what = dict(seg=seg, nmix=nmix, forward=np.flatnonzero(forward).tolist(), on_host=np.flatnonzero(on_host).tolist(),
+                tavg=np.flatnonzero(tavg).tolist())
+    for it in range(1, nsteps + 1):
+        k = (it - 1) // seg
+        for r in (ref, shim):
+            r.set_step_kind(bool(forward[it]))
+            r.ref.set("euler2", 1 if on_host[it] else 0)
+            r.ref.set("timavgperts", 1 if tavg[it] else 0)
+            _segment_switches(r, it, seg)
+            r.ref.set("nmix", nmix)
+            if (it - 1) % seg == 0:
+                r.v["dnswr"][...] = f.dnswr * (1.0 + 0.1 * (k % 3)) * (1.0 + 0.1 * np.sin(0.3 * ii + k))
+                r.v["aice"][:, :, 1] = np.clip(f.aice + 0.2 * (k % 3) * (np.cos(0.2 * jj) > 0.5), 0.0, 1.0)
+                r.v["hice"][:, :, 1] = f.hice + 10.0 * (k % 3) * (r.v["aice"][:, :, 1] > 0)
+                r.ref.set("co2ccn", f.co2ccn + 10.0 * k)
+        want = ref.step().copy()
+        got = shim.step().copy()
+        assert np.array_equal(got[:, :, 1:jmt - 1, :2], want[:, :, 1:jmt - 1, :2]), (it, what)
+        ref.rotate(); shim.rotate()
+    shim.flush()
+    a, b = np.array(shim.v["t"][..., 1]), np.array(ref.v["t"][..., 1])
+    for n, name in enumerate(oc.cfg.tracers):
+        x, y = a[:, :, 1:jmt - 1, n], b[:, :, 1:jmt - 1, n]
+        assert np.abs(x - y).max() <= PROD_TOL * np.abs(y).max(), (name, np.abs(x - y).max(), what)
+
+
 def test_resident_overlay_back_to_back_on_the_full_grid(monkeypatch):
     """The resident overlay on 102x102x19 with option set C, sixteen steps in segments of four with NOTHING between the calls
     but the reference's own step -- long enough kernels and a busy enough device for the overlay's asynchronous schedule to

@@ -403,6 +403,9 @@
       logical, save :: uvic_resident_u = .false.
 !     ... and so do isopyc and vmixc (UVIC_RESIDENT=3: uvic_resident_mix; mixing_gpu.F): uvic_mix_skip_itt is the step
 !     on which the host's two routines were left out, so that `tracer` sends no diff_cbt and the device forms its own
+!     the atmosphere and ice fields MOBI reads change at a segment's first step; if that step went to the reference routine the
+!     device has not seen them yet
+      logical, save :: uvic_forcing_stale = .false.
       logical, save :: uvic_resident_mix = .false.
       integer, save :: uvic_mix_skip_itt = -1
 !     ... and loadmw's `state` (rho of t(tau) for clinic, loadmw.F:154): left out on the step uvic_state_skip_itt; whoever
