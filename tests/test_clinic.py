@@ -620,7 +620,7 @@ def _compare_runs(oc, ref_out, shim_out, level, tol=1e-11):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(1, 1 + int(__import__("os").environ.get("UVIC_TEST_SCHEDULES", "8"))))
 @pytest.mark.parametrize("cfg", ["m2", "t30"])
-@pytest.mark.parametrize("level", ["1", "2", "3"])
+@pytest.mark.parametrize("level", ["0", "1", "2", "3"])
 def test_fortran_overlays_random_schedules(level, cfg, seed, monkeypatch):
     """Twelve steps whose kinds are drawn at random (fixed seeds): forward steps, time-average steps, steps both overlays
     hand to the reference routines (trmbts), steps only `tracer` (gyrets) or only `clinic` (glents) hands over, and changes of
@@ -631,7 +631,10 @@ def test_fortran_overlays_random_schedules(level, cfg, seed, monkeypatch):
     imt, jmt, km, nsteps = 14, 14, 6, int(__import__("os").environ.get("UVIC_TEST_SCHEDULE_STEPS", "12"))
     if not (refmodel.available(cfg, imt, jmt, km) and refmodel.available(cfg, imt, jmt, km, shim=True)):
         pytest.skip("oracle/_ref build %s (reference and shim) did not travel with the tree" % cfg)
-    monkeypatch.setenv("UVIC_RESIDENT", level)
+    if level == "0":      # the default: nothing resident, every call moves the state both ways
+        monkeypatch.delenv("UVIC_RESIDENT", raising=False)
+    else:
+        monkeypatch.setenv("UVIC_RESIDENT", level)
     monkeypatch.delenv("UVIC_EXACT", raising=False)
     rng = np.random.default_rng(1000 * seed + 7)
     steps = np.arange(1, nsteps + 1)
