@@ -747,6 +747,51 @@ def test_fortran_overlays_with_the_shipped_options_and_switches(exact, monkeypat
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(1, 1 + int(__import__("os").environ.get("UVIC_TEST_FULL_SCHEDULES", "2"))))
+def test_full_grid_random_schedule_resident_equals_not_resident(seed, monkeypatch):
+    """102x102x19, option set C as run/mk.in builds it, time-step monitor on every step: a randomly drawn schedule of
+    sixteen steps (forward, time-average, handed-over steps, a change of the state by the host, new atmosphere and ice
+    fields every segment) with everything resident and asynchronous (UVIC_RESIDENT=3: look-ahead chains, relaxed ordering,
+    copies beside the kernels -- at this size the kernels are long enough for a wrong dependency to show) against the same
+    schedule with nothing resident (every call moves the state both ways and waits): every tracer, u, zu and the integrals
+    bit for bit, since the arithmetic is the same.  (The non-resident mode against the reference itself: the small grids.)"""
+    import refmodel
+    from uvic29_amd import synthetic
+    imt, jmt, km, nsteps = 102, 102, 19, 16
+    if not refmodel.available("t30", imt, jmt, km, shim=True):
+        pytest.skip("oracle/_ref shim t30 102x102x19 did not travel with the tree")
+    monkeypatch.delenv("UVIC_EXACT", raising=False)
+    rng = np.random.default_rng(4242 + seed)
+    steps = np.arange(1, nsteps + 1)
+    draw = lambda p: tuple(int(n) for n in steps[rng.random(nsteps) < p])
+    kw = dict(segment=4, tsi=True, vary=True, nmix=int(rng.integers(0, 5)), forward=draw(0.2), tavg=draw(0.2), on_host=draw(0.1),
+              gyre=draw(0.1), glen=draw(0.1), perturb=tuple(n for n in draw(0.1) if n < nsteps))
+    oc = synthetic.make_ocean("t30", imt, jmt, km)
+    mom = synthetic.make_momentum(oc.grid, oc.topo, oc.u, anisotropic=True)
+    kw["tidal"] = synthetic.make_tidal(oc.grid, oc.topo, oc.params.kappa_h)
+    runs = {}
+    for level in ("0", "3"):
+        if level == "0":
+            monkeypatch.delenv("UVIC_RESIDENT", raising=False)
+        else:
+            monkeypatch.setenv("UVIC_RESIDENT", level)
+        out = _reference_loop(oc, mom, nsteps, True, shim=True, **kw)
+        if len(out) != 6:
+            pytest.skip("oracle/_ref shim predates mixing_gpu.F")
+        runs[level] = out
+    (t0, u0, um0, zu0, _, h0), (t3, u3, um3, zu3, _, h3) = runs["0"], runs["3"]
+    what = {k: v for k, v in kw.items() if k != "tidal"}
+    assert np.isfinite(t3).all(), what
+    assert len(zu0) == len(zu3)
+    for n, (a, b) in enumerate(zip(zu0, zu3)):
+        assert np.array_equal(a, b), (n, what)
+    assert np.array_equal(t0, t3), what
+    assert np.array_equal(u0, u3) and np.array_equal(um0, um3), what
+    for a, b in zip(h0["tsi"], h3["tsi"]):
+        assert all(np.array_equal(a[n], b[n]) for n in a), what
+
+
+@pytest.mark.gpu
 def test_full_grid_with_mixing_on_the_device_equals_mixing_on_the_host(monkeypatch):
     """102x102x19, option set C as run/mk.in builds it, shipped switches, production arithmetic, twelve steps through the three
     overlays: with isopyc, vmixc and adv_vel left to the device (UVIC_RESIDENT=3) EVERY tracer, u and zu come out bit for bit
