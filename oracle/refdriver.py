@@ -87,6 +87,11 @@ class RefOcean:
         S("diff_cet", prm.diff_cet); S("diff_cnt", prm.diff_cnt); S("ah", prm.diff_cet)
         S("taum1", -1); S("tau", 0); S("taup1", 1)
         S("eots", 1); S("first", 1); S("euler2", 0)
+        # one library = one set of COMMON blocks per process: a new instance starts from plain leapfrog steps with every
+        # diagnostic switch off, whatever the instance before it left behind
+        S("euler1", 0); S("forward", 0); S("leapfrog", 1)
+        for n in ("tavgts", "trmbts", "gyrets", "glents", "xbtperts", "timavgperts", "tsiperts", "stabts", "cmixts", "osegs", "osege"):
+            S(n, 0)
         S("relyr", oc.forcing.relyr)
         S("jfrst", jmt + 1)            # polar filter off
         for n in ("xt", "yt", "xu", "yu", "zw", "zt", "dxtdeg", "dytdeg", "dzt", "dxudeg", "dyudeg", "dzw",

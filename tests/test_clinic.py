@@ -256,7 +256,7 @@ def _psi(g, n):
     return p
 
 
-def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None, vary=False, perturb=()):
+def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0, tavg=(), tidal=None, tsi=False, gyre=(), glen=(), forward=(), nmix=None, vary=False, perturb=(), clock=False):
     """mom.F's loop through the compiled reference's own routines (oracle/_ref build "m2"): add_ext_mode, state, adv_vel,
     isopyc, "+K33", setvbc, tracer, clinic; the time levels of t and u rotated as the memory window does.
     shim: the same loop with `tracer` and `clinic` replaced by the package's Fortran overlays (the host-side routines still
@@ -276,7 +276,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
     stress (sbc planes, which setvbc turns into stf and smf) differ from step to step -- the device copies of the step's
     inputs are taken in turn, a stale one would show.  perturb: after these steps the HOST changes t and u (as a restart
     read or a nudging term would); a shim run brings its copies up to date first (clinic_gpu_flush, tracer_gpu_flush) and
-    says so afterwards (tracer_gpu_invalidate)."""
+    says so afterwards (tracer_gpu_invalidate).  clock: relyr advances every step (the overlay extrapolates it for the
+    sources it computes ahead and accepts its guess when it is right to rounding: runs that are compared bit for bit between
+    two modes of the overlay keep the clock still)."""
     import refdriver
     g = oc.grid
     R = refdriver.RefOcean(oc, shim=shim)
@@ -304,10 +306,9 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         v["diff_cbt"][...] = oc.diff_cbt_bg[:, :, 1:g.jmt - 1]
         v["k33"][...] = 0.0
     tsis = []
-    if tsi:
-        S("tsiperts", 1)
-        if "relyr" in v:            # MOBI: the overlay predicts the next step's light from these (switch.F:217-223, tmngr.F:330-367)
-            S("nmix", 0); S("prelyr", float(v["relyr"][0]))
+    S("tsiperts", 1 if tsi else 0)
+    if "relyr" in v:                # MOBI: the overlay predicts the next step's light from these (switch.F:217-223, tmngr.F:330-367)
+        S("nmix", 0); S("prelyr", float(v["relyr"][0]))
     if nmix is not None:
         S("nmix", nmix)
     zus = []
@@ -315,19 +316,15 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
         S("itt", n)
         if segment:
             S("osegs", 1 if (n - 1) % segment == 0 else 0); S("osege", 1 if n % segment == 0 else 0)
-        if on_host:
-            S("trmbts", 1 if n in on_host else 0)
-        if tavg:
-            S("timavgperts", 1 if n in tavg else 0)
-        if gyre:
-            S("gyrets", 1 if n in gyre else 0)
-        if glen:
-            S("glents", 1 if n in glen else 0)
-        if forward:
-            fwd = n in forward
-            R.set_step_kind(fwd)
-            S("c2dtuv", mom.dtuv if fwd else 2.0 * mom.dtuv)
-            S("taum1", 0 if fwd else -1)          # (mw.h: the time levels are indexed -1:1)
+        # (every switch on every step: the COMMON blocks outlive the model instances of a process)
+        S("trmbts", 1 if n in on_host else 0)
+        S("timavgperts", 1 if n in tavg else 0)
+        S("gyrets", 1 if n in gyre else 0)
+        S("glents", 1 if n in glen else 0)
+        fwd = n in forward
+        R.set_step_kind(fwd)
+        S("c2dtuv", mom.dtuv if fwd else 2.0 * mom.dtuv)
+        S("taum1", 0 if fwd else -1)          # (mw.h: the time levels are indexed -1:1)
         if vary and segment and "dnswr" in v and (n - 1) % segment == 0:
             # ... and at a segment's first step the atmosphere and ice fields MOBI reads (the coupler runs between segments)
             kseg = (n - 1) // segment
@@ -336,6 +333,10 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             v["aice"][:, :, 1] = np.clip(fo.aice + 0.2 * (kseg % 3) * (np.cos(0.2 * np.arange(g.jmt)) > 0.5)[None, :], 0.0, 1.0)
             v["hice"][:, :, 1] = fo.hice + 10.0 * (kseg % 3) * (v["aice"][:, :, 1] > 0)
             S("co2ccn", fo.co2ccn + 10.0 * kseg)
+        if clock and "relyr" in v:      # the model's clock advances (tmngr.F:330-367), here across a month boundary
+            dyr = oc.params.dtts / (365.0 * 86400.0)
+            S("prelyr", (1.0 / 12.0 + (n - 5.3) * dyr) % 1.0)
+            v["relyr"][...] = (1.0 / 12.0 + (n - 4.3) * dyr) % 1.0
         if vary:
             w = 1.0 + 0.2 * np.sin(1.7 * n)
             v["sbc"][:, :, np_ - 4] = oc.stf[:, :, 0] * w
@@ -363,7 +364,7 @@ def _reference_loop(oc, mom, nsteps, filters, shim=False, on_host=(), segment=0,
             tsis.append({name: np.array(v[name], order="F") for name in ("tbar", "travar", "dtabs", "ektot")})
         if segment and n % segment == 0:
             zus.append(np.array(v["sbc"][:, :, np_ - 10:np_ - 6], order="F"))     # the averages the atmosphere reads
-        if forward and n in forward:
+        if n in forward:
             S("taum1", -1)
         if n in tavg:      # what avgvar (diag.F:138-147) reads next
             zus.append(np.array(v["t"][:, :, 1:-1, :, 1], order="F"))
@@ -639,7 +640,7 @@ def test_fortran_overlays_random_schedules(level, cfg, seed, monkeypatch):
     rng = np.random.default_rng(1000 * seed + 7)
     steps = np.arange(1, nsteps + 1)
     draw = lambda p: tuple(int(n) for n in steps[rng.random(nsteps) < p])
-    kw = dict(segment=int(rng.integers(2, 5)), tsi=(cfg == "t30"), vary=True, nmix=int(rng.integers(0, 5)),
+    kw = dict(segment=int(rng.integers(2, 5)), tsi=(cfg == "t30"), vary=True, clock=True, nmix=int(rng.integers(0, 5)),
               forward=draw(0.2), tavg=draw(0.25), on_host=draw(0.12), gyre=draw(0.12), glen=draw(0.12),
               perturb=tuple(n for n in draw(0.15) if n < nsteps))
     oc = synthetic.make_ocean(cfg, imt, jmt, km)

@@ -239,8 +239,13 @@ def test_resident_overlay_random_schedules(level, cfg, seed, monkeypatch):
     imt, jmt = dims[0], dims[1]
     f = oc.forcing
     ii, jj = np.meshgrid(np.arange(imt), np.arange(jmt), indexing="ij")
+    # the model's clock advances every step (tmngr.F:330-367); the month of the dust field and the solar declination follow it
+    # (tracer.F:311-338), and the overlay computes the next step's sources ahead with the clock it expects then: start near a
+    # month boundary, near the end of the year (relyr wraps: the guess is wrong once and must be caught), or anywhere
+    dyr = oc.params.dtts / (365.0 * 86400.0)
+    start = [1.0 / 12.0 - 3.3 * dyr, 1.0 - 4.2 * dyr, 0.4][int(rng.integers(0, 3))]
     what = dict(seg=seg, nmix=nmix, forward=np.flatnonzero(forward).tolist(), on_host=np.flatnonzero(on_host).tolist(),
-                tavg=np.flatnonzero(tavg).tolist())
+                tavg=np.flatnonzero(tavg).tolist(), clock=start)
     for it in range(1, nsteps + 1):
         k = (it - 1) // seg
         for r in (ref, shim):
@@ -249,6 +254,8 @@ def test_resident_overlay_random_schedules(level, cfg, seed, monkeypatch):
             r.ref.set("timavgperts", 1 if tavg[it] else 0)
             _segment_switches(r, it, seg)
             r.ref.set("nmix", nmix)
+            r.ref.set("prelyr", (start + (it - 2) * dyr) % 1.0 if it > 1 else (start - dyr) % 1.0)
+            r.v["relyr"][...] = (start + (it - 1) * dyr) % 1.0
             if (it - 1) % seg == 0:
                 r.v["dnswr"][...] = f.dnswr * (1.0 + 0.1 * (k % 3)) * (1.0 + 0.1 * np.sin(0.3 * ii + k))
                 r.v["aice"][:, :, 1] = np.clip(f.aice + 0.2 * (k % 3) * (np.cos(0.2 * jj) > 0.5), 0.0, 1.0)
