@@ -166,7 +166,10 @@ def test_config5_four_slabs_refined_grid_nt30(tmp_path):
 
 
 @pytest.mark.parametrize("decomp,world,grid", [("tracer", 2, (14, 14, 6)), ("slab", 2, (14, 14, 6)), ("slab", 4, (102, 102, 19)),
-                                               ("tracer", 4, (102, 102, 19))])
+                                               ("tracer", 4, (102, 102, 19)),
+                                               # rank counts that divide neither the rows nor the tracers evenly
+                                               ("slab", 3, (102, 102, 19)), ("tracer", 3, (14, 14, 6)), ("tracer", 5, (102, 102, 19)),
+                                               ("slab", 6, (102, 102, 19))])
 def test_direct_push_between_processes_on_one_gpu(tmp_path, decomp, world, grid):
     """The library's own exchange (uvic_gpu_push_*): each rank's pack kernel writes straight into the receive window its
     peer exported through hipIpc, raises the peer's arrival counter, and waits on the device for its own -- no
